@@ -1,0 +1,425 @@
+"""Pure-PyTorch fp32 CPU restatement of the reference's ViT-B/16 + AVT-h training path.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).  Every function cites the reference location
+(paths are relative to the upstream facebookresearch/AVT checkout) whose arithmetic it restates.  The
+ViT lives in the un-vendored dependency ``timm==0.4.12`` (env.yaml:302) and GPT-2 in
+``transformers==4.2.2`` (env.yaml:183); their published algorithms are restated here and pinned by
+``oracle/make_golden.py`` against (a) the reference's own modules imported in the build container
+(BaseModel / AVTh / Basic / BasicLossAccuracy / MultiDimCrossEntropy / Warmup / CosineLR, with the
+installed HF ``GPT2Model`` underneath) and (b) HF ``ViTModel`` as an independent implementation of the
+same ViT architecture.  Pin status: head + losses + schedulers pinned to the imported reference
+(tests/golden/*.npz); ViT arithmetic "parity pinned to an independent implementation, not to timm
+itself" (timm is not installable here).
+
+State-dict names and shapes are identical to the reference's (timm naming under ``backbone.model.``,
+HF naming under ``future_predictor.gpt_model.`` with Conv1D weights stored (in, out)).
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------------------
+# ViT (timm 0.4.12 vision_transformer.py semantics; call sites models/video_classification.py:224,255)
+# --------------------------------------------------------------------------------------------------
+class _PatchEmbed(nn.Module):
+    def __init__(self, dim, patch=16, in_chans=3):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, dim, kernel_size=patch, stride=patch)
+
+    def forward(self, x):
+        return self.proj(x).flatten(2).transpose(1, 2)  # (N, 196, D)
+
+
+class _ViTAttention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.scale = (dim // heads) ** -0.5
+        self.qkv = nn.Linear(dim, 3 * dim, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        n, s, d = x.shape
+        qkv = self.qkv(x).reshape(n, s, 3, self.num_heads, d // self.num_heads).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        att = (q @ k.transpose(-2, -1)) * self.scale
+        att = att.softmax(dim=-1)
+        out = (att @ v).transpose(1, 2).reshape(n, s, d)
+        return self.proj(out)
+
+
+class _ViTMlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(F.gelu(self.fc1(x)))  # exact (erf) GELU
+
+
+class _ViTBlock(nn.Module):
+    def __init__(self, dim, heads, mlp_ratio=4):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _ViTAttention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _ViTMlp(dim, dim * mlp_ratio)
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
+
+
+class OracleViT(nn.Module):
+    """timm ``VisionTransformer(num_classes=0)``: returns the CLS token after the final LayerNorm."""
+    def __init__(self, embed_dim=768, depth=12, num_heads=12, img=224, patch=16):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.patch_embed = _PatchEmbed(embed_dim, patch)
+        num_patches = (img // patch) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        self.blocks = nn.ModuleList([_ViTBlock(embed_dim, num_heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+
+    def forward(self, x):
+        x = self.patch_embed(x)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
+        for blk in self.blocks:
+            x = blk(x)
+        return self.norm(x)[:, 0]
+
+
+VIT_CONFIGS = {
+    # name -> (embed_dim, depth, heads); conf/model/backbone/avt_b.yaml:3, avt_b_in21k.yaml:3
+    'vit_base_patch16_224': (768, 12, 12),
+    'vit_base_patch16_224_in21k': (768, 12, 12),
+    'vit_large_patch16_224': (1024, 24, 16),
+    'vit_large_patch16_224_in21k': (1024, 24, 16),
+}
+
+
+class OracleTIMMModel(nn.Module):
+    """models/video_classification.py:249-257 (TIMMModel) + :213-238 (process_each_frame)."""
+    def __init__(self, num_classes=None, model_type='vit_base_patch16_224', vit=None):
+        super().__init__()
+        del num_classes
+        self.model = vit if vit is not None else OracleViT(*VIT_CONFIGS[model_type])
+
+    @property
+    def output_dim(self):
+        return self.model.embed_dim
+
+    def forward(self, video):  # (N, C, T, H, W) -> (N, D, T, 1, 1)
+        n, t = video.size(0), video.size(2)
+        flat = video.transpose(1, 2).flatten(0, 1)
+        feats = self.model(flat)
+        return feats.view((n, t) + feats.shape[1:]).transpose(1, 2).unsqueeze(-1).unsqueeze(-1)
+
+
+class OracleIdentityBackbone(nn.Module):
+    """Config 1 (pre-extracted TSN features, expts/02_ek100_avt_tsn): features pass straight through."""
+    def forward(self, video):
+        return video
+
+
+# --------------------------------------------------------------------------------------------------
+# GPT-2 (HF transformers modeling_gpt2.py semantics; call sites models/future_prediction.py:89-93,178-181)
+# --------------------------------------------------------------------------------------------------
+class _Conv1D(nn.Module):
+    """HF Conv1D: y = x @ W + b with W stored (in, out)."""
+    def __init__(self, nf, nx):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(nx, nf).normal_(std=0.02))
+        self.bias = nn.Parameter(torch.zeros(nf))
+
+    def forward(self, x):
+        return x @ self.weight + self.bias
+
+
+def gelu_new(x):
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+class _GPT2Attention(nn.Module):
+    def __init__(self, n_embd, n_head, attn_pdrop, resid_pdrop):
+        super().__init__()
+        self.n_head = n_head
+        self.c_attn = _Conv1D(3 * n_embd, n_embd)
+        self.c_proj = _Conv1D(n_embd, n_embd)
+        self.attn_dropout = nn.Dropout(attn_pdrop)
+        self.resid_dropout = nn.Dropout(resid_pdrop)
+
+    def forward(self, x):
+        b, t, c = x.shape
+        hd = c // self.n_head
+        q, k, v = self.c_attn(x).split(c, dim=2)
+        q = q.view(b, t, self.n_head, hd).transpose(1, 2)
+        k = k.view(b, t, self.n_head, hd).transpose(1, 2)
+        v = v.view(b, t, self.n_head, hd).transpose(1, 2)
+        att = (q @ k.transpose(-1, -2)) / math.sqrt(hd)
+        causal = torch.tril(torch.ones(t, t, dtype=torch.bool, device=x.device))
+        att = att.masked_fill(~causal, torch.finfo(att.dtype).min)
+        att = self.attn_dropout(att.softmax(dim=-1))
+        out = (att @ v).transpose(1, 2).reshape(b, t, c)
+        return self.resid_dropout(self.c_proj(out))
+
+
+class _GPT2MLP(nn.Module):
+    def __init__(self, n_embd, n_inner, resid_pdrop):
+        super().__init__()
+        self.c_fc = _Conv1D(n_inner, n_embd)
+        self.c_proj = _Conv1D(n_embd, n_inner)
+        self.dropout = nn.Dropout(resid_pdrop)
+
+    def forward(self, x):
+        return self.dropout(self.c_proj(gelu_new(self.c_fc(x))))
+
+
+class _GPT2Block(nn.Module):
+    def __init__(self, n_embd, n_head, eps, attn_pdrop, resid_pdrop):
+        super().__init__()
+        self.ln_1 = nn.LayerNorm(n_embd, eps=eps)
+        self.attn = _GPT2Attention(n_embd, n_head, attn_pdrop, resid_pdrop)
+        self.ln_2 = nn.LayerNorm(n_embd, eps=eps)
+        self.mlp = _GPT2MLP(n_embd, 4 * n_embd, resid_pdrop)
+
+    def forward(self, x):
+        x = x + self.attn(self.ln_1(x))
+        return x + self.mlp(self.ln_2(x))
+
+
+class OracleGPT2(nn.Module):
+    """GPT2Model(inputs_embeds, position_ids) without wte (deleted at models/future_prediction.py:95)."""
+    def __init__(self, n_embd, n_layer=12, n_head=12, n_positions=1024, layer_norm_epsilon=1e-5,
+                 embd_pdrop=0.1, attn_pdrop=0.1, resid_pdrop=0.1):
+        super().__init__()
+        self.wpe = nn.Embedding(n_positions, n_embd)
+        self.drop = nn.Dropout(embd_pdrop)
+        self.h = nn.ModuleList([
+            _GPT2Block(n_embd, n_head, layer_norm_epsilon, attn_pdrop, resid_pdrop) for _ in range(n_layer)])
+        self.ln_f = nn.LayerNorm(n_embd, eps=layer_norm_epsilon)
+
+    def forward(self, inputs_embeds, position_ids):
+        h = self.drop(inputs_embeds + self.wpe(position_ids))
+        for blk in self.h:
+            h = blk(h)
+        return self.ln_f(h)
+
+
+# --------------------------------------------------------------------------------------------------
+# AVT-h (models/future_prediction.py:51-258, non-quantised path, output_len == 1)
+# --------------------------------------------------------------------------------------------------
+class OracleAVTh(nn.Module):
+    def __init__(self, in_features, output_len=1, avg_last_n=1, inter_dim=2048, future_pred_loss=True,
+                 return_past_too=True, n_head=4, n_layer=6, **gpt_kwargs):
+        super().__init__()
+        gpt_kwargs.pop('future_pred_loss_wt', None)   # rides along in the HF config upstream (:21 of expt 01)
+        assert output_len == 1, 'roll-out (output_len > 1, KV cache) is outside the hot path (SURVEY 8f)'
+        self.encoder = nn.Linear(in_features, inter_dim, bias=False)      # :80
+        self.decoder = nn.Linear(inter_dim, in_features, bias=False)      # :81
+        self.gpt_model = OracleGPT2(inter_dim, n_layer=n_layer, n_head=n_head, **gpt_kwargs)  # :89-93
+        self.in_features, self.inter_dim = in_features, inter_dim
+        self.output_len, self.avg_last_n = output_len, avg_last_n
+        self.return_past_too, self.use_feat_loss = return_past_too, future_pred_loss
+
+    @property
+    def output_dim(self):
+        return self.in_features
+
+    def forward(self, feats, target_shape=None):
+        del target_shape
+        t = feats.size(1)
+        pos = torch.arange(0, t, dtype=torch.long, device=feats.device)          # :170-173
+        decoded = self.decoder(self.gpt_model(self.encoder(feats), pos))          # :163,178-190
+        losses = {}
+        if self.use_feat_loss:                                                    # :207-215
+            losses['feat'] = (decoded[:, :t - 1] - feats[:, 1:t]) ** 2
+        if self.return_past_too:                                                  # :232-235
+            final = torch.cat((feats, decoded[:, t - 1:]), dim=1)
+        else:
+            final = decoded[:, -self.output_len:]
+        if self.avg_last_n > 0:                                                   # :241-242
+            final = final[:, -self.avg_last_n:].mean(dim=1)
+        past = torch.cat([feats[:, :1], decoded[:, :t - 1]], dim=1)               # :249-250
+        return past, final, losses, {}
+
+
+# --------------------------------------------------------------------------------------------------
+# BaseModel glue (models/base_model.py:140-273) for the AVT configs: Identity aggregators, Linear classifier
+# --------------------------------------------------------------------------------------------------
+class OracleBaseModel(nn.Module):
+    def __init__(self, backbone: nn.Module, future_predictor: nn.Module, feat_dim: int,
+                 num_classes: Dict[str, int], dropout=0.2, classifier_on_past=True):
+        super().__init__()
+        self.backbone = backbone
+        self.future_predictor = future_predictor
+        self.dropout = nn.Dropout(dropout)
+        self.classifiers = nn.ModuleDict({k: nn.Linear(feat_dim, c) for k, c in num_classes.items()})
+        self.classifier_on_past = classifier_on_past
+        for m in self.modules():                      # base_model.py:110-127: every nn.Linear <- N(0, 0.01), bias 0
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward_singlecrop(self, video, target_shape=None):
+        out = {}
+        b, t = video.size(0), video.size(1)
+        feats = self.backbone(video.flatten(0, 1))                    # :153-154
+        out['backbone'] = feats
+        feats = feats.mean(dim=[-1, -2])                              # :157
+        out['backbone_mean'] = feats.mean(dim=-1)                     # :159
+        feats = feats.permute(0, 2, 1)                                # :166
+        out['temp_agg'] = feats                                       # Identity aggregator (:175-177)
+        out['temp_agg_projected'] = feats                             # empty project_mlp (:179)
+        agg = feats.reshape((b, t) + feats.shape[1:]).flatten(1, 2)   # :183-191
+        past, future, aux, _ = self.future_predictor(agg, target_shape)
+        out['future'], out['past'] = future, past
+        if self.classifier_on_past:                                   # :203-207
+            drop = self.dropout(past)
+            for k, cls in self.classifiers.items():
+                out[f'past_logits/{k}'] = cls(drop)
+        out['future_projected'] = agg                                 # :209
+        out['future_agg'] = future                                    # Identity aggregator after future pred
+        drop = self.dropout(future)                                   # :215-216
+        for k, cls in self.classifiers.items():
+            out[f'logits/{k}'] = cls(drop)
+        return out, dict(aux)
+
+    def forward(self, video, target_shape=None):                      # :240-273
+        if video.ndim == 6:
+            crops = [video]
+        elif video.ndim == 7:
+            crops = list(torch.unbind(video, dim=2))
+        else:
+            raise NotImplementedError(f'Unsupported size {tuple(video.shape)}')
+        res = [self.forward_singlecrop(c, target_shape) for c in crops]
+        outs = {k: torch.stack([r[0][k] for r in res]).mean(0) for k in res[0][0]}
+        losses = {k: torch.stack([r[1][k] for r in res]).mean(0) for k in res[0][1]}
+        return outs, losses
+
+
+# --------------------------------------------------------------------------------------------------
+# Losses / accuracy (func/train_eval_ops.py:45-85, loss_fn/multidim_xentropy.py:11-25, common/utils.py:17-44)
+# --------------------------------------------------------------------------------------------------
+def multidim_cross_entropy(logits, target, ignore_index=-1):
+    flat = F.cross_entropy(logits.reshape(-1, logits.size(-1)), target.reshape(-1),
+                           ignore_index=ignore_index, reduction='none')
+    return flat.reshape(target.shape)
+
+
+def topk_accuracy(logits, target, topk=(1, 5)):
+    if bool(torch.all(target < 0)):
+        return [torch.zeros([]) for _ in topk]
+    logits, target = logits.flatten(0, -2), target.flatten()
+    _, pred = logits.topk(max(topk), 1, True, True)
+    correct = pred.t().eq(target[None])
+    return [correct[:k].flatten().sum(dtype=torch.float32) * (100.0 / target.size(0)) for k in topk]
+
+
+def basic_loss_accuracy(outputs, target, target_subclips):
+    losses, accs = {}, {}
+    for key, tgt in target.items():
+        logits = outputs[f'logits/{key}']
+        losses[f'cls_{key}'] = multidim_cross_entropy(logits, tgt)
+        a1, a5 = topk_accuracy(logits, tgt, (1, min(5, logits.size(-1))))
+        accs[f'acc1/{key}'], accs[f'acc5/{key}'] = a1, a5
+        pk = f'past_logits/{key}'
+        if pk in outputs and target_subclips is not None:
+            past_tgt = torch.mode(target_subclips[key], -1)[0]
+            losses[f'past_cls_{key}'] = multidim_cross_entropy(outputs[pk], past_tgt)
+    return losses, accs
+
+
+def total_loss(losses, loss_wts):
+    """func/train.py:207-217: mean every loss tensor, weighted sum over keys whose weight is > 0."""
+    tot = None
+    for k, v in losses.items():
+        w = loss_wts.get(k, 0.0)
+        if w > 0:
+            term = w * v.mean()
+            tot = term if tot is None else tot + term
+    return tot
+
+
+# --------------------------------------------------------------------------------------------------
+# Optimiser + LR schedule (torch.optim.SGD nesterov; common/scheduler.py:57-75, 88-135)
+# --------------------------------------------------------------------------------------------------
+def sgd_nesterov_step(p, g, buf, lr, momentum=0.9, weight_decay=0.0, first=False):
+    """In-place on fp32 tensors; ``buf`` is the momentum buffer (initialised to g on the first step)."""
+    g = g + weight_decay * p
+    if first:
+        buf.copy_(g)
+    else:
+        buf.mul_(momentum).add_(g)
+    p.sub_(lr * (g + momentum * buf))
+
+
+def lr_schedule(base_lr, warmup_iters, cosine_iters, n_steps, init_lr_ratio=0.0, eta_min=0.0):
+    """LR seen by optimizer.step() number i (i = 0..n_steps-1) under Warmup(CosineLR), stepped per iteration.
+
+    Reproduces the reference quirk: warm-up yields base*i/W for i < W, then CosineAnnealingLR's
+    *recursive* update continues from base*(W-1)/W, so the peak LR is never reached.
+    """
+    W = max(warmup_iters, 1)
+    ratio0 = init_lr_ratio if W > 1 else 1.0
+    lrs, lr, last, cos_epoch = [], None, 0, 0
+    lr = base_lr * (ratio0 + (1 - ratio0) * 0.0)
+    for _ in range(n_steps):
+        lrs.append(lr)
+        if last < W - 1:
+            last += 1
+            lr = base_lr * (ratio0 + (1 - ratio0) * (last / W))
+        else:
+            cos_epoch += 1
+            T = cosine_iters
+            if cos_epoch >= T:
+                lr = 0.0
+            elif (cos_epoch - 1 - T) % (2 * T) == 0:
+                lr = lr + (base_lr - eta_min) * (1 - math.cos(math.pi / T)) / 2
+            else:
+                lr = ((1 + math.cos(math.pi * cos_epoch / T)) / (1 + math.cos(math.pi * (cos_epoch - 1) / T))
+                      * (lr - eta_min) + eta_min)
+    return lrs
+
+
+# --------------------------------------------------------------------------------------------------
+# Deterministic closed-form parameter fill shared by the golden generator and the tests
+# --------------------------------------------------------------------------------------------------
+def closed_form_fill_(named_tensors, scale_overrides: Optional[Dict[str, float]] = None):
+    """Fill every tensor in-place with w.flatten()[i] = s * sin(a*i + b); (a, b) derive from the name.
+
+    LayerNorm weights get 1 + s*sin(.).  Reproducible on any box without shipping weights.
+    """
+    for idx, (name, t) in enumerate(sorted(named_tensors, key=lambda kv: kv[0])):
+        h = 0
+        for ch in name:
+            h = (h * 131 + ord(ch)) % 1000003
+        a = 0.37 + (h % 1000) / 1000.0
+        b = (h % 6283) / 1000.0
+        n = t.numel()
+        fan_in = t.shape[-1] if t.ndim >= 2 else 1
+        if t.ndim == 4:
+            fan_in = t.shape[1] * t.shape[2] * t.shape[3]
+        s = 1.0 / math.sqrt(fan_in) if t.ndim >= 2 else 0.05
+        is_norm_w = (('norm' in name or 'ln_' in name) and name.endswith('weight'))
+        if 'c_attn.weight' in name or 'c_fc.weight' in name or ('c_proj.weight' in name):
+            s = 1.0 / math.sqrt(t.shape[0])           # Conv1D is (in, out)
+        if 'pos_embed' in name or 'cls_token' in name or 'wpe' in name:
+            s = 0.05
+        if scale_overrides:
+            for key, val in scale_overrides.items():
+                if key in name:
+                    s = val
+        i = torch.arange(n, dtype=torch.float64)
+        vals = s * torch.sin(a * i + b)
+        if is_norm_w:
+            vals = 1.0 + vals
+        with torch.no_grad():
+            t.copy_(vals.to(t.dtype).reshape(t.shape))
