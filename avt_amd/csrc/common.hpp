@@ -1,0 +1,75 @@
+// Shared device helpers for the AVT gfx950 kernels (bf16 conversion, GELU variants, counter-based RNG,
+// wave reductions) and the host-side error channel of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                               // raw bf16 bits in HBM
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;           // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define AVT_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {                      // round-to-nearest-even, NaN kept quiet
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// exact (erf) GELU -- timm Mlp act_layer=nn.GELU ; tanh GELU -- HF "gelu_new"
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float gelu_tanh(float x) {
+  float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float dgelu_tanh(float x) {
+  float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  float t = tanhf(u);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+}
+
+// Counter-based RNG for dropout: keep(seed, idx) is a pure function, so backward recomputes the mask.
+__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 16);
+}
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) { return rng_u32(seed, idx) >= thresh; }
+static inline uint32_t drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t < 0) t = 0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- host-side error channel -------------------------------------------------------------------------
+void avt_set_error(const char* fmt, ...);
+#define AVT_CHECK(cond, ...) do { if (!(cond)) { avt_set_error(__VA_ARGS__); return -1; } } while (0)
+#define AVT_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { \
+  avt_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); return (int)e__; } } while (0)
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

@@ -1,0 +1,229 @@
+// HBM-bound helper kernels of the AVT step: patch extraction (im2col for the 16x16/stride-16 patch-embed conv),
+// positional/CLS residual table, fp32->bf16 casts, dropout, GPT-2 position-embedding add, reductions that feed
+// parameter gradients (pos_embed / cls_token / patch bias / wpe), shifted-MSE feature loss.
+// All of them move 8-16 B per lane per access and touch every byte once.
+#include "common.hpp"
+#include "../../include/avt_hip.h"
+
+namespace {
+
+// video fp32 [N,3,Hi,Wi] -> patches bf16 [N*(P+1), 768]; row n*(P+1) is the (zero) CLS slot, row n*(P+1)+1+p is
+// patch p = py*(Wi/16)+px flattened as k = c*256 + ky*16 + kx (the Conv2d weight's (3,16,16) order).
+__global__ __launch_bounds__(256) void im2col16_kernel(const float* __restrict__ video, bf16_t* __restrict__ patches,
+                                                       int N, int Hi, int Wi) {
+  const int PW = Wi / 16, PH = Hi / 16, P = PW * PH;
+  const long total = (long)N * (P + 1) * 48;           // 48 = 3 channels x 16 ky: one 16-pixel run each
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    int run = (int)(idx % 48);
+    long row = idx / 48;
+    int s = (int)(row % (P + 1));
+    int n = (int)(row / (P + 1));
+    u32x4_t w0 = {0u, 0u, 0u, 0u}, w1 = {0u, 0u, 0u, 0u};
+    if (s > 0) {
+      int p = s - 1, py = p / PW, px = p % PW, c = run >> 4, ky = run & 15;
+      const float* src = video + (((size_t)n * 3 + c) * Hi + (py * 16 + ky)) * Wi + px * 16;
+      f32x4_t a = *(const f32x4_t*)(src), b = *(const f32x4_t*)(src + 4), cc = *(const f32x4_t*)(src + 8), d = *(const f32x4_t*)(src + 12);
+      w0[0] = pack2bf(a[0], a[1]); w0[1] = pack2bf(a[2], a[3]); w0[2] = pack2bf(b[0], b[1]); w0[3] = pack2bf(b[2], b[3]);
+      w1[0] = pack2bf(cc[0], cc[1]); w1[1] = pack2bf(cc[2], cc[3]); w1[2] = pack2bf(d[0], d[1]); w1[3] = pack2bf(d[2], d[3]);
+    }
+    bf16_t* dst = patches + (size_t)row * 768 + run * 16;
+    *(u32x4_t*)(dst) = w0;
+    *(u32x4_t*)(dst + 8) = w1;
+  }
+}
+
+// R[s] = pos[s] + (s == 0 ? cls : conv_bias)  (bf16) -- the row-periodic residual of the patch-embed GEMM
+__global__ void posres_kernel(const float* __restrict__ pos, const float* __restrict__ cls, const float* __restrict__ bias,
+                              bf16_t* __restrict__ R, int S, int D) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * D) return;
+  int s = i / D, d = i % D;
+  R[i] = f2bf(pos[i] + (s == 0 ? cls[d] : bias[d]));
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+  long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+  const long stride = (long)gridDim.x * 256 * 8;
+  for (; i + 8 <= n; i += stride) {
+    f32x4_t a = *(const f32x4_t*)(src + i), b = *(const f32x4_t*)(src + i + 4);
+    u32x4_t w; w[0] = pack2bf(a[0], a[1]); w[1] = pack2bf(a[2], a[3]); w[2] = pack2bf(b[0], b[1]); w[3] = pack2bf(b[2], b[3]);
+    *(u32x4_t*)(dst + i) = w;
+  }
+  if (i < n) for (long j = i; j < n; ++j) dst[j] = f2bf(src[j]);
+}
+
+__global__ __launch_bounds__(256) void cast_back_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = bf2f(src[i]);
+}
+
+// y = keep(seed, idx) ? x / (1-p) : 0, bf16 -> bf16 (also its own backward on gradients, same seed)
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n,
+                                                      uint32_t thresh, float scale, uint64_t seed) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    y[i] = drop_keep(seed, (uint64_t)i, thresh) ? f2bf(bf2f(x[i]) * scale) : (bf16_t)0;
+}
+
+// h[b,t,:] = dropout(enc[b,t,:] + wpe[t,:])   (HF GPT2Model: inputs_embeds + position_embeds, then drop)
+__global__ __launch_bounds__(256) void embed_pos_kernel(const bf16_t* __restrict__ enc, const float* __restrict__ wpe,
+                                                        bf16_t* __restrict__ h, int B, int T, int E,
+                                                        uint32_t thresh, float scale, uint64_t seed) {
+  long n = (long)B * T * E;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    int e = (int)(i % E);
+    int t = (int)((i / E) % T);
+    float v = bf2f(enc[i]) + wpe[(size_t)t * E + e];
+    if (thresh) v = drop_keep(seed, (uint64_t)i, thresh) ? v * scale : 0.f;
+    h[i] = f2bf(v);
+  }
+}
+// backward: denc = dh * mask ; dwpe[t] += sum_b denc[b,t]
+__global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const bf16_t* __restrict__ dh, bf16_t* __restrict__ denc,
+                                                            float* __restrict__ dwpe, int B, int T, int E,
+                                                            uint32_t thresh, float scale, uint64_t seed) {
+  long n = (long)T * E;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+      long idx = (long)b * n + i;
+      float v = bf2f(dh[idx]);
+      if (thresh) v = drop_keep(seed, (uint64_t)idx, thresh) ? v * scale : 0.f;
+      bf16_t o = f2bf(v);
+      denc[idx] = o;
+      acc += bf2f(o);
+    }
+    dwpe[i] += acc;
+  }
+}
+
+// dx0 bf16 [N,S,D] -> dpos[S,D] += sum_n ; dcls[D] += row s=0 ; dbias[D] += sum_{s>=1}
+__global__ __launch_bounds__(256) void patch_bwd_reduce_kernel(const bf16_t* __restrict__ dx, float* __restrict__ dpos,
+                                                               float* __restrict__ dcls, float* __restrict__ dbias,
+                                                               int N, int S, int D) {
+  const int nch = D / 8;
+  long total = (long)S * nch;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    int c = (int)(idx % nch), s = (int)(idx / nch);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n) {
+      u32x4_t w = *(const u32x4_t*)(dx + ((size_t)n * S + s) * D + c * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += bflo(w[e]); acc[2 * e + 1] += bfhi(w[e]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dpos[(size_t)s * D + c * 8 + e] += acc[e];
+      if (s == 0) dcls[c * 8 + e] += acc[e];
+      else unsafeAtomicAdd(&dbias[c * 8 + e], acc[e]);
+    }
+  }
+}
+
+// column sums of a bf16 matrix: out[n] += sum_m x[m][n]   (bias gradients that have no producer to fuse into)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int ld, float* __restrict__ out, int M, int N, int rows_per_block) {
+  const int nch = N / 8;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= nch) return;
+  const int m0 = blockIdx.y * rows_per_block;
+  int m1 = m0 + rows_per_block; if (m1 > M) m1 = M;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int m = m0; m < m1; ++m) {
+    u32x4_t w = *(const u32x4_t*)(x + (size_t)m * ld + c * 8);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[2 * e] += bflo(w[e]); acc[2 * e + 1] += bfhi(w[e]); }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) unsafeAtomicAdd(&out[c * 8 + e], acc[e]);
+}
+
+// feat loss (models/future_prediction.py:207-215): loss[b,t,:] = (dec[b,t,:] - x[b,t+1,:])^2, t < T-1 (fp32 out)
+__global__ __launch_bounds__(256) void mse_shift_fwd_kernel(const bf16_t* __restrict__ dec, const bf16_t* __restrict__ x,
+                                                            float* __restrict__ loss, int B, int T, int F) {
+  long n = (long)B * (T - 1) * F;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    int f = (int)(i % F); long r = i / F; int t = (int)(r % (T - 1)); int b = (int)(r / (T - 1));
+    float d = bf2f(dec[((size_t)b * T + t) * F + f]) - bf2f(x[((size_t)b * T + t + 1) * F + f]);
+    loss[i] = d * d;
+  }
+}
+}  // namespace
+
+#define GRID_FOR(n, per) ({ long g__ = ((n) + (per) - 1) / (per); if (g__ > 8192) g__ = 8192; if (g__ < 1) g__ = 1; (int)g__; })
+
+extern "C" int avt_im2col_patch16(const float* video, void* patches, int N, int Himg, int Wimg, void* stream) {
+  AVT_CHECK(video && patches && N > 0, "avt_im2col_patch16: null argument");
+  AVT_CHECK(Himg % 16 == 0 && Wimg % 16 == 0 && Himg > 0 && Wimg > 0, "avt_im2col_patch16: image size must be a multiple of 16");
+  AVT_CHECK(aligned16(video) && aligned16(patches), "avt_im2col_patch16: 16-byte alignment required");
+  long total = (long)N * ((Himg / 16) * (Wimg / 16) + 1) * 48;
+  hipLaunchKernelGGL(im2col16_kernel, dim3(GRID_FOR(total, 256)), dim3(256), 0, (hipStream_t)stream, video, (bf16_t*)patches, N, Himg, Wimg);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_posres_prep(const float* pos, const float* cls, const float* bias, void* R, int S, int D, void* stream) {
+  AVT_CHECK(pos && cls && bias && R && S > 0 && D > 0, "avt_posres_prep: null argument");
+  hipLaunchKernelGGL(posres_kernel, dim3((S * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, pos, cls, bias, (bf16_t*)R, S, D);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream) {
+  AVT_CHECK(src && dst && n > 0, "avt_cast_f32_to_bf16: null argument");
+  AVT_CHECK(aligned16(src) && aligned16(dst), "avt_cast_f32_to_bf16: 16-byte alignment required");
+  hipLaunchKernelGGL(cast_kernel, dim3(GRID_FOR(n, 2048)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_cast_bf16_to_f32(const void* src, float* dst, long n, void* stream) {
+  AVT_CHECK(src && dst && n > 0, "avt_cast_bf16_to_f32: null argument");
+  hipLaunchKernelGGL(cast_back_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, void* stream) {
+  AVT_CHECK(x && y && n > 0, "avt_dropout_bf16: null argument");
+  AVT_CHECK(p >= 0.f && p < 1.f, "avt_dropout_bf16: bad p");
+  hipLaunchKernelGGL(dropout_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n,
+                     drop_threshold(p), 1.f / (1.f - p), seed);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_embed_pos_fwd(const void* enc, const float* wpe, void* h, int B, int T, int E, float p, uint64_t seed, void* stream) {
+  AVT_CHECK(enc && wpe && h && B > 0 && T > 0 && E > 0, "avt_embed_pos_fwd: null argument");
+  AVT_CHECK(p >= 0.f && p < 1.f, "avt_embed_pos_fwd: bad p");
+  long n = (long)B * T * E;
+  hipLaunchKernelGGL(embed_pos_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)enc, wpe, (bf16_t*)h, B, T, E,
+                     drop_threshold(p), 1.f / (1.f - p), seed);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_embed_pos_bwd(const void* dh, void* denc, float* dwpe, int B, int T, int E, float p, uint64_t seed, void* stream) {
+  AVT_CHECK(dh && denc && dwpe && B > 0 && T > 0 && E > 0, "avt_embed_pos_bwd: null argument");
+  long n = (long)T * E;
+  hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dh, (bf16_t*)denc, dwpe, B, T, E,
+                     drop_threshold(p), 1.f / (1.f - p), seed);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_patch_embed_bwd_reduce(const void* dx, float* dpos, float* dcls, float* dbias, int N, int S, int D, void* stream) {
+  AVT_CHECK(dx && dpos && dcls && dbias && N > 0 && S > 0 && D > 0 && D % 8 == 0, "avt_patch_embed_bwd_reduce: bad argument");
+  AVT_CHECK(aligned16(dx), "avt_patch_embed_bwd_reduce: 16-byte alignment required");
+  long total = (long)S * (D / 8);
+  hipLaunchKernelGGL(patch_bwd_reduce_kernel, dim3(GRID_FOR(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, dpos, dcls, dbias, N, S, D);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_colsum_bf16(const void* x, int ld, float* out, int M, int N, void* stream) {
+  AVT_CHECK(x && out && M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "avt_colsum_bf16: N and ld must be multiples of 8");
+  AVT_CHECK(aligned16(x), "avt_colsum_bf16: 16-byte alignment required");
+  int nch = N / 8, gx = (nch + 255) / 256;
+  int gy = 2048 / gx; if (gy < 1) gy = 1; if (gy > (M + 15) / 16) gy = (M + 15) / 16;
+  int rpb = (M + gy - 1) / gy;
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, out, M, N, rpb);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_mse_shift_fwd(const void* dec, const void* x, float* loss, int B, int T, int F, void* stream) {
+  AVT_CHECK(dec && x && loss && B > 0 && T > 1 && F > 0, "avt_mse_shift_fwd: bad argument");
+  long n = (long)B * (T - 1) * F;
+  hipLaunchKernelGGL(mse_shift_fwd_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dec, (const bf16_t*)x, loss, B, T, F);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}

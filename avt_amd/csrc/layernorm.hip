@@ -1,0 +1,227 @@
+// Fused LayerNorm forward / backward for bf16 activations (fp32 statistics), gfx950.
+// One 64-lane wave per row; a row of D = 8*64*V bf16 is held in registers (D in {64..4096}, D % 8 == 0).
+// HBM-bound: every element is read once and written once, 16 B per lane per access.
+//
+// forward : y = (x - mean) * rstd * gamma + beta ; saves mean, rstd (fp32) -- timm LayerNorm eps 1e-6,
+//           HF GPT-2 eps 1e-5 (eps is an argument).  Input rows may be strided (CLS-row select before the
+//           final ViT norm).
+// backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) [+ dres],  g = dy * gamma
+//           dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy ; optional colsum(dx_out) (the bias gradient
+//           of the Linear that produced the residual stream) -- all accumulated with fp32 atomics after a
+//           per-block reduction.
+#include "common.hpp"
+#include "../../include/avt_hip.h"
+
+namespace {
+
+constexpr int MAXV = 8;   // up to 8 x 16-B chunks per lane -> D <= 4096
+
+template <int V>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y, int ldy,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     int rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = D >> 3;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const bf16_t* xr = x + (size_t)row * ldx;
+    float v[V][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      int c = lane + i * 64;
+      if (c < nchunk) {
+        u32x4_t w = *(const u32x4_t*)(xr + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][2 * e] = bflo(w[e]); v[i][2 * e + 1] = bfhi(w[e]); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      int c = lane + i * 64;
+      if (c < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float d = v[i][e] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) { if (mean_out) mean_out[row] = mean; if (rstd_out) rstd_out[row] = rstd; }
+    bf16_t* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      int c = lane + i * 64;
+      if (c < nchunk) {
+        f32x4_t g0 = *(const f32x4_t*)(gamma + c * 8), g1 = *(const f32x4_t*)(gamma + c * 8 + 4);
+        f32x4_t b0 = *(const f32x4_t*)(beta + c * 8), b1 = *(const f32x4_t*)(beta + c * 8 + 4);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (v[i][e] - mean) * rstd * g0[e] + b0[e];
+          o[4 + e] = (v[i][4 + e] - mean) * rstd * g1[e] + b1[e];
+        }
+        u32x4_t w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack2bf(o[2 * e], o[2 * e + 1]);
+        *(u32x4_t*)(yr + c * 8) = w;
+      }
+    }
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
+                                                     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                     const float* __restrict__ gamma, const bf16_t* __restrict__ dres, int lddres,
+                                                     bf16_t* __restrict__ dx, int lddx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, float* __restrict__ colsum, int rows, int D) {
+  __shared__ float red[3][4][64 * 8];    // [quantity][wave][lane*8+e] scratch for one chunk column at a time
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nchunk = D >> 3;
+  float ag[V][8], ab[V][8], ac[V][8];
+#pragma unroll
+  for (int i = 0; i < V; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; ac[i][e] = 0.f; }
+  float gam[V][8];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    int c = lane + i * 64;
+    if (c < nchunk) {
+      f32x4_t g0 = *(const f32x4_t*)(gamma + c * 8), g1 = *(const f32x4_t*)(gamma + c * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { gam[i][e] = g0[e]; gam[i][4 + e] = g1[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gam[i][e] = 0.f;
+    }
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    const bf16_t* xr = x + (size_t)row * ldx;
+    const bf16_t* dyr = dy + (size_t)row * lddy;
+    float xh[V][8], g[V][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      int c = lane + i * 64;
+      if (c < nchunk) {
+        u32x4_t wx = *(const u32x4_t*)(xr + c * 8);
+        u32x4_t wd = *(const u32x4_t*)(dyr + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x0 = (bflo(wx[e]) - mean) * rstd, x1 = (bfhi(wx[e]) - mean) * rstd;
+          float d0 = bflo(wd[e]), d1 = bfhi(wd[e]);
+          xh[i][2 * e] = x0; xh[i][2 * e + 1] = x1;
+          ag[i][2 * e] += d0 * x0; ag[i][2 * e + 1] += d1 * x1;
+          ab[i][2 * e] += d0; ab[i][2 * e + 1] += d1;
+          g[i][2 * e] = d0 * gam[i][2 * e]; g[i][2 * e + 1] = d1 * gam[i][2 * e + 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1 += g[i][e]; s2 += g[i][e] * xh[i][e]; }
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+    bf16_t* dxr = dx + (size_t)row * lddx;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      int c = lane + i * 64;
+      if (c < nchunk) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - m1 - xh[i][e] * m2);
+        if (dres) {
+          u32x4_t wr = *(const u32x4_t*)(dres + (size_t)row * lddres + c * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[2 * e] += bflo(wr[e]); o[2 * e + 1] += bfhi(wr[e]); }
+        }
+        u32x4_t w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack2bf(o[2 * e], o[2 * e + 1]);
+        *(u32x4_t*)(dxr + c * 8) = w;
+        if (colsum) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ac[i][e] += bf2f(f2bf(o[e]));   // sum what the consumer GEMM will see
+        }
+      }
+    }
+  }
+  // block reduction of the per-lane column partials, one chunk column (64 lanes x 8) at a time
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    int c = lane + i * 64;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[0][wave][lane * 8 + e] = ag[i][e];
+      red[1][wave][lane * 8 + e] = ab[i][e];
+      red[2][wave][lane * 8 + e] = ac[i][e];
+    }
+    __syncthreads();
+    // 256 threads fold 3 x 512 values: thread t handles elements t and t+256 of each quantity
+    for (int idx = threadIdx.x; idx < 512; idx += 256) {
+      int l = idx >> 3, e = idx & 7;
+      int cc = l + i * 64;
+      if (cc < nchunk) {
+        float sg = red[0][0][idx] + red[0][1][idx] + red[0][2][idx] + red[0][3][idx];
+        float sb = red[1][0][idx] + red[1][1][idx] + red[1][2][idx] + red[1][3][idx];
+        if (dgamma) unsafeAtomicAdd(&dgamma[cc * 8 + e], sg);
+        if (dbeta) unsafeAtomicAdd(&dbeta[cc * 8 + e], sb);
+        if (colsum) {
+          float sc = red[2][0][idx] + red[2][1][idx] + red[2][2][idx] + red[2][3][idx];
+          unsafeAtomicAdd(&colsum[cc * 8 + e], sc);
+        }
+      }
+    }
+    (void)c;
+  }
+}
+
+int pick_v(int D) { int nchunk = D / 8; return (nchunk + 63) / 64; }
+
+}  // namespace
+
+extern "C" int avt_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
+                                 float* mean, float* rstd, int rows, int D, float eps, void* stream) {
+  AVT_CHECK(x && gamma && beta && y, "avt_layernorm_fwd: null argument");
+  AVT_CHECK(rows > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * MAXV, "avt_layernorm_fwd: D must be a multiple of 8 and <= 4096 (D=%d)", D);
+  AVT_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta),
+            "avt_layernorm_fwd: 16-byte alignment required");
+  int grid = (rows + 3) / 4; if (grid > 4096) grid = 4096;
+  hipStream_t s = (hipStream_t)stream;
+#define LN_FWD(V) hipLaunchKernelGGL((ln_fwd_kernel<V>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd, rows, D, eps)
+  switch (pick_v(D)) {
+    case 1: LN_FWD(1); break; case 2: LN_FWD(2); break; case 3: LN_FWD(3); break; case 4: LN_FWD(4); break;
+    case 5: LN_FWD(5); break; case 6: LN_FWD(6); break; case 7: LN_FWD(7); break; default: LN_FWD(8); break;
+  }
+#undef LN_FWD
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int avt_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
+                                 const float* gamma, const void* dres, int lddres, void* dx, int lddx,
+                                 float* dgamma, float* dbeta, float* colsum, int rows, int D, void* stream) {
+  AVT_CHECK(dy && x && mean && rstd && gamma && dx, "avt_layernorm_bwd: null argument");
+  AVT_CHECK(rows > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * MAXV, "avt_layernorm_bwd: D must be a multiple of 8 and <= 4096 (D=%d)", D);
+  AVT_CHECK(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && (!dres || lddres % 8 == 0), "avt_layernorm_bwd: leading dims must be multiples of 8");
+  AVT_CHECK(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (!dres || aligned16(dres)), "avt_layernorm_bwd: 16-byte alignment required");
+  int grid = (rows + 3) / 4; if (grid > 512) grid = 512;
+  hipStream_t s = (hipStream_t)stream;
+#define LN_BWD(V) hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, dgamma, dbeta, colsum, rows, D)
+  switch (pick_v(D)) {
+    case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break; case 4: LN_BWD(4); break;
+    case 5: LN_BWD(5); break; case 6: LN_BWD(6); break; case 7: LN_BWD(7); break; default: LN_BWD(8); break;
+  }
+#undef LN_BWD
+  AVT_LAUNCH_CHECK();
+  return 0;
+}

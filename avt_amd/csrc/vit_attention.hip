@@ -1,0 +1,382 @@
+// ViT spatial multi-head self-attention (timm Attention: softmax(q k^T * hd^-0.5) v, no mask, no dropout),
+// forward and backward, head_dim 64, sequence S <= 208 (ViT-*/16 @224: S = 197), bf16 I/O, fp32 softmax.
+//
+// One workgroup per (frame, head); wave w owns the 16-row strip w of the sequence (13 waves for S = 197).
+// The whole K / V (and Q / dO in backward) of one head fit in LDS, so the forward needs no online softmax and
+// the backward recomputes P from the saved log-sum-exp.
+// All products run on v_mfma_f32_16x16x32_bf16.  Scores are produced TRANSPOSED (S^T = K Q^T, keys along
+// accumulator registers, queries along lanes) so that P^T / dS^T are already in the B-operand register layout
+// of the following P V / dS K products; the second operand of those products (V^T, K^T, Q^T, dO^T) is staged
+// into LDS transposed once per workgroup.
+//   qkv layout: [frames*S, 3*D] with columns [q | k | v], each head-major (timm reshape(N,S,3,H,hd)).
+#include "common.hpp"
+#include "../../include/avt_hip.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// row-major [R][64] bf16 tile, 128-B rows, 16-B chunk c of row r stored at c ^ ((r>>1)&7)
+__device__ __forceinline__ int rm_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// Stage S rows x 64 columns (global row stride ld) into a swizzled row-major tile of RP rows (zero padded) and/or
+// a transposed tile [64][TS] (element (d, r) at d*TS + r), zero padded to TP rows.
+__device__ __forceinline__ void stage_head(const bf16_t* __restrict__ src, int ld, int S, char* rm, int RP, bf16_t* tr, int TS,
+                                           int TP, int tid, int nthr) {
+  int RMAX = RP > TP ? RP : TP;
+  for (int idx = tid; idx < RMAX * 8; idx += nthr) {
+    int r = idx >> 3, c = idx & 7;
+    u32x4_t w = {0u, 0u, 0u, 0u};
+    if (r < S) w = *(const u32x4_t*)(src + (size_t)r * ld + c * 8);
+    if (rm && r < RP) *(u32x4_t*)(rm + rm_off(r, c)) = w;
+    if (tr && r < TP) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tr[(c * 8 + 2 * e) * TS + r] = (bf16_t)(w[e] & 0xffffu);
+        tr[(c * 8 + 2 * e + 1) * TS + r] = (bf16_t)(w[e] >> 16);
+      }
+    }
+  }
+}
+
+// B-operand fragments of a 16-row strip taken straight from global: lane (j = l&15, g = l>>4) holds
+// X[row0 + j][ks*32 + g*8 .. +7], ks = 0, 1.  Rows >= S read as zero.
+__device__ __forceinline__ void load_strip(const bf16_t* __restrict__ src, int ld, int S, int row0, int lane, bf16x8_t out[2]) {
+  int r = row0 + (lane & 15), g = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    union { u32x4_t u; bf16x8_t v; } t;
+    t.u = (u32x4_t){0u, 0u, 0u, 0u};
+    if (r < S) t.u = *(const u32x4_t*)(src + (size_t)r * ld + ks * 32 + g * 8);
+    out[ks] = t.v;
+  }
+}
+// A-operand fragment from a swizzled row-major LDS tile: lane (i = l&15, g) holds X[tile*16 + i][ks*32 + g*8 .. +7]
+__device__ __forceinline__ bf16x8_t frag_rm(const char* rm, int tile, int ks, int lane) {
+  int r = tile * 16 + (lane & 15), c = ks * 4 + (lane >> 4);
+  return *(const bf16x8_t*)(rm + rm_off(r, c));
+}
+// A-operand fragment from a transposed LDS tile for the pair of 16-index tiles (2t, 2t+1):
+// lane (i = l&15, g) holds Xt[dt*16 + i][32t + 4g .. +3] ++ Xt[dt*16 + i][32t + 16 + 4g .. +3]
+__device__ __forceinline__ bf16x8_t frag_tr(const bf16_t* tr, int TS, int dt, int t, int lane) {
+  const bf16_t* p = tr + (dt * 16 + (lane & 15)) * TS + 32 * t + 4 * (lane >> 4);
+  union { bf16x8_t v; u32x2_t h[2]; } u;
+  u.h[0] = *(const u32x2_t*)(p);
+  u.h[1] = *(const u32x2_t*)(p + 16);
+  return u.v;
+}
+__device__ __forceinline__ bf16x8_t pack_pair(f32x4_t a, f32x4_t b) {
+  union { bf16x8_t v; uint32_t w[4]; } u;
+  u.w[0] = pack2bf(a[0], a[1]); u.w[1] = pack2bf(a[2], a[3]);
+  u.w[2] = pack2bf(b[0], b[1]); u.w[3] = pack2bf(b[2], b[3]);
+  return u.v;
+}
+// sum / max over the 4 lane groups g (lanes sharing l&15)
+__device__ __forceinline__ float gsum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ float gmax(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
+// sum over the 16 lanes of a group (l&15)
+__device__ __forceinline__ float lsum16(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+template <int NKT>
+__global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                float* __restrict__ lse, int S, int H, float scale) {
+  constexpr int NP = (NKT + 1) / 2;          // key-tile pairs
+  constexpr int KP = NP * 32;                // padded key count
+  constexpr int TS = KP + 8;                 // transposed row stride (elements)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Klds = smem;                         // [NKT*16][64] swizzled
+  bf16_t* Vt = (bf16_t*)(smem + NKT * 16 * 128);   // [64][TS]
+  const int D = H * HD, ld = 3 * D;
+  const int frame = blockIdx.x / H, head = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_t* base = qkv + (size_t)frame * S * ld + head * HD;
+  stage_head(base + D, ld, S, Klds, NKT * 16, nullptr, 0, 0, tid, 64 * NKT);
+  stage_head(base + 2 * D, ld, S, nullptr, 0, Vt, TS, KP, tid, 64 * NKT);
+  __syncthreads();
+
+  const int q0 = wave * 16, g = lane >> 4;
+  bf16x8_t bq[2];
+  load_strip(base, ld, S, q0, lane, bq);
+  f32x4_t st[2 * NP];
+#pragma unroll
+  for (int kt = 0; kt < 2 * NP; ++kt) st[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+    a = mfma16(frag_rm(Klds, kt, 0, lane), bq[0], a);
+    a = mfma16(frag_rm(Klds, kt, 1, lane), bq[1], a);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int key = kt * 16 + 4 * g + r;
+      a[r] = (key < S) ? a[r] : -3.0e38f;
+      mx = fmaxf(mx, a[r]);
+    }
+    st[kt] = a;
+  }
+  mx = gmax(mx);
+  const float sl = scale * LOG2E;
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int key = kt * 16 + 4 * g + r;
+      float pv = (key < S) ? exp2f((st[kt][r] - mx) * sl) : 0.f;
+      st[kt][r] = pv;
+      sum += pv;
+    }
+  sum = gsum(sum);
+  f32x4_t o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NP; ++t) {
+    bf16x8_t pb = pack_pair(st[2 * t], st[2 * t + 1]);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(frag_tr(Vt, TS, dt, t, lane), pb, o[dt]);
+  }
+  const int q = q0 + (lane & 15);
+  if (q < S) {
+    const float inv = 1.0f / sum;
+    bf16_t* orow = out + ((size_t)frame * S + q) * D + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      u32x2_t w; w[0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv); w[1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+      *(u32x2_t*)(orow + dt * 16 + 4 * g) = w;
+    }
+    if (g == 0) lse[((size_t)frame * H + head) * S + q] = mx * scale + __logf(sum);
+  }
+}
+
+template <int NKT>
+__global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                                const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
+                                                                int S, int H, float scale) {
+  constexpr int NP = (NKT + 1) / 2;
+  constexpr int KP = NP * 32;
+  constexpr int TS = KP + 8;
+  constexpr int RM = NKT * 16 * 128;         // bytes of a row-major tile
+  constexpr int TR = 64 * TS * 2;            // bytes of a transposed tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // phase A: [K rm | V rm | Kt]           phase B: [Q rm | dO rm | Qt | dOt]      tail: lse, Dq (fp32), bias partials
+  char* buf0 = smem;
+  char* buf1 = smem + RM;
+  bf16_t* tr0 = (bf16_t*)(smem + 2 * RM);
+  bf16_t* tr1 = (bf16_t*)(smem + 2 * RM + TR);
+  float* lse_s = (float*)(smem + 2 * RM + 2 * TR);
+  float* dq_s = lse_s + KP;
+  float* bias_s = dq_s + KP;                 // [3*64]
+  const int D = H * HD, ld = 3 * D;
+  const int frame = blockIdx.x / H, head = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = 64 * NKT;
+  const int g = lane >> 4;
+  const size_t row0 = (size_t)frame * S;
+  const bf16_t* base = qkv + row0 * ld + head * HD;
+  const bf16_t* obase = out + row0 * D + head * HD;
+  const bf16_t* dobase = dout + row0 * D + head * HD;
+  bf16_t* dbase = dqkv + row0 * ld + head * HD;
+  const float* lse_g = lse + ((size_t)frame * H + head) * S;
+
+  for (int i = tid; i < KP; i += nthr) lse_s[i] = (i < S) ? lse_g[i] : 0.f;
+  for (int i = tid; i < 192; i += nthr) bias_s[i] = 0.f;
+  stage_head(base + D, ld, S, buf0, NKT * 16, tr0, TS, KP, tid, nthr);          // K rm + Kt
+  stage_head(base + 2 * D, ld, S, buf1, NKT * 16, nullptr, 0, 0, tid, nthr);    // V rm
+  __syncthreads();
+
+  // ---------------- phase A: this wave's 16-query strip -> dQ -----------------------------------
+  {
+    const int q0 = wave * 16, q = q0 + (lane & 15);
+    bf16x8_t bq[2], bdo[2], bo[2];
+    load_strip(base, ld, S, q0, lane, bq);
+    load_strip(dobase, D, S, q0, lane, bdo);
+    load_strip(obase, D, S, q0, lane, bo);
+    float dsum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dsum += (float)bdo[ks][e] * (float)bo[ks][e];
+    dsum = gsum(dsum);
+    if (g == 0) dq_s[q] = dsum;              // q < KP always (q0 + 15 < NKT*16 <= KP)
+    const float lq = (q < S) ? lse_s[q] : 0.f;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      f32x4_t dsv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int kt = 2 * t + u;
+        dsv[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (kt < NKT) {
+          f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          s = mfma16(frag_rm(buf0, kt, 0, lane), bq[0], s);
+          s = mfma16(frag_rm(buf0, kt, 1, lane), bq[1], s);
+          dp = mfma16(frag_rm(buf1, kt, 0, lane), bdo[0], dp);
+          dp = mfma16(frag_rm(buf1, kt, 1, lane), bdo[1], dp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int key = kt * 16 + 4 * g + r;
+            float pv = (key < S && q < S) ? __expf(s[r] * scale - lq) : 0.f;
+            dsv[u][r] = pv * (dp[r] - dsum) * scale;
+          }
+        }
+      }
+      bf16x8_t b = pack_pair(dsv[0], dsv[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(frag_tr(tr0, TS, dt, t, lane), b, acc[dt]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      if (q < S) {
+        u32x2_t w; w[0] = pack2bf(acc[dt][0], acc[dt][1]); w[1] = pack2bf(acc[dt][2], acc[dt][3]);
+        *(u32x2_t*)(dbase + (size_t)q * ld + dt * 16 + 4 * g) = w;
+      }
+      if (dbias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = lsum16((q < S) ? acc[dt][r] : 0.f);
+          if ((lane & 15) == 0) atomicAdd(&bias_s[dt * 16 + 4 * g + r], v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---------------- phase B: this wave's 16-key strip -> dK, dV ---------------------------------
+  stage_head(base, ld, S, buf0, NKT * 16, tr0, TS, KP, tid, nthr);              // Q rm + Qt
+  stage_head(dobase, D, S, buf1, NKT * 16, tr1, TS, KP, tid, nthr);             // dO rm + dOt
+  __syncthreads();
+  {
+    const int k0 = wave * 16, key = k0 + (lane & 15);
+    bf16x8_t bk[2], bv[2];
+    load_strip(base + D, ld, S, k0, lane, bk);
+    load_strip(base + 2 * D, ld, S, k0, lane, bv);
+    f32x4_t adk[4], adv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      f32x4_t pv2[2], ds2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int qt = 2 * t + u;
+        pv2[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        ds2[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (qt < NKT) {
+          f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          s = mfma16(frag_rm(buf0, qt, 0, lane), bk[0], s);
+          s = mfma16(frag_rm(buf0, qt, 1, lane), bk[1], s);
+          dp = mfma16(frag_rm(buf1, qt, 0, lane), bv[0], dp);
+          dp = mfma16(frag_rm(buf1, qt, 1, lane), bv[1], dp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int qq = qt * 16 + 4 * g + r;
+            float p = (qq < S && key < S) ? __expf(s[r] * scale - lse_s[qq]) : 0.f;
+            pv2[u][r] = p;
+            ds2[u][r] = p * (dp[r] - dq_s[qq]) * scale;
+          }
+        }
+      }
+      bf16x8_t bp = pack_pair(pv2[0], pv2[1]);
+      bf16x8_t bd = pack_pair(ds2[0], ds2[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        adv[dt] = mfma16(frag_tr(tr1, TS, dt, t, lane), bp, adv[dt]);
+        adk[dt] = mfma16(frag_tr(tr0, TS, dt, t, lane), bd, adk[dt]);
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      if (key < S) {
+        u32x2_t w; w[0] = pack2bf(adk[dt][0], adk[dt][1]); w[1] = pack2bf(adk[dt][2], adk[dt][3]);
+        *(u32x2_t*)(dbase + (size_t)key * ld + D + dt * 16 + 4 * g) = w;
+        u32x2_t x; x[0] = pack2bf(adv[dt][0], adv[dt][1]); x[1] = pack2bf(adv[dt][2], adv[dt][3]);
+        *(u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g) = x;
+      }
+      if (dbias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float vk = lsum16((key < S) ? adk[dt][r] : 0.f);
+          float vv = lsum16((key < S) ? adv[dt][r] : 0.f);
+          if ((lane & 15) == 0) { atomicAdd(&bias_s[64 + dt * 16 + 4 * g + r], vk); atomicAdd(&bias_s[128 + dt * 16 + 4 * g + r], vv); }
+        }
+      }
+    }
+  }
+  if (dbias) {
+    __syncthreads();
+    for (int i = tid; i < 192; i += nthr) unsafeAtomicAdd(&dbias[(i >> 6) * D + head * HD + (i & 63)], bias_s[i]);
+  }
+}
+
+int pick_nkt(int S) { int n = (S + 15) / 16; if (n <= 1) return 1; if (n <= 2) return 2; if (n <= 4) return 4; if (n <= 8) return 8; return 13; }
+
+template <int NKT> size_t fwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)NKT * 16 * 128 + 64 * (NP * 32 + 8) * 2; }
+template <int NKT> size_t bwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)2 * NKT * 16 * 128 + 2 * 64 * (NP * 32 + 8) * 2 + (2 * NP * 32 + 192) * 4; }
+
+template <int NKT>
+int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, int H, float scale, hipStream_t s) {
+  size_t sm = fwd_smem<NKT>();
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)vit_attn_fwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
+  hipLaunchKernelGGL((vit_attn_fwd_kernel<NKT>), dim3(frames * H), dim3(64 * NKT), sm, s, qkv, out, lse, S, H, scale);
+  return 0;
+}
+template <int NKT>
+int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, float* dbias,
+               int frames, int S, int H, float scale, hipStream_t s) {
+  size_t sm = bwd_smem<NKT>();
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
+  hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT>), dim3(frames * H), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, S, H, scale);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int avt_vit_attn_fwd(const void* qkv, void* out, float* lse, int frames, int S, int H, int head_dim, float scale, void* stream) {
+  AVT_CHECK(qkv && out && lse, "avt_vit_attn_fwd: null argument");
+  AVT_CHECK(head_dim == 64, "avt_vit_attn_fwd: head_dim must be 64 (got %d)", head_dim);
+  AVT_CHECK(S >= 1 && S <= 208, "avt_vit_attn_fwd: S must be in [1, 208] (got %d)", S);
+  AVT_CHECK(frames > 0 && H > 0 && aligned16(qkv) && aligned16(out), "avt_vit_attn_fwd: bad shape or alignment");
+  hipStream_t s = (hipStream_t)stream;
+  const bf16_t* q = (const bf16_t*)qkv; bf16_t* o = (bf16_t*)out;
+  switch (pick_nkt(S)) {
+    case 1: launch_fwd<1>(q, o, lse, frames, S, H, scale, s); break;
+    case 2: launch_fwd<2>(q, o, lse, frames, S, H, scale, s); break;
+    case 4: launch_fwd<4>(q, o, lse, frames, S, H, scale, s); break;
+    case 8: launch_fwd<8>(q, o, lse, frames, S, H, scale, s); break;
+    default: launch_fwd<13>(q, o, lse, frames, S, H, scale, s); break;
+  }
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int avt_vit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
+                                int frames, int S, int H, int head_dim, float scale, void* stream) {
+  AVT_CHECK(qkv && out && dout && lse && dqkv, "avt_vit_attn_bwd: null argument");
+  AVT_CHECK(head_dim == 64, "avt_vit_attn_bwd: head_dim must be 64 (got %d)", head_dim);
+  AVT_CHECK(S >= 1 && S <= 208, "avt_vit_attn_bwd: S must be in [1, 208] (got %d)", S);
+  AVT_CHECK(frames > 0 && H > 0 && aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), "avt_vit_attn_bwd: bad shape or alignment");
+  hipStream_t s = (hipStream_t)stream;
+  const bf16_t* q = (const bf16_t*)qkv; const bf16_t* o = (const bf16_t*)out; const bf16_t* d = (const bf16_t*)dout; bf16_t* dq = (bf16_t*)dqkv;
+  switch (pick_nkt(S)) {
+    case 1: launch_bwd<1>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
+    case 2: launch_bwd<2>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
+    case 4: launch_bwd<4>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
+    case 8: launch_bwd<8>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
+    default: launch_bwd<13>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
+  }
+  AVT_LAUNCH_CHECK();
+  return 0;
+}

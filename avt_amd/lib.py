@@ -1,0 +1,77 @@
+"""ctypes binding of libavt_hip.so (the C ABI declared in include/avt_hip.h).
+
+The product path has NO fallback: if the shared library is missing or an entry point is absent, importing/using
+the ops raises.  ``build()`` in ``__graft_entry__.py`` (or ``make -C avt_amd/csrc``) produces the library.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libavt_hip.so')
+ABI_VERSION = 1
+
+_P, _I, _F, _L, _U64 = c_void_p, c_int, c_float, c_long, c_uint64
+
+# name -> argtypes (restype is int unless noted); must mirror include/avt_hip.h exactly
+SIGNATURES = {
+    'avt_abi_version': [],
+    'avt_gemm_bf16': [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _U64, _P,
+                      _I, _I, _I, _P],
+    'avt_layernorm_fwd': [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P],
+    'avt_layernorm_bwd': [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
+    'avt_vit_attn_fwd': [_P, _P, _P, _I, _I, _I, _I, _F, _P],
+    'avt_vit_attn_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    'avt_causal_attn_fwd': [_P, _P, _P, _I, _I, _I, _I, _F, _F, _U64, _P],
+    'avt_causal_attn_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _U64, _P],
+    'avt_im2col_patch16': [_P, _P, _I, _I, _I, _P],
+    'avt_posres_prep': [_P, _P, _P, _P, _I, _I, _P],
+    'avt_patch_embed_bwd_reduce': [_P, _P, _P, _P, _I, _I, _I, _P],
+    'avt_cast_f32_to_bf16': [_P, _P, _L, _P],
+    'avt_cast_bf16_to_f32': [_P, _P, _L, _P],
+    'avt_dropout_bf16': [_P, _P, _L, _F, _U64, _P],
+    'avt_embed_pos_fwd': [_P, _P, _P, _I, _I, _I, _F, _U64, _P],
+    'avt_embed_pos_bwd': [_P, _P, _P, _I, _I, _I, _F, _U64, _P],
+    'avt_colsum_bf16': [_P, _I, _P, _I, _I, _P],
+    'avt_mse_shift_fwd': [_P, _P, _P, _I, _I, _I, _P],
+    'avt_xent_fwd': [_P, _I, _P, _P, _P, _P, _I, _I, _L, _P],
+    'avt_xent_bwd': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _L, _P],
+    'avt_sgd_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _I, _I, _P],
+}
+
+_lib = None
+
+
+class AvtHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libavt_hip.so once; raise loudly when it is absent (no CPU / eager fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AvtHipError(
+            f'{LIB_PATH} not found: the HIP extension is not built. Run `python -c "import __graft_entry__ as g; '
+            f'g.build()"` or `make -C avt_amd/csrc`. There is no fallback path.')
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.avt_last_error.restype = c_char_p
+    lib.avt_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    v = lib.avt_abi_version()
+    if v != ABI_VERSION:
+        raise AvtHipError(f'libavt_hip.so ABI version {v} != binding version {ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.avt_last_error()
+        raise AvtHipError(f'{name} failed (rc={rc}): {msg.decode() if msg else "?"}')

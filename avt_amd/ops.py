@@ -1,0 +1,229 @@
+"""Tensor-level wrappers over the C ABI (``avt_amd.lib``): torch is used only for device memory and streams.
+
+Every function enqueues HIP kernels on torch's current stream and returns immediately.  Inputs must live on the
+GPU; there is no CPU or eager fallback -- a missing library raises ``AvtHipError``.
+"""
+import torch
+
+from . import lib as _lib
+
+BF16 = torch.bfloat16
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_DGELU_ERF, ACT_DGELU_TANH = 0, 1, 2, 3, 4
+OUT_BF16, OUT_F32, OUT_ACCUM_F32 = 0, 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name):
+    if t.device.type != 'cuda':
+        raise _lib.AvtHipError(f'{name} must be a GPU tensor (no CPU fallback exists)')
+    if t.dtype != dtype:
+        raise _lib.AvtHipError(f'{name} must be {dtype}, got {t.dtype}')
+
+
+def _ld(t):
+    """Leading dimension (elements) of a 2-D row-major view with unit inner stride."""
+    assert t.dim() == 2 and t.stride(1) == 1, 'expected a 2-D tensor with unit inner stride'
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
+def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_BF16, bias=None, act=ACT_NONE,
+         aux=None, c2=None, res=None, res_period=0, drop_p=0.0, seed=0, colsum=None, splitk=0, tile=0):
+    """C[M,N] = epilogue(sum_k opA[m,k] opB[n,k]); see avt_gemm_bf16 in include/avt_hip.h."""
+    _chk(A, BF16, 'A'); _chk(B, BF16, 'B')
+    if out is None:
+        assert out_mode != OUT_ACCUM_F32, 'accumulate mode needs an output buffer'
+        out = torch.empty((M, N), device=A.device, dtype=BF16 if out_mode == OUT_BF16 else torch.float32)
+    _lib.call('avt_gemm_bf16', _p(A), int(a_kmajor), _ld(A), _p(B), int(b_kmajor), _ld(B), _p(out), _ld(out), M, N, K,
+              _p(bias), act, _p(aux), _ld(aux) if aux is not None else 0, _p(c2), _ld(c2) if c2 is not None else 0,
+              _p(res), _ld(res) if res is not None else 0, res_period, float(drop_p), int(seed), _p(colsum),
+              out_mode, splitk, tile, _stream())
+    return out
+
+
+# ---- the six contractions of a Linear (weight (out,in)) / HF Conv1D (weight (in,out)) layer ---------------------
+def linear_fwd(x, w, **kw):
+    """y[M,N] = x[M,K] @ w[N,K]^T"""
+    return gemm(x, w, x.size(0), w.size(0), w.size(1), a_kmajor=True, b_kmajor=True, **kw)
+
+
+def linear_dgrad(dy, w, **kw):
+    """dx[M,K] = dy[M,N] @ w[N,K]"""
+    return gemm(dy, w, dy.size(0), w.size(1), w.size(0), a_kmajor=True, b_kmajor=False, **kw)
+
+
+def linear_wgrad(dy, x, dw, rows=None, **kw):
+    """dw[N,K] (fp32) += dy[M,N]^T @ x[M,K]; ``rows`` limits the valid output rows (padded classifier)."""
+    n = dw.size(0) if rows is None else rows
+    return gemm(dy, x, n, x.size(1), dy.size(0), a_kmajor=False, b_kmajor=False, out=dw, out_mode=OUT_ACCUM_F32, **kw)
+
+
+def conv1d_fwd(x, w, **kw):
+    """y[M,N] = x[M,K] @ w[K,N]"""
+    return gemm(x, w, x.size(0), w.size(1), w.size(0), a_kmajor=True, b_kmajor=False, **kw)
+
+
+def conv1d_dgrad(dy, w, **kw):
+    """dx[M,K] = dy[M,N] @ w[K,N]^T"""
+    return gemm(dy, w, dy.size(0), w.size(0), w.size(1), a_kmajor=True, b_kmajor=True, **kw)
+
+
+def conv1d_wgrad(x, dy, dw, **kw):
+    """dw[K,N] (fp32) += x[M,K]^T @ dy[M,N]"""
+    return gemm(x, dy, x.size(1), dy.size(1), x.size(0), a_kmajor=False, b_kmajor=False, out=dw, out_mode=OUT_ACCUM_F32, **kw)
+
+
+# ---- LayerNorm -------------------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, rows=None, ldx=None, save_stats=True):
+    """x: 2-D bf16 view; optional (rows, ldx) override lets the caller normalise strided rows (CLS select)."""
+    _chk(x, BF16, 'x')
+    D = gamma.numel()
+    if rows is None:
+        rows, ldx = x.size(0), _ld(x)
+    y = torch.empty((rows, D), device=x.device, dtype=BF16)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32) if save_stats else None
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if save_stats else None
+    _lib.call('avt_layernorm_fwd', _p(x), ldx, _p(gamma), _p(beta), _p(y), D, _p(mean), _p(rstd), rows, D, float(eps), _stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, colsum=None, rows=None, ldx=None, dx=None, lddx=None):
+    _chk(dy, BF16, 'dy'); _chk(x, BF16, 'x')
+    D = gamma.numel()
+    if rows is None:
+        rows, ldx = x.size(0), _ld(x)
+    if dx is None:
+        dx = torch.empty((rows, D), device=x.device, dtype=BF16)
+        lddx = D
+    _lib.call('avt_layernorm_bwd', _p(dy), _ld(dy), _p(x), ldx, _p(mean), _p(rstd), _p(gamma), _p(dres),
+              _ld(dres) if dres is not None else 0, _p(dx), lddx, _p(dgamma), _p(dbeta), _p(colsum), rows, D, _stream())
+    return dx
+
+
+# ---- attention cores ---------------------------------------------------------------------------------------------------
+def vit_attn_fwd(qkv, frames, S, H):
+    _chk(qkv, BF16, 'qkv')
+    D = H * 64
+    out = torch.empty((frames * S, D), device=qkv.device, dtype=BF16)
+    lse = torch.empty((frames, H, S), device=qkv.device, dtype=torch.float32)
+    _lib.call('avt_vit_attn_fwd', _p(qkv), _p(out), _p(lse), frames, S, H, 64, 0.125, _stream())
+    return out, lse
+
+
+def vit_attn_bwd(qkv, out, dout, lse, frames, S, H, dbias=None):
+    dqkv = torch.empty_like(qkv)
+    _lib.call('avt_vit_attn_bwd', _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(dbias), frames, S, H, 64, 0.125, _stream())
+    return dqkv
+
+
+def causal_attn_fwd(qkv, B, T, H, hd, drop_p=0.0, seed=0):
+    _chk(qkv, BF16, 'qkv')
+    out = torch.empty((B * T, H * hd), device=qkv.device, dtype=BF16)
+    probs = torch.empty((B, H, T, T), device=qkv.device, dtype=torch.float32)
+    _lib.call('avt_causal_attn_fwd', _p(qkv), _p(out), _p(probs), B, T, H, hd, float(hd) ** -0.5, float(drop_p), int(seed), _stream())
+    return out, probs
+
+
+def causal_attn_bwd(qkv, probs, dout, B, T, H, hd, drop_p=0.0, seed=0):
+    dqkv = torch.empty_like(qkv)
+    _lib.call('avt_causal_attn_bwd', _p(qkv), _p(probs), _p(dout), _p(dqkv), B, T, H, hd, float(hd) ** -0.5, float(drop_p), int(seed), _stream())
+    return dqkv
+
+
+# ---- patch embedding helpers ---------------------------------------------------------------------------------------------
+def im2col_patch16(frames):
+    """frames fp32 [N,3,H,W] -> bf16 [N*(P+1), 768] with a zero CLS row per frame."""
+    _chk(frames, torch.float32, 'frames')
+    frames = frames.contiguous()
+    n, _, h, w = frames.shape
+    rows = n * ((h // 16) * (w // 16) + 1)
+    out = torch.empty((rows, 768), device=frames.device, dtype=BF16)
+    _lib.call('avt_im2col_patch16', _p(frames), _p(out), n, h, w, _stream())
+    return out
+
+
+def posres_prep(pos, cls, bias, S, D):
+    R = torch.empty((S, D), device=pos.device, dtype=BF16)
+    _lib.call('avt_posres_prep', _p(pos), _p(cls), _p(bias), _p(R), S, D, _stream())
+    return R
+
+
+def patch_embed_bwd_reduce(dx0, dpos, dcls, dbias, N, S, D):
+    _lib.call('avt_patch_embed_bwd_reduce', _p(dx0), _p(dpos), _p(dcls), _p(dbias), N, S, D, _stream())
+
+
+# ---- elementwise ---------------------------------------------------------------------------------------------------------
+def cast_to_bf16(src, dst=None):
+    _chk(src, torch.float32, 'src')
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=BF16)
+    _lib.call('avt_cast_f32_to_bf16', _p(src), _p(dst), src.numel(), _stream())
+    return dst
+
+
+def cast_to_f32(src):
+    _chk(src, BF16, 'src')
+    dst = torch.empty(src.shape, device=src.device, dtype=torch.float32)
+    _lib.call('avt_cast_bf16_to_f32', _p(src), _p(dst), src.numel(), _stream())
+    return dst
+
+
+def dropout(x, p, seed):
+    _chk(x, BF16, 'x')
+    y = torch.empty_like(x)
+    _lib.call('avt_dropout_bf16', _p(x), _p(y), x.numel(), float(p), int(seed), _stream())
+    return y
+
+
+def embed_pos_fwd(enc, wpe, B, T, E, p, seed):
+    h = torch.empty_like(enc)
+    _lib.call('avt_embed_pos_fwd', _p(enc), _p(wpe), _p(h), B, T, E, float(p), int(seed), _stream())
+    return h
+
+
+def embed_pos_bwd(dh, dwpe, B, T, E, p, seed):
+    denc = torch.empty_like(dh)
+    _lib.call('avt_embed_pos_bwd', _p(dh), _p(denc), _p(dwpe), B, T, E, float(p), int(seed), _stream())
+    return denc
+
+
+def colsum(x, out):
+    _chk(x, BF16, 'x')
+    _lib.call('avt_colsum_bf16', _p(x), _ld(x), _p(out), x.size(0), x.size(1), _stream())
+
+
+def mse_shift_fwd(dec, x, B, T, F):
+    loss = torch.empty((B, T - 1, F), device=dec.device, dtype=torch.float32)
+    _lib.call('avt_mse_shift_fwd', _p(dec), _p(x), _p(loss), B, T, F, _stream())
+    return loss
+
+
+# ---- cross entropy ---------------------------------------------------------------------------------------------------------
+def xent_fwd(logits, target, C, ignore_index=-1):
+    """logits fp32 [R, ld>=C]; returns (loss[R], lse[R], rank[R])."""
+    _chk(logits, torch.float32, 'logits')
+    R = logits.size(0)
+    loss = torch.empty(R, device=logits.device, dtype=torch.float32)
+    lse = torch.empty(R, device=logits.device, dtype=torch.float32)
+    rank = torch.empty(R, device=logits.device, dtype=torch.int32)
+    _lib.call('avt_xent_fwd', _p(logits), _ld(logits), _p(target), _p(loss), _p(lse), _p(rank), R, C, ignore_index, _stream())
+    return loss, lse, rank
+
+
+def xent_bwd(logits, target, lse, gout, C, ldd, ignore_index=-1):
+    R = logits.size(0)
+    dlogits = torch.empty((R, ldd), device=logits.device, dtype=BF16)
+    _lib.call('avt_xent_bwd', _p(logits), _ld(logits), _p(target), _p(lse), _p(gout), _p(dlogits), ldd, R, C, ignore_index, _stream())
+    return dlogits
+
+
+# ---- optimizer -------------------------------------------------------------------------------------------------------------
+def sgd_step(param, grad, buf, shadow, lr, momentum, weight_decay, grad_scale=1.0, nesterov=True, first_step=False, zero_grad=True):
+    _lib.call('avt_sgd_step', _p(param), _p(grad), _p(buf), _p(shadow), param.numel(), float(lr), float(momentum),
+              float(weight_decay), float(grad_scale), int(nesterov), int(first_step), int(zero_grad), _stream())

@@ -1,0 +1,124 @@
+/* avt_hip.h -- C ABI of libavt_hip.so: the MI355X (gfx950) kernels behind the AVT training hot path.
+ *
+ * This is the drop-in boundary.  The reference (facebookresearch/AVT) is pure Python: its "FFI" for this path is
+ * the set of torch.nn calls its modules make.  Each entry point below names the reference call it replaces
+ * (file:line in the upstream checkout; [timm]/[hf] = the un-vendored timm==0.4.12 / transformers==4.2.2 code those
+ * lines dispatch into).  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, explicit dims / leading dimensions (in ELEMENTS), scalar hyper-parameters and an
+ *     explicit hipStream_t (passed as void*).  No torch types.  Nothing is allocated or retained by the library;
+ *     kernels are enqueued on `stream` and the call returns immediately (never synchronises).
+ *   - activations and activation gradients are bf16 (raw uint16 bits); statistics, losses, parameters' master copies,
+ *     parameter gradients and optimizer state are fp32.
+ *   - return 0 on success; non-zero on failure, in which case avt_last_error() (thread-local) describes it.
+ *     Shape / alignment violations are rejected on the host before any launch.
+ *   - re-entrant, no dependence on the thread's "current device/stream" (forward runs on the Python main thread,
+ *     backward on the autograd thread -- SURVEY 8b).
+ *   - parameter-gradient outputs ACCUMULATE (fp32 atomics): the caller keeps the gradient buffer zeroed between
+ *     steps (avt_sgd_step can re-zero it while it consumes it).
+ */
+#ifndef AVT_HIP_H_
+#define AVT_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVT_ABI_VERSION 1
+
+const char* avt_last_error(void);
+int avt_abi_version(void);
+
+/* ---- GEMM -------------------------------------------------------------------------------------------------------
+ * C[M,N] = epilogue( sum_k opA[m,k] * opB[n,k] ), bf16 inputs, fp32 accumulate (v_mfma_f32_32x32x16_bf16).
+ *   a_kmajor = 1: A stored [M][K] (row stride lda);  0: A stored [K][M] (the reduction index is the row index).
+ *   b_kmajor = 1: B stored [N][K] (row stride ldb);  0: B stored [K][N].
+ * Replaces every torch.nn.Linear / HF Conv1D matmul of the step and their autograd backward:
+ *   ViT qkv/proj/fc1/fc2 [timm] (models/video_classification.py:224), patch-embed Conv2d as a GEMM over avt_im2col
+ *   rows, AVT-h encoder/decoder (models/future_prediction.py:80-81,163,190), GPT-2 c_attn/c_proj/c_fc [hf]
+ *   (models/future_prediction.py:178-181), classifier (models/base_model.py:203-216, 222-238).
+ * out_mode 0: bf16 C, 1: fp32 C, with the fused epilogue, applied in this order:
+ *     v = acc + bias[n];  act 3|4: v *= gelu_erf'|gelu_tanh'(aux[m,n]);  C2[m,n] = v (optional pre-activation copy);
+ *     act 1|2: v = gelu_erf|gelu_tanh(v);  dropout(drop_p, drop_seed, element index m*N+n);
+ *     v += res[(res_period ? m % res_period : m), n];  colsum[n] += v (fp32 atomics);  C[m,n] = v
+ * out_mode 2: C (fp32) += acc with atomics, no epilogue; splitk > 1 splits the reduction over workgroups
+ *             (splitk <= 0 picks a factor that fills the chip).  Used for weight gradients.
+ * tile: 0 = choose, 64 | 128 = force the block tile.  Requirements: 16-B aligned pointers, lda/ldb % 8 == 0,
+ * K % 8 == 0 when an operand is k-major, N % 4 == 0 and ldc % 4 == 0 for out_mode 0/1. */
+int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,
+                  void* C, int ldc, int M, int N, int K,
+                  const float* bias, int act, const void* aux, int ldaux,
+                  void* C2, int ldc2, const void* res, int ldres, int res_period,
+                  float drop_p, uint64_t drop_seed, float* colsum,
+                  int out_mode, int splitk, int tile, void* stream);
+
+/* ---- LayerNorm ---------------------------------------------------------------------------------------------------
+ * [timm] Block.norm1/norm2/VisionTransformer.norm (eps 1e-6); [hf] GPT2 ln_1/ln_2/ln_f (eps 1e-5).
+ * fwd: y = (x-mean)*rstd*gamma+beta, rows of D (% 8 == 0, <= 4096) bf16, strided rows allowed; mean/rstd may be NULL.
+ * bwd: dx = LN'(dy) [+ dres];  dgamma/dbeta/colsum (fp32 [D], may be NULL) accumulate; colsum = column sums of dx. */
+int avt_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy,
+                      float* mean, float* rstd, int rows, int D, float eps, void* stream);
+int avt_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
+                      const float* gamma, const void* dres, int lddres, void* dx, int lddx,
+                      float* dgamma, float* dbeta, float* colsum, int rows, int D, void* stream);
+
+/* ---- ViT spatial attention core ----------------------------------------------------------------------------------
+ * [timm] Attention.forward: softmax(q k^T * scale) v per (frame, head); qkv [frames*S, 3*H*64] with columns [q|k|v]
+ * head-major; out [frames*S, H*64]; lse fp32 [frames, H, S].  S <= 208, head_dim == 64.
+ * bwd writes dqkv (same layout) and accumulates dbias[3*H*64] += column sums of dqkv (may be NULL). */
+int avt_vit_attn_fwd(const void* qkv, void* out, float* lse, int frames, int S, int H, int head_dim, float scale, void* stream);
+int avt_vit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
+                     int frames, int S, int H, int head_dim, float scale, void* stream);
+
+/* ---- AVT-h causal attention core ---------------------------------------------------------------------------------
+ * [hf] GPT2Attention._attn via models/future_prediction.py:178-181: softmax(causal(q k^T * scale)), attention dropout,
+ * times v.  qkv [B*T, 3*H*hd]; probs fp32 [B,H,T,T] = pre-dropout probabilities saved for backward.  T <= 32. */
+int avt_causal_attn_fwd(const void* qkv, void* out, float* probs, int B, int T, int H, int head_dim, float scale,
+                        float drop_p, uint64_t seed, void* stream);
+int avt_causal_attn_bwd(const void* qkv, const float* probs, const void* dout, void* dqkv, int B, int T, int H,
+                        int head_dim, float scale, float drop_p, uint64_t seed, void* stream);
+
+/* ---- patch embedding helpers ([timm] PatchEmbed + cls_token/pos_embed, via models/video_classification.py:213-227) --
+ * avt_im2col_patch16: video fp32 [N,3,H,W] -> bf16 rows [N*(P+1), 768], row n*(P+1) (CLS slot) zero, k = c*256+ky*16+kx.
+ * avt_posres_prep:    R[s,:] = pos[s,:] + (s == 0 ? cls : conv_bias)  (bf16 [S,D]) = row-periodic residual of the GEMM.
+ * avt_patch_embed_bwd_reduce: dx0 bf16 [N,S,D] -> dpos[S,D] += sum_n; dcls[D] += row 0; dbias[D] += rows >= 1. */
+int avt_im2col_patch16(const float* video, void* patches, int N, int Himg, int Wimg, void* stream);
+int avt_posres_prep(const float* pos, const float* cls, const float* bias, void* R, int S, int D, void* stream);
+int avt_patch_embed_bwd_reduce(const void* dx, float* dpos, float* dcls, float* dbias, int N, int S, int D, void* stream);
+
+/* ---- elementwise ---------------------------------------------------------------------------------------------------
+ * casts (bf16 shadow of fp32 parameters), dropout (nn.Dropout, models/base_model.py:81,204,215; also its own backward),
+ * GPT-2 position embedding + embd dropout ([hf] GPT2Model.forward: inputs_embeds + wpe(position_ids), drop) and its
+ * backward (denc = dh*mask, dwpe[t] += sum_b), column sums (bias gradients), shifted MSE
+ * (models/future_prediction.py:207-215: (decoded[:, :T-1] - feats[:, 1:T])^2, fp32 [B,T-1,F]). */
+int avt_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
+int avt_cast_bf16_to_f32(const void* src, float* dst, long n, void* stream);
+int avt_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, void* stream);
+int avt_embed_pos_fwd(const void* enc, const float* wpe, void* h, int B, int T, int E, float p, uint64_t seed, void* stream);
+int avt_embed_pos_bwd(const void* dh, void* denc, float* dwpe, int B, int T, int E, float p, uint64_t seed, void* stream);
+int avt_colsum_bf16(const void* x, int ld, float* out, int M, int N, void* stream);
+int avt_mse_shift_fwd(const void* dec, const void* x, float* loss, int B, int T, int F, void* stream);
+
+/* ---- softmax cross-entropy -------------------------------------------------------------------------------------------
+ * loss_fn/multidim_xentropy.py:11-25 (CrossEntropyLoss(ignore_index=-1, reduction='none')) + common/utils.py:17-44.
+ * logits fp32 [R, ld], C valid columns; target int64 [R]; loss/lse fp32 [R]; rank int32 [R] (#logits > target logit,
+ * -1 for ignored rows; may be NULL).  bwd: dlogits bf16 [R, ldd] = (softmax - onehot) * gout[r], padding columns zero. */
+int avt_xent_fwd(const float* logits, int ld, const long* target, float* loss, float* lse, int* rank, int R, int C,
+                 long ignore_index, void* stream);
+int avt_xent_bwd(const float* logits, int ld, const long* target, const float* lse, const float* gout, void* dlogits,
+                 int ldd, int R, int C, long ignore_index, void* stream);
+
+/* ---- optimizer -------------------------------------------------------------------------------------------------------
+ * torch.optim.SGD(momentum, nesterov, weight_decay) over a flat fp32 range (func/train.py:233, conf/opt/optimizer/sgd.yaml):
+ * g = grad*grad_scale + wd*p; buf = first ? g : mom*buf + g; p -= lr*(nesterov ? g + mom*buf : buf).
+ * Also writes the bf16 shadow (may be NULL) and re-zeroes grad when zero_grad != 0. */
+int avt_sgd_step(float* param, float* grad, float* momentum_buf, void* shadow_bf16, long n, float lr, float momentum,
+                 float weight_decay, float grad_scale, int nesterov, int first_step, int zero_grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVT_HIP_H_ */

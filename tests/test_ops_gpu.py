@@ -1,0 +1,340 @@
+"""Per-kernel parity (-m gpu): every HIP op, called through the C ABI, against a plain PyTorch fp32 evaluation of
+the same op on the same (bf16-rounded) inputs.  Tolerances are stated per test: outputs are bf16 (8 mantissa
+bits), accumulation is fp32, so errors are a few bf16 ulps of the output scale."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from avt_amd import ops as _ops
+    return _ops
+
+
+def rnd(shape, scale=1.0, seed=0, dtype=torch.bfloat16):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    return (torch.randn(shape, device='cuda', generator=g) * scale).to(dtype)
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (197 * 3, 768, 768), (1000, 2304, 768), (160, 6144, 2048),
+               (37, 64, 32), (200, 100, 200), (64, 3840, 768), (3152, 768, 3072)]
+
+
+@pytest.mark.parametrize('M,N,K', GEMM_SHAPES)
+@pytest.mark.parametrize('layout', ['NT', 'NN'])
+def test_gemm_plain(ops, M, N, K, layout):
+    """asymmetric random operands (transpose-detecting); bf16 out: tol 1e-2 of max|C|, fp32 out: 2e-3."""
+    if K % 8 or N % 4 or (layout == 'NN' and N % 8):
+        pytest.skip('unsupported alignment for this layout')
+    a = rnd((M, K), 1.0, 1)
+    if layout == 'NT':
+        b = rnd((N, K), 1.0, 2)
+        ref = a.float() @ b.float().t()
+        out = ops.gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=True, out_mode=ops.OUT_F32)
+    else:
+        b = rnd((K, N), 1.0, 2)
+        ref = a.float() @ b.float()
+        out = ops.gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=False, out_mode=ops.OUT_F32)
+    torch.cuda.synchronize()
+    assert relerr(out, ref) < 2e-3, relerr(out, ref)
+    for tile in (64, 128):
+        o2 = ops.gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=(layout == 'NT'), out_mode=ops.OUT_BF16, tile=tile)
+        torch.cuda.synchronize()
+        assert relerr(o2, ref) < 1e-2, (tile, relerr(o2, ref))
+
+
+@pytest.mark.parametrize('M,P,Q', [(64, 128, 128), (500, 768, 768), (3152, 2304, 768), (160, 2048, 6144), (176, 3840, 768),
+                                   (77, 64, 32), (1000, 256, 64)])
+def test_gemm_tn_accumulate(ops, M, P, Q):
+    """weight-gradient form: C[P,Q] += A[M,P]^T B[M,Q] (fp32 atomics, split-K); run twice -> 2x; tol 2e-3."""
+    a, b = rnd((M, P), 1.0, 3), rnd((M, Q), 1.0, 4)
+    ref = a.float().t() @ b.float()
+    for splitk, tile in ((0, 0), (1, 128), (3, 64)):
+        c = torch.zeros((P, Q), device='cuda', dtype=torch.float32)
+        ops.gemm(a, b, P, Q, M, a_kmajor=False, b_kmajor=False, out=c, out_mode=ops.OUT_ACCUM_F32, splitk=splitk, tile=tile)
+        ops.gemm(a, b, P, Q, M, a_kmajor=False, b_kmajor=False, out=c, out_mode=ops.OUT_ACCUM_F32, splitk=splitk, tile=tile)
+        torch.cuda.synchronize()
+        assert relerr(c, 2 * ref) < 2e-3, (splitk, tile, relerr(c, 2 * ref))
+
+
+def test_gemm_tn_row_limit(ops):
+    """padded classifier: only the first `rows` output rows may be written."""
+    M, P, Q, rows = 176, 128, 64, 100
+    a, b = rnd((M, P), 1.0, 5), rnd((M, Q), 1.0, 6)
+    c = torch.zeros((P, Q), device='cuda', dtype=torch.float32)
+    ops.gemm(a, b, rows, Q, M, a_kmajor=False, b_kmajor=False, out=c, out_mode=ops.OUT_ACCUM_F32)
+    torch.cuda.synchronize()
+    ref = a.float().t() @ b.float()
+    assert relerr(c[:rows], ref[:rows]) < 2e-3
+    assert float(c[rows:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_gemm_epilogue_bias_act_res(ops, act):
+    M, N, K = 333, 256, 128
+    a, b = rnd((M, K), 0.5, 7), rnd((N, K), 0.5, 8)
+    bias = rnd((N,), 0.5, 9, torch.float32)
+    res = rnd((M, N), 1.0, 10)
+    pre = a.float() @ b.float().t() + bias
+    if act == 1:
+        post = torch.nn.functional.gelu(pre)
+    elif act == 2:
+        post = torch.nn.functional.gelu(pre, approximate='tanh')
+    else:
+        post = pre
+    ref = post + res.float()
+    c2 = torch.empty((M, N), device='cuda', dtype=torch.bfloat16)
+    cs = torch.zeros(N, device='cuda', dtype=torch.float32)
+    out = ops.gemm(a, b, M, N, K, bias=bias, act=act, c2=c2, res=res, colsum=cs)
+    torch.cuda.synchronize()
+    assert relerr(out, ref) < 1e-2
+    assert relerr(c2, pre) < 1e-2
+    assert relerr(cs, ref.sum(0)) < 1e-2
+    # row-periodic residual (patch-embed positional table)
+    period = 37
+    resp = rnd((period, N), 1.0, 11)
+    out = ops.gemm(a, b, M, N, K, res=resp, res_period=period)
+    torch.cuda.synchronize()
+    ref = a.float() @ b.float().t() + resp.float()[torch.arange(M, device='cuda') % period]
+    assert relerr(out, ref) < 1e-2
+
+
+@pytest.mark.parametrize('act', [3, 4])
+def test_gemm_epilogue_dgelu(ops, act):
+    M, N, K = 200, 128, 192
+    a, b = rnd((M, K), 0.5, 12), rnd((N, K), 0.5, 13)
+    h = rnd((M, N), 1.5, 14)
+    hh = h.float().requires_grad_(True)
+    g = torch.nn.functional.gelu(hh, approximate='none' if act == 3 else 'tanh')
+    g.sum().backward()
+    ref = (a.float() @ b.float().t()) * hh.grad
+    out = ops.gemm(a, b, M, N, K, act=act, aux=h)
+    torch.cuda.synchronize()
+    assert relerr(out, ref) < 1e-2
+
+
+def test_gemm_epilogue_dropout(ops):
+    M, N, K = 256, 256, 64
+    a, b = rnd((M, K), 0.5, 15), rnd((N, K), 0.5, 16)
+    ref = a.float() @ b.float().t()
+    out = ops.gemm(a, b, M, N, K, drop_p=0.25, seed=1234, out_mode=ops.OUT_F32)
+    out2 = ops.gemm(a, b, M, N, K, drop_p=0.25, seed=1234, out_mode=ops.OUT_F32)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)                          # mask is a pure function of (seed, index)
+    kept = out != 0
+    frac = float(kept.float().mean())
+    assert abs(frac - 0.75) < 0.02, frac
+    assert relerr(out[kept], (ref / 0.75)[kept]) < 2e-3
+    # the standalone dropout kernel reproduces the same mask for the same (seed, index)
+    ones = torch.ones((M, N), device='cuda', dtype=torch.bfloat16)
+    m = ops.dropout(ones, 0.25, 1234)
+    torch.cuda.synchronize()
+    assert torch.equal(m != 0, kept)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('rows,D,eps', [(197 * 4, 768, 1e-6), (160, 2048, 1e-5), (33, 64, 1e-6), (100, 1024, 1e-6)])
+def test_layernorm(ops, rows, D, eps):
+    x = rnd((rows, D), 2.0, 20) + 0.5
+    gamma = (1 + 0.1 * torch.randn(D, device='cuda')).float()
+    beta = (0.1 * torch.randn(D, device='cuda')).float()
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
+    xr = x.float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, eps)
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < 1e-2
+    assert relerr(mean, xr.mean(1)) < 1e-4
+    dy = rnd((rows, D), 1.0, 21)
+    dres = rnd((rows, D), 1.0, 22)
+    ref.backward(dy.float())
+    dgam = torch.zeros(D, device='cuda'); dbet = torch.zeros(D, device='cuda'); cs = torch.zeros(D, device='cuda')
+    dx = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dgam, dbet, dres=dres, colsum=cs)
+    torch.cuda.synchronize()
+    ref_dx = xr.grad + dres.float()
+    assert relerr(dx, ref_dx) < 1e-2
+    assert relerr(dgam, gr.grad) < 5e-3
+    assert relerr(dbet, br.grad) < 5e-3
+    assert relerr(cs, ref_dx.sum(0)) < 2e-2
+
+
+def test_layernorm_strided_rows(ops):
+    """final ViT norm on the CLS rows only: input row stride = S*D."""
+    N, S, D = 6, 5, 64
+    x = rnd((N * S, D), 1.0, 23)
+    gamma, beta = torch.ones(D, device='cuda'), torch.zeros(D, device='cuda')
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-6, rows=N, ldx=S * D)
+    ref = torch.nn.functional.layer_norm(x.float().view(N, S, D)[:, 0], (D,), gamma, beta, 1e-6)
+    torch.cuda.synchronize()
+    assert relerr(y, ref) < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('frames,S,H', [(3, 197, 12), (2, 5, 4), (2, 17, 2), (1, 50, 3), (2, 100, 2), (1, 208, 1)])
+def test_vit_attention(ops, frames, S, H):
+    D = H * 64
+    qkv = rnd((frames * S, 3 * D), 1.0, 30)
+    out, lse = ops.vit_attn_fwd(qkv, frames, S, H)
+    t = qkv.float().view(frames, S, 3, H, 64).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)
+    q, k, v = t[0], t[1], t[2]
+    att = (q @ k.transpose(-2, -1)) * 0.125
+    ref_lse = torch.logsumexp(att, -1)
+    ref = (att.softmax(-1) @ v).transpose(1, 2).reshape(frames * S, D)
+    torch.cuda.synchronize()
+    assert relerr(out, ref) < 1e-2, relerr(out, ref)
+    assert float((lse - ref_lse).abs().max()) < 1e-3
+    dout = rnd((frames * S, D), 1.0, 31)
+    ref.backward(dout.float())
+    ref_dqkv = t.grad.permute(1, 3, 0, 2, 4).reshape(frames * S, 3 * D)
+    dbias = torch.zeros(3 * D, device='cuda')
+    dqkv = ops.vit_attn_bwd(qkv, out, dout, lse, frames, S, H, dbias=dbias)
+    torch.cuda.synchronize()
+    for j, name in enumerate('qkv'):
+        e = relerr(dqkv[:, j * D:(j + 1) * D], ref_dqkv[:, j * D:(j + 1) * D])
+        assert e < 2e-2, (name, e)
+    assert relerr(dbias, ref_dqkv.sum(0)) < 2e-2
+
+
+@pytest.mark.parametrize('B,T,H,hd,p', [(2, 10, 4, 512, 0.0), (3, 15, 4, 16, 0.0), (2, 10, 4, 64, 0.1), (1, 32, 2, 32, 0.0)])
+def test_causal_attention(ops, B, T, H, hd, p):
+    E = H * hd
+    qkv = rnd((B * T, 3 * E), 1.0, 40)
+    out, probs = ops.causal_attn_fwd(qkv, B, T, H, hd, drop_p=p, seed=77)
+    t = qkv.float().view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)
+    q, k, v = t[0], t[1], t[2]
+    att = (q @ k.transpose(-2, -1)) / math.sqrt(hd)
+    mask = torch.tril(torch.ones(T, T, device='cuda', dtype=torch.bool))
+    att = att.masked_fill(~mask, float('-inf')).softmax(-1)
+    torch.cuda.synchronize()
+    assert float((probs - att).abs().max()) < 2e-3
+    if p > 0:      # rebuild the kernel's mask from its output probabilities convention: dropped = pure fn of (seed, idx)
+        ones = torch.ones(B * H * T * T, device='cuda', dtype=torch.bfloat16)
+        keep = (ops.dropout(ones, p, 77).float() != 0).view(B, H, T, T)
+        att_d = att * keep / (1 - p)
+    else:
+        att_d = att
+    ref = (att_d @ v).transpose(1, 2).reshape(B * T, E)
+    assert relerr(out, ref) < 1e-2
+    dout = rnd((B * T, E), 1.0, 41)
+    ref.backward(dout.float())
+    ref_dqkv = t.grad.permute(1, 3, 0, 2, 4).reshape(B * T, 3 * E)
+    dqkv = ops.causal_attn_bwd(qkv, probs, dout, B, T, H, hd, drop_p=p, seed=77)
+    torch.cuda.synchronize()
+    assert relerr(dqkv, ref_dqkv) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_im2col_and_patch_embed(ops):
+    N, D, IMG = 3, 64, 32
+    frames = torch.rand((N, 3, IMG, IMG), device='cuda') * 2 - 1
+    w = rnd((D, 3, 16, 16), 0.05, 50, torch.float32)
+    bias = rnd((D,), 0.1, 51, torch.float32)
+    pos = rnd((1, 5, D), 0.1, 52, torch.float32)
+    cls = rnd((1, 1, D), 0.1, 53, torch.float32)
+    patches = ops.im2col_patch16(frames)
+    ref_p = torch.nn.functional.unfold(frames, 16, stride=16).transpose(1, 2)       # (N, 4, 768)
+    torch.cuda.synchronize()
+    got = patches.float().view(N, 5, 768)
+    assert float(got[:, 0].abs().max()) == 0.0
+    assert relerr(got[:, 1:], ref_p) < 5e-3
+    R = ops.posres_prep(pos, cls, bias, 5, D)
+    x0 = ops.gemm(patches, ops.cast_to_bf16(w.view(D, 768)), N * 5, D, 768, res=R, res_period=5)
+    conv = torch.nn.functional.conv2d(frames, w, bias, stride=16).flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.expand(N, -1, -1), conv], 1) + pos
+    torch.cuda.synchronize()
+    assert relerr(x0.view(N, 5, D), ref) < 1e-2
+    dx0 = rnd((N * 5, D), 1.0, 54)
+    dpos = torch.zeros(5 * D, device='cuda'); dcls = torch.zeros(D, device='cuda'); dbias = torch.zeros(D, device='cuda')
+    ops.patch_embed_bwd_reduce(dx0, dpos, dcls, dbias, N, 5, D)
+    torch.cuda.synchronize()
+    d = dx0.float().view(N, 5, D)
+    assert relerr(dpos.view(5, D), d.sum(0)) < 1e-4
+    assert relerr(dcls, d[:, 0].sum(0)) < 1e-4
+    assert relerr(dbias, d[:, 1:].sum((0, 1))) < 1e-4
+
+
+def test_embed_pos_mse_colsum_cast(ops):
+    B, T, E = 3, 10, 64
+    enc = rnd((B * T, E), 1.0, 60)
+    wpe = rnd((1024, E), 0.1, 61, torch.float32)
+    h = ops.embed_pos_fwd(enc, wpe, B, T, E, 0.0, 0)
+    torch.cuda.synchronize()
+    assert relerr(h.view(B, T, E), enc.float().view(B, T, E) + wpe[:T]) < 1e-2
+    dh = rnd((B * T, E), 1.0, 62)
+    dwpe = torch.zeros((1024, E), device='cuda')
+    denc = ops.embed_pos_bwd(dh, dwpe, B, T, E, 0.0, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(denc, dh)
+    assert relerr(dwpe[:T], dh.float().view(B, T, E).sum(0)) < 1e-4 and float(dwpe[T:].abs().max()) == 0
+    hd = ops.embed_pos_fwd(enc, wpe, B, T, E, 0.5, 9)
+    dd = ops.embed_pos_bwd(dh, dwpe, B, T, E, 0.5, 9)
+    torch.cuda.synchronize()
+    assert torch.equal(hd != 0, dd != 0) or float(((hd != 0) ^ (dd != 0)).float().mean()) < 0.01
+    F = 48
+    dec, x = rnd((B * T, F), 1.0, 63), rnd((B * T, F), 1.0, 64)
+    loss = ops.mse_shift_fwd(dec, x, B, T, F)
+    ref = (dec.float().view(B, T, F)[:, :T - 1] - x.float().view(B, T, F)[:, 1:]) ** 2
+    torch.cuda.synchronize()
+    assert relerr(loss, ref) < 1e-5
+    m = rnd((1000, 256), 1.0, 65)
+    cs = torch.zeros(256, device='cuda')
+    ops.colsum(m, cs)
+    torch.cuda.synchronize()
+    assert relerr(cs, m.float().sum(0)) < 1e-4
+    f = rnd((1000003,), 1.0, 66, torch.float32)
+    bf = ops.cast_to_bf16(f)
+    torch.cuda.synchronize()
+    assert torch.equal(bf, f.to(torch.bfloat16))
+    assert torch.equal(ops.cast_to_f32(bf), bf.float())
+
+
+def test_xent(ops):
+    R, C, LD = 37, 3806, 3840
+    logits = torch.zeros((R, LD), device='cuda')
+    logits[:, :C] = torch.randn((R, C), device='cuda') * 3
+    logits[:, C:] = 1e9                                         # padding must be ignored
+    tgt = torch.randint(0, C, (R,), device='cuda')
+    tgt[::5] = -1
+    loss, lse, rank = ops.xent_fwd(logits, tgt, C)
+    lr = logits[:, :C].clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, tgt, ignore_index=-1, reduction='none')
+    torch.cuda.synchronize()
+    assert float((loss - ref).abs().max()) < 1e-4
+    valid = tgt >= 0
+    ref_rank = (lr.detach() > lr.detach().gather(1, tgt.clamp(min=0)[:, None])).sum(1)
+    assert torch.equal(rank[valid].long(), ref_rank[valid]) and bool((rank[~valid] == -1).all())
+    gout = torch.rand(R, device='cuda')
+    ref.backward(gout)
+    dl = ops.xent_bwd(logits, tgt, lse, gout, C, LD)
+    torch.cuda.synchronize()
+    assert relerr(dl[:, :C], lr.grad) < 1e-2
+    assert float(dl[:, C:].float().abs().max()) == 0.0
+
+
+def test_sgd_step(ops):
+    n = 100003
+    p = torch.randn(n, device='cuda'); g = torch.randn(n, device='cuda'); buf = torch.zeros(n, device='cuda')
+    shadow = torch.empty(n, device='cuda', dtype=torch.bfloat16)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-3)
+    for step in range(3):
+        pr.grad = g.clone() * (step + 1)
+        opt.step()
+        gg = g.clone() * (step + 1) * 2.0                  # grad_scale 0.5 undoes the x2 (DDP averaging)
+        ops.sgd_step(p, gg, buf, shadow, 0.1, 0.9, 1e-3, grad_scale=0.5, nesterov=True, first_step=(step == 0), zero_grad=True)
+        torch.cuda.synchronize()
+        assert float((p - pr.detach()).abs().max()) < 1e-5
+        assert float(gg.abs().max()) == 0.0
+        assert torch.equal(shadow, p.to(torch.bfloat16))
