@@ -1,0 +1,147 @@
+"""Flat parameter storage for the HIP path: one fp32 master buffer, one fp32 gradient buffer and one bf16 shadow
+buffer, all with identical layout (registration order == forward order, so backward completes from the END of the
+buffers towards the start -- that is what the gradient all-reduce buckets rely on).
+
+Every ``nn.Parameter`` of the model becomes a view into the master buffer, its ``.grad`` a view into the gradient
+buffer; the GEMM kernels read the bf16 shadow.  Each tensor is padded to a multiple of 64 elements (16-byte
+alignment for every dtype, and room for the classifier's row padding); padding is zero and stays zero.
+
+Reference behaviour mirrored: parameters stay ordinary fp32 ``nn.Parameter``s with the reference's state_dict
+names, so ``torch.save(model.state_dict())`` / ``load_state_dict`` / ``torch.optim.SGD`` keep working
+(func/train.py:52-74, 457-497, 744).  Loading or stepping through torch bumps the tensors' version counters; the
+shadow is refreshed lazily from that.
+"""
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+
+ALIGN = 64
+
+
+def _round_up(n, a=ALIGN):
+    return (n + a - 1) // a * a
+
+
+class ParamArena:
+    def __init__(self, module: torch.nn.Module, padded_numel: Optional[Dict[str, int]] = None):
+        padded_numel = padded_numel or {}
+        params = [(n, p) for n, p in module.named_parameters()]
+        assert params, 'module has no parameters'
+        dev = params[0][1].device
+        if dev.type != 'cuda':
+            raise RuntimeError('ParamArena needs the model on a GPU (call model.to("cuda") first); there is no CPU path')
+        self.device = dev
+        self.names, self.offsets, self.sizes, self.shapes = [], {}, {}, {}
+        off = 0
+        for n, p in params:
+            assert p.dtype == torch.float32, f'{n}: parameters must be fp32 master copies'
+            size = _round_up(max(padded_numel.get(n, 0), p.numel()))
+            self.names.append(n)
+            self.offsets[n], self.sizes[n], self.shapes[n] = off, size, tuple(p.shape)
+            off += size
+        self.total = off
+        self.master = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.shadow = torch.zeros(off, device=dev, dtype=torch.bfloat16)
+        self.params = {}
+        self.name_of = {}
+        with torch.no_grad():
+            for n, p in params:
+                o, k = self.offsets[n], p.numel()
+                view = self.master[o:o + k].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.grad[o:o + k].view(p.shape)
+                self.params[n] = p
+                self.name_of[id(p)] = n
+        self._version = None
+        self.refresh_shadow(force=True)
+
+    # ---- views -------------------------------------------------------------------------------------------------
+    def shadow_of(self, name, rows=None):
+        """bf16 view with the parameter's shape; ``rows`` widens dim 0 into the (zero) padding."""
+        o, shp = self.offsets[name], self.shapes[name]
+        if rows is not None:
+            shp = (rows,) + shp[1:]
+        k = 1
+        for s in shp:
+            k *= s
+        assert k <= self.sizes[name]
+        return self.shadow[o:o + k].view(shp)
+
+    def grad_of(self, name, rows=None):
+        o, shp = self.offsets[name], self.shapes[name]
+        if rows is not None:
+            shp = (rows,) + shp[1:]
+        k = 1
+        for s in shp:
+            k *= s
+        assert k <= self.sizes[name]
+        return self.grad[o:o + k].view(shp)
+
+    def master_padded(self, name):
+        o = self.offsets[name]
+        return self.master[o:o + self.sizes[name]]
+
+    # ---- consistency ---------------------------------------------------------------------------------------------
+    def is_valid(self):
+        """False once someone re-allocated the parameters (e.g. ``model.to()``): views no longer alias the arena."""
+        for n in (self.names[0], self.names[-1]):
+            p = self.params[n]
+            if p.data_ptr() != self.master.data_ptr() + 4 * self.offsets[n]:
+                return False
+        return True
+
+    def _current_version(self):
+        return sum(self.params[n]._version for n in self.names)
+
+    def refresh_shadow(self, force=False):
+        """Re-cast master -> bf16 shadow when a torch-side write (load_state_dict, torch optimizer) touched it."""
+        v = self._current_version()
+        if force or v != self._version:
+            ops.cast_to_bf16(self.master, self.shadow)
+            self._version = v
+
+    def mark_shadow_current(self):
+        self._version = self._current_version()
+
+    def attach_grads(self):
+        """Re-attach ``.grad`` views dropped by ``zero_grad(set_to_none=True)``; zero the buffer when that happened."""
+        dropped = False
+        for n in self.names:
+            p = self.params[n]
+            o = self.offsets[n]
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                dropped = True
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        if dropped:
+            self.grad.zero_()
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    # ---- lookups by parameter object (sub-modules do not know their prefix) -------------------------------------
+    def sh(self, param, rows=None):
+        return self.shadow_of(self.name_of[id(param)], rows)
+
+    def gr(self, param, rows=None):
+        return self.grad_of(self.name_of[id(param)], rows)
+
+
+def get_arena(module: torch.nn.Module, padded_numel_fn=None) -> ParamArena:
+    """Arena shared by ``module`` and all its children; (re)built when absent or invalidated by ``.to()``."""
+    arena = module.__dict__.get('_avt_arena')
+    if arena is not None and arena.is_valid() and all(id(p) in arena.name_of for p in module.parameters()):
+        return arena
+    padded = {}
+    for name, m in module.named_modules():
+        fn = getattr(m, 'avt_padded_numel', None)
+        if fn is not None:
+            for pn, k in fn().items():
+                padded[(name + '.' if name else '') + pn] = k
+    arena = ParamArena(module, padded)
+    for m in module.modules():
+        m.__dict__['_avt_arena'] = arena
+    return arena

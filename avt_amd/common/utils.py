@@ -1,0 +1,50 @@
+"""Helpers mirrored from the reference's common/utils.py: top-k accuracy (:17-44) and distributed init (:106-150)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def accuracy(output, target, topk=(1,)):
+    """Top-k accuracy in percent over all rows (ignored targets < 0 count as misses); all-ignored batch -> zeros."""
+    if torch.all(target < 0):
+        return [torch.zeros([], device=output.device) for _ in range(len(topk))]
+    with torch.no_grad():
+        output = output.flatten(0, -2)
+        target = target.flatten()
+        maxk = max(topk)
+        batch_size = target.size(0)
+        _, pred = output.topk(maxk, 1, True, True)
+        correct = pred.t().eq(target[None])
+        return [correct[:k].flatten().sum(dtype=torch.float32) * (100.0 / batch_size) for k in topk]
+
+
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def init_distributed_mode(backend=None):
+    """One process per GPU, rank/world from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+    ``backend='nccl'`` is RCCL on ROCm (xGMI inside a node); ``gloo`` is used by the CPU tests."""
+    if 'RANK' not in os.environ or int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        return False, 0, 1, 0
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    local = int(os.environ.get('LOCAL_RANK', rank))
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        kw = {}
+        if backend == 'nccl':
+            kw['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend=backend, init_method='env://', world_size=world, rank=rank, **kw)
+    return True, rank, world, local

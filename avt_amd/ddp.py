@@ -1,0 +1,77 @@
+"""Data-parallel gradient exchange for the flat arena -- the MI355X counterpart of the reference's
+``DistributedDataParallel(model, device_ids=[gpu])`` wrap (func/train.py:771-778).
+
+One process per GPU; ``torch.distributed`` backend ``nccl`` (= RCCL, xGMI inside the node).  Because every gradient
+lives in ONE flat fp32 buffer whose layout follows forward order, backward finishes the buffer from its END towards
+its start.  The backward autograd nodes report finished segments through ``grad_ready_hook(first_param, last_param)``;
+the reducer cuts the finished region into buckets and launches ``all_reduce(SUM)`` for each bucket on a side stream as
+soon as the kernels producing it have been enqueued (event-ordered), so the 1.2 GB of AVT-h gradients -- produced
+first -- travel while the long ViT backward still runs.  ``finish()`` makes the compute stream wait for the tail.
+The 1/world averaging is folded into the fused optimizer (``grad_scale``), not into a separate pass.
+Ring all-reduce on xGMI is per-link bound, so buckets are large (default 256 MiB) to keep the link pipelines full.
+"""
+import torch
+import torch.distributed as dist
+
+from .arena import ParamArena
+
+
+class GradReducer:
+    def __init__(self, model, bucket_bytes=256 << 20, process_group=None, overlap=True):
+        self.model = model
+        self.arena: ParamArena = model.arena
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.group = process_group
+        self.bucket_elems = max(bucket_bytes // 4, 1)
+        self.overlap = overlap and self.arena.grad.is_cuda
+        self.comm_stream = torch.cuda.Stream() if self.arena.grad.is_cuda else None
+        self._lo = self.arena.total         # everything in [_lo, total) has been produced
+        self._sent = self.arena.total       # everything in [_sent, total) has been handed to the collective
+        self._handles = []
+        for m in model.modules():
+            if hasattr(m, 'grad_ready_hook'):
+                m.grad_ready_hook = self._segment_ready
+
+    @staticmethod
+    def broadcast_parameters(model, src=0):
+        """DDP constructor semantics: every rank starts from rank ``src``'s parameters (func/train.py:775-778)."""
+        arena = model.arena
+        dist.broadcast(arena.master, src=src)
+        arena.refresh_shadow(force=True)
+
+    def start_step(self):
+        self._lo = self._sent = self.arena.total
+        self._handles = []
+
+    def _segment_ready(self, first_param, last_param):
+        a = self.arena
+        start = a.offsets[a.name_of[id(first_param)]]
+        self._lo = min(self._lo, start)
+        if self.world > 1 and self.overlap:
+            while self._sent - self._lo >= self.bucket_elems:
+                self._launch(self._sent - self.bucket_elems, self._sent)
+
+    def _launch(self, s, e):
+        a = self.arena
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                h = dist.all_reduce(a.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            h = dist.all_reduce(a.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._handles.append(h)
+        self._sent = s
+
+    def finish(self):
+        """Reduce whatever is left (everything, if no hook fired) and order the compute stream after the collectives."""
+        if self.world <= 1:
+            return
+        if self._sent > 0:
+            self._launch(0, self._sent)
+        for h in self._handles:
+            h.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._handles = []

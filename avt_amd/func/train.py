@@ -1,0 +1,152 @@
+"""Training driver pieces of the hot path (reference func/train.py): model construction (:660-664), parameter groups /
+optimizer / schedulers (:696-758), the data-parallel wrap (:771-778) and the per-iteration step of
+``train_one_epoch`` (:203-265).  Data loading, evaluation, H5 logging and checkpoint rotation are outside the
+accelerated path; inputs here are synthetic clips or tensors handed in by the caller.
+"""
+import logging
+import time
+from typing import Dict
+
+import torch
+
+from ..common import scheduler as sched
+from ..common import utils
+from ..config import Cfg, instantiate
+from ..ddp import GradReducer
+from ..models.base_model import BaseModel
+from ..optim import FusedSGD
+
+__all__ = ['build_model', 'build_optimizer', 'build_schedulers', 'Trainer', 'synthetic_batch', 'main']
+
+
+def build_model(cfg, num_classes: Dict[str, int], class_mappings=None, device='cuda'):
+    """func/train.py:660-664,690"""
+    model = BaseModel(cfg.model, num_classes=num_classes, class_mappings=class_mappings or {})
+    return model.to(device)
+
+
+def _param_groups(model, lr_wd, world_size, bias_bn_wd_scale=1.0):
+    """func/train.py:696-742: per ``opt.lr_wd`` entry two groups (names ending in 'bias' or containing '.bn' get the
+    weight decay scaled), LR multiplied by the number of replicas, zero-LR groups dropped."""
+    groups = []
+    for modules, lr, wd in lr_wd:
+        if not isinstance(modules, (list, tuple)):
+            modules = [modules]
+        named = []
+        for mod_name in modules:
+            mod = model if mod_name == '__all__' else _get_submodule(model, mod_name)
+            named.extend((mod_name + '.' + n, p) for n, p in mod.named_parameters() if p.requires_grad)
+        decay = [p for n, p in named if not (n.endswith('bias') or '.bn' in n)]
+        no_decay = [p for n, p in named if (n.endswith('bias') or '.bn' in n)]
+        this_lr = lr * world_size
+        if this_lr == 0:
+            continue
+        groups.append({'params': decay, 'lr': this_lr, 'weight_decay': wd})
+        groups.append({'params': no_decay, 'lr': this_lr, 'weight_decay': wd * bias_bn_wd_scale})
+    return [g for g in groups if g['params']]
+
+
+def _get_submodule(model, dotted):
+    cur = model
+    for part in dotted.split('.'):
+        cur = getattr(cur, part)
+    return cur
+
+
+def build_optimizer(cfg, model, world_size=1):
+    """func/train.py:744 ``hydra.utils.instantiate(cfg.opt.optimizer, params)``; ``_target_: torch.optim.SGD`` maps to the
+    fused arena optimizer (same hyper-parameters, same update rule)."""
+    groups = _param_groups(model, cfg.opt.lr_wd, world_size, cfg.opt.get('bias_bn_wd_scale', 1.0))
+    oc = dict(cfg.opt.optimizer)
+    target = oc.pop('_target_', 'torch.optim.SGD')
+    if target == 'torch.optim.SGD':
+        return FusedSGD(groups, lr=groups[0]['lr'], arena=model.arena, **oc)
+    from ..config import locate
+    return locate(target)(groups, lr=groups[0]['lr'], **oc)
+
+
+def build_schedulers(cfg, optimizer, iters_per_epoch, world_size=1):
+    """func/train.py:749-758: main scheduler then the Warmup wrapper, both stepped per iteration."""
+    main = instantiate(cfg.opt.scheduler, optimizer, iters_per_epoch=iters_per_epoch, world_size=world_size)
+    return instantiate(cfg.opt.warmup, optimizer, main, iters_per_epoch=iters_per_epoch, world_size=world_size)
+
+
+def synthetic_batch(batch_size, num_frames, num_classes, device, seed=42, feat_shape=(3, 1, 224, 224)):
+    """SURVEY 8d synthetic inputs: video ~ U(-1,1) (mean=std=0.5 normalised pixels), random targets, -1 = unlabeled."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    video = torch.rand((batch_size, num_frames) + tuple(feat_shape), device=device, generator=g) * 2 - 1
+    target = torch.randint(0, num_classes, (batch_size,), device=device, generator=g)
+    sub = torch.randint(-1, num_classes, (batch_size, num_frames, 1), device=device, generator=g)
+    return {'video': video, 'target': {'action': target}, 'target_subclips': {'action': sub}}
+
+
+class Trainer:
+    """One optimisation step = reference train_one_epoch body (func/train.py:203-265):
+    op(data) -> mean each loss -> weighted sum over keys with weight > 0 -> zero_grad, backward (+ overlapped gradient
+    all-reduce), step -> lr_scheduler.step().  The NaN check / ``loss.item()`` host syncs of the reference are made
+    optional (``sync_loss``) because they stall the launch queue."""
+    def __init__(self, model, train_eval_op, optimizer, lr_scheduler=None, loss_wts=None, distributed=False,
+                 bucket_bytes=256 << 20):
+        self.model, self.op, self.optimizer, self.lr_scheduler = model, train_eval_op, optimizer, lr_scheduler
+        self.loss_wts = dict(loss_wts or {})
+        self.world = utils.get_world_size() if distributed else 1
+        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes) if self.world > 1 else None
+        if self.reducer is not None:
+            GradReducer.broadcast_parameters(model)
+            if hasattr(optimizer, 'grad_scale'):
+                optimizer.grad_scale = 1.0 / self.world
+        self.last_losses = {}
+
+    def total_loss(self, losses):
+        final = None
+        for key, val in losses.items():
+            wt = self.loss_wts.get(key, 0.0)
+            if wt > 0:
+                term = wt * torch.mean(val)
+                final = term if final is None else final + term
+        return final
+
+    def step(self, data, sync_loss=False):
+        if self.reducer is not None:
+            self.reducer.start_step()
+        data, outputs, losses, accuracies = self.op(data, train_mode=True)
+        loss = self.total_loss(losses)
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
+        if sync_loss:
+            val = loss.item()
+            if not (val == val):
+                raise ValueError('Overall loss is NaN')
+            return val, outputs, losses, accuracies
+        return loss, outputs, losses, accuracies
+
+
+def main(cfg, steps=10, batch_size=None, log_every=1):
+    """Synthetic-data training loop driven by a composed config (see avt_amd/train_net.py)."""
+    dist_on, rank, world, local = utils.init_distributed_mode(cfg.get('dist_backend', None))
+    device = torch.device('cuda', local)
+    torch.manual_seed(cfg.get('seed', 42) + rank)
+    C = cfg.get('synthetic', Cfg()).get('num_classes', 3806)
+    T = cfg.data_train.num_frames
+    B = batch_size or cfg.train.batch_size
+    model = build_model(cfg, {'action': C}, device=device)
+    optimizer = build_optimizer(cfg, model, world)
+    iters_per_epoch = cfg.get('synthetic', Cfg()).get('iters_per_epoch', 100)
+    lr_sched = build_schedulers(cfg, optimizer, iters_per_epoch, world)
+    op = instantiate(cfg.train_eval_op, model, device, None, _recursive_=False)
+    trainer = Trainer(model, op, optimizer, lr_sched, cfg.train.train_one_epoch_fn.loss_wts, distributed=dist_on)
+    feat_shape = tuple(cfg.get('synthetic', Cfg()).get('feat_shape', (3, 1, 224, 224)))
+    data = synthetic_batch(B, T, C, device, seed=cfg.get('seed', 42) + rank, feat_shape=feat_shape)
+    for it in range(steps):
+        t0 = time.time()
+        loss, _, _, accs = trainer.step(data, sync_loss=True)
+        dt = time.time() - t0
+        if rank == 0 and it % log_every == 0:
+            logging.info('iter %d loss %.4f clips/s %.1f lr %.3g', it, loss, B * world / dt, optimizer.param_groups[0]['lr'])
+            print(f'iter {it} loss {loss:.4f} clips/s {B * world / dt:.1f} lr {optimizer.param_groups[0]["lr"]:.3g}', flush=True)
+    return trainer

@@ -1,0 +1,94 @@
+"""Fused SGD over the model's flat parameter arena -- drop-in for ``torch.optim.SGD`` in
+conf/opt/optimizer/sgd.yaml (momentum 0.9, nesterov per expts/01_ek100_avt.txt:28, weight decay from ``opt.lr_wd``).
+
+One HIP kernel per parameter group range updates fp32 master weights + momentum, emits the bf16 shadow the GEMMs read
+and re-zeroes the gradient buffer for the next step's atomic accumulation (avt_sgd_step).  ``param_groups`` keeps
+torch's shape ({'params', 'lr', 'momentum', 'weight_decay', 'nesterov'}) so the reference's schedulers and
+checkpoint code (func/train.py:52-74) work on it.  Groups with identical hyper-parameters covering adjacent arena
+ranges are merged into a single launch.
+"""
+import torch
+
+from . import ops
+from .arena import ParamArena
+
+
+class FusedSGD:
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0, nesterov=False, dampening=0, arena: ParamArena = None):
+        assert dampening == 0, 'dampening is not supported'
+        if arena is None:
+            raise ValueError('FusedSGD needs the model arena (model.arena)')
+        self.arena = arena
+        params = list(params)
+        if params and not isinstance(params[0], dict):
+            params = [{'params': params}]
+        self.param_groups = []
+        for g in params:
+            g = dict(g)
+            g['params'] = list(g['params'])
+            g.setdefault('lr', lr)
+            g.setdefault('momentum', momentum)
+            g.setdefault('weight_decay', weight_decay)
+            g.setdefault('nesterov', nesterov)
+            self.param_groups.append(g)
+        self.momentum_buf = torch.zeros_like(arena.master)
+        self.steps = 0
+        self.grad_scale = 1.0            # set to 1/world_size by the gradient reducer (sum all-reduce)
+        self._ranges = None
+
+    def _build_ranges(self):
+        """[(start, end, group_index)] covering each group's parameters as maximal contiguous arena ranges."""
+        a = self.arena
+        spans = []
+        for gi, g in enumerate(self.param_groups):
+            for p in g['params']:
+                n = a.name_of[id(p)]
+                spans.append((a.offsets[n], a.offsets[n] + a.sizes[n], gi))
+        spans.sort()
+        merged = []
+        for s, e, gi in spans:
+            if merged and merged[-1][2] == gi and merged[-1][1] == s:
+                merged[-1] = (merged[-1][0], e, gi)
+            else:
+                merged.append((s, e, gi))
+        return merged
+
+    def zero_grad(self, set_to_none: bool = False):
+        """No-op by design: step() re-zeroes the gradient range it consumed."""
+
+    @torch.no_grad()
+    def step(self):
+        if self._ranges is None:
+            self._ranges = self._build_ranges()
+        a = self.arena
+        # launch per maximal run of adjacent ranges whose hyper-parameters agree
+        i = 0
+        R = self._ranges
+        while i < len(R):
+            s, e, gi = R[i]
+            g = self.param_groups[gi]
+            key = (g['lr'], g['momentum'], g['weight_decay'], g['nesterov'])
+            j = i + 1
+            while j < len(R):
+                g2 = self.param_groups[R[j][2]]
+                if R[j][0] == e and (g2['lr'], g2['momentum'], g2['weight_decay'], g2['nesterov']) == key:
+                    e = R[j][1]
+                    j += 1
+                else:
+                    break
+            ops.sgd_step(a.master[s:e], a.grad[s:e], self.momentum_buf[s:e], a.shadow[s:e], g['lr'], g['momentum'],
+                         g['weight_decay'], grad_scale=self.grad_scale, nesterov=bool(g['nesterov']),
+                         first_step=(self.steps == 0), zero_grad=True)
+            i = j
+        self.steps += 1
+        a.mark_shadow_current()
+
+    def state_dict(self):
+        return {'momentum_buf': self.momentum_buf, 'steps': self.steps,
+                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.momentum_buf.copy_(sd['momentum_buf'])
+        self.steps = sd['steps']
+        for g, s in zip(self.param_groups, sd['param_groups']):
+            g.update(s)

@@ -392,33 +392,45 @@ def lr_schedule(base_lr, warmup_iters, cosine_iters, n_steps, init_lr_ratio=0.0,
 # --------------------------------------------------------------------------------------------------
 # Deterministic closed-form parameter fill shared by the golden generator and the tests
 # --------------------------------------------------------------------------------------------------
-def closed_form_fill_(named_tensors, scale_overrides: Optional[Dict[str, float]] = None):
-    """Fill every tensor in-place with w.flatten()[i] = s * sin(a*i + b); (a, b) derive from the name.
+def _hash_uniform(n, seed):
+    """u[i] in [-1, 1): a pure integer hash of (i, seed) -- bit-identical on every box, no RNG state involved."""
+    m32 = 0xFFFFFFFF
+    x = (torch.arange(n, dtype=torch.int64) * 2654435761 + (seed * 40503 + 12345)) & m32
+    x = x ^ (x >> 16)
+    x = (x * 0x45D9F3B) & m32
+    x = x ^ (x >> 16)
+    x = (x * 0x45D9F3B) & m32
+    x = x ^ (x >> 16)
+    return x.to(torch.float64) / 2147483648.0 - 1.0
 
-    LayerNorm weights get 1 + s*sin(.).  Reproducible on any box without shipping weights.
+
+def closed_form_fill_(named_tensors, scale_overrides: Optional[Dict[str, float]] = None):
+    """Fill every tensor in-place with w.flatten()[i] = s * sqrt(3) * u(i, hash(name)), u uniform in [-1, 1).
+
+    s = 1/sqrt(fan_in) for matrices (so activations stay O(1) and attention is far from uniform), 0.05 for biases,
+    position/CLS embeddings 0.05; LayerNorm weights are 1 + 0.1*u.  Weights are full-rank (unlike a sinusoid fill)
+    and reproducible on any box without shipping 1.5 GB of parameters.
     """
-    for idx, (name, t) in enumerate(sorted(named_tensors, key=lambda kv: kv[0])):
+    for name, t in sorted(named_tensors, key=lambda kv: kv[0]):
         h = 0
         for ch in name:
             h = (h * 131 + ord(ch)) % 1000003
-        a = 0.37 + (h % 1000) / 1000.0
-        b = (h % 6283) / 1000.0
-        n = t.numel()
         fan_in = t.shape[-1] if t.ndim >= 2 else 1
         if t.ndim == 4:
             fan_in = t.shape[1] * t.shape[2] * t.shape[3]
-        s = 1.0 / math.sqrt(fan_in) if t.ndim >= 2 else 0.05
+        s = math.sqrt(3.0 / fan_in) if t.ndim >= 2 else 0.05
         is_norm_w = (('norm' in name or 'ln_' in name) and name.endswith('weight'))
         if 'c_attn.weight' in name or 'c_fc.weight' in name or ('c_proj.weight' in name):
-            s = 1.0 / math.sqrt(t.shape[0])           # Conv1D is (in, out)
+            s = math.sqrt(3.0 / t.shape[0])           # Conv1D is (in, out)
         if 'pos_embed' in name or 'cls_token' in name or 'wpe' in name:
             s = 0.05
+        if is_norm_w:
+            s = 0.1
         if scale_overrides:
             for key, val in scale_overrides.items():
                 if key in name:
                     s = val
-        i = torch.arange(n, dtype=torch.float64)
-        vals = s * torch.sin(a * i + b)
+        vals = s * _hash_uniform(t.numel(), h)
         if is_norm_w:
             vals = 1.0 + vals
         with torch.no_grad():

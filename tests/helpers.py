@@ -1,0 +1,79 @@
+"""Shared builders for the parity tests: the same architecture as an oracle (CPU, fp32) and as the HIP model."""
+import numpy as np
+import torch
+
+from avt_amd.config import Cfg
+from oracle import avt_oracle as O
+
+LOSS_WTS = {'cls_action': 1.0, 'past_cls_action': 1.0, 'feat': 1.0}
+
+
+def load_golden(path):
+    z = np.load(path)
+    return {k.replace('__', '/'): torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+def model_cfg(backbone, in_dim, inter_dim, n_layer, n_head, dropout=0.0, head_drop=0.0):
+    fp = Cfg(_target_='models.future_prediction.AVTh', n_head=n_head, n_layer=n_layer, output_len=1,
+             inter_dim=inter_dim, return_past_too=True, avg_last_n=1, future_pred_loss_wt=1.0,
+             embd_pdrop=head_drop, attn_pdrop=head_drop, resid_pdrop=head_drop,
+             future_pred_loss=Cfg(_target_='torch.nn.MSELoss'))
+    return Cfg(backbone=backbone, backbone_last_n_modules_to_drop=0, backbone_dim=in_dim, intermediate_featdim=None,
+               temporal_aggregator=Cfg(_target_='models.temporal_aggregation.Identity'),
+               temporal_aggregator_after_future_pred=Cfg(_target_='models.temporal_aggregation.Identity'),
+               future_predictor=fp, classifier=Cfg(_target_='torch.nn.Linear', bias=True),
+               same_temp_agg_dim=False, project_dim_for_nce=None, dropout=dropout, use_cls_mappings=False,
+               classifier_on_past=True, add_regression_head=False, bn=Cfg(eps=0.001, mom=0.1))
+
+
+def build_hip_model(kind, in_dim, inter_dim, n_layer, n_head, C, vit=None, device='cuda'):
+    from avt_amd.models.base_model import BaseModel
+    if kind == 'feat':
+        bb = Cfg(_target_='models.video_classification.IdentityFeatures')
+    else:
+        dim, depth, heads, img = vit
+        bb = Cfg(_target_='models.video_classification.TIMMModel', model_type='custom', embed_dim=dim, depth=depth,
+                 num_heads=heads, img_size=img)
+    cfg = model_cfg(bb, in_dim, inter_dim, n_layer, n_head)
+    return BaseModel(cfg, {'action': C}, {}).to(device)
+
+
+def build_oracle_model(kind, in_dim, inter_dim, n_layer, n_head, C, vit=None):
+    if kind == 'feat':
+        bb = O.OracleIdentityBackbone()
+    else:
+        dim, depth, heads, img = vit
+        bb = O.OracleTIMMModel(vit=O.OracleViT(dim, depth, heads, img=img))
+    head = O.OracleAVTh(in_dim, inter_dim=inter_dim, n_layer=n_layer, n_head=n_head, embd_pdrop=0., attn_pdrop=0., resid_pdrop=0.)
+    return O.OracleBaseModel(bb, head, in_dim, {'action': C}, dropout=0.0)
+
+
+def oracle_step(orc, video, target, sub):
+    out, aux = orc(video, target_shape=target.shape)
+    losses, accs = O.basic_loss_accuracy(out, {'action': target}, {'action': sub})
+    losses.update(aux)
+    tot = O.total_loss(losses, LOSS_WTS)
+    orc.zero_grad()
+    tot.backward()
+    return out, losses, accs, tot
+
+
+def hip_step(model, video, target, sub):
+    from avt_amd.func.train_eval_ops import Basic
+    op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
+    data = {'video': video, 'target': {'action': target}, 'target_subclips': {'action': sub}}
+    model.zero_grad()
+    _, out, losses, accs = op(data, train_mode=True)
+    tot = None
+    for k, v in losses.items():
+        if LOSS_WTS.get(k, 0) > 0:
+            t = LOSS_WTS[k] * v.mean()
+            tot = t if tot is None else tot + t
+    tot.backward()
+    torch.cuda.synchronize()
+    return out, losses, accs, tot
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
