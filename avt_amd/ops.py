@@ -12,8 +12,23 @@ ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_DGELU_ERF, ACT_DGELU_TANH = 0, 1, 2, 
 OUT_BF16, OUT_F32, OUT_ACCUM_F32 = 0, 1, 2
 
 
+# When set to a list, every gemm() appends (variant, flops, start_event, end_event): bench.py's live roofline probe.
+GEMM_TRACE = None
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile):
+    """Mirror of the tile choice in avt_gemm_bf16 (csrc/gemm.hip): names the kernel template a call lands on."""
+    epi = 1 if out_mode == OUT_ACCUM_F32 else 0
+    bm = 128
+    if epi == 0 and (tile == 64 or (tile == 0 and ((M + 127) // 128) * ((N + 127) // 128) < 192)):
+        bm = 64
+    if epi == 1:
+        bm = 64 if tile == 64 else 128
+    return f'gemm_kernel<{bm},{bm},{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
 
 
 def _p(t):
@@ -40,10 +55,17 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
     if out is None:
         assert out_mode != OUT_ACCUM_F32, 'accumulate mode needs an output buffer'
         out = torch.empty((M, N), device=A.device, dtype=BF16 if out_mode == OUT_BF16 else torch.float32)
+    trace = GEMM_TRACE
+    if trace is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _lib.call('avt_gemm_bf16', _p(A), int(a_kmajor), _ld(A), _p(B), int(b_kmajor), _ld(B), _p(out), _ld(out), M, N, K,
               _p(bias), act, _p(aux), _ld(aux) if aux is not None else 0, _p(c2), _ld(c2) if c2 is not None else 0,
               _p(res), _ld(res) if res is not None else 0, res_period, float(drop_p), int(seed), _p(colsum),
               out_mode, splitk, tile, _stream())
+    if trace is not None:
+        ev1.record()
+        trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile), 2.0 * M * N * K, ev0, ev1))
     return out
 
 

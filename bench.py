@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""Headline benchmark: training clips/sec of ViT-B/16 + AVT-h (10 x 224^2 frames, C = 3806) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = forward + losses + backward (+ overlapped RCCL gradient all-reduce for N > 1) + fused SGD-nesterov update on a
+synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line:
+  value      whole-job clips/sec (N x per-GPU batch / max-over-ranks step time)
+  roofline   the dominant kernel (the 128x128-tile bf16 MFMA GEMM templates): algorithmic 2*M*N*K flops of every launch
+             in the timed region / their summed HIP-event durations, against the 2.5 PFLOP/s dense bf16 MFMA peak
+  cpu_baseline  the fp32 CPU oracle (a port of the reference's timm/HF path, oracle/avt_oracle.py) timed on this box's
+             host cores on a bounded sample (B = 1 clip, 1 warm-up + 2 timed steps of fwd+bwd+SGD)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+NUM_CLASSES = 3806
+
+VIT = {'vit_base_patch16_224': (768, 12, 12), 'vit_large_patch16_224': (1024, 24, 16)}
+
+
+def flops_per_clip(D, L, T, Dh=2048, Lh=6, C=NUM_CLASSES, S=197):
+    """GEMM + attention flops, backward = 2x forward except the patch-embed data gradient."""
+    patch = 2 * 196 * 768 * D
+    f_v = patch + L * (2 * S * D * 3 * D + 4 * S * S * D + 2 * S * D * D + 4 * S * D * 4 * D)
+    f_h = 2 * T * D * Dh * 2 + Lh * (2 * T * Dh * 3 * Dh + 4 * T * T * Dh + 2 * T * Dh * Dh + 16 * T * Dh * Dh) + 2 * (T + 1) * D * C
+    return 3 * (T * f_v + f_h) - T * patch
+
+
+def build(args, device, world):
+    from avt_amd.config import Cfg
+    from avt_amd.func.train import Trainer, synthetic_batch
+    from avt_amd.func.train_eval_ops import Basic
+    from avt_amd.models.base_model import BaseModel
+    from avt_amd.optim import FusedSGD
+    fp = Cfg(_target_='models.future_prediction.AVTh', n_head=4, n_layer=6, output_len=1, inter_dim=2048,
+             return_past_too=True, avg_last_n=1, future_pred_loss=Cfg(_target_='torch.nn.MSELoss'), future_pred_loss_wt=1.0)
+    mcfg = Cfg(backbone=Cfg(_target_='models.video_classification.TIMMModel', model_type=args.model),
+               backbone_last_n_modules_to_drop=0, backbone_dim=VIT[args.model][0], intermediate_featdim=None,
+               temporal_aggregator=Cfg(_target_='models.temporal_aggregation.Identity'),
+               temporal_aggregator_after_future_pred=Cfg(_target_='models.temporal_aggregation.Identity'),
+               future_predictor=fp, classifier=Cfg(_target_='torch.nn.Linear', bias=True), same_temp_agg_dim=False,
+               project_dim_for_nce=None, dropout=0.2, use_cls_mappings=False, classifier_on_past=True,
+               add_regression_head=False, bn=Cfg(eps=0.001, mom=0.1))
+    torch.manual_seed(42)
+    model = BaseModel(mcfg, {'action': NUM_CLASSES}, {}).to(device)
+    with torch.no_grad():                       # ViT weights: N(0, 0.02) stand-in for the (absent) pretrained checkpoint
+        for n, p in model.backbone.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.02)
+    opt = FusedSGD(model.parameters(), lr=1e-4 * world, momentum=0.9, nesterov=True, weight_decay=1e-6, arena=model.arena)
+    op = Basic(model, device, None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
+    trainer = Trainer(model, op, opt, None, {'cls_action': 1.0, 'past_cls_action': 1.0, 'feat': 1.0}, distributed=world > 1,
+                      bucket_bytes=args.bucket_mb << 20)
+    rank = int(os.environ.get('RANK', 0))
+    data = synthetic_batch(args.batch, args.frames, NUM_CLASSES, device, seed=42 + rank)
+    return trainer, data
+
+
+def cpu_baseline(args):
+    """fp32 CPU oracle, fwd + bwd + SGD-nesterov, B = 1 clip (bounded sample of the same workload)."""
+    from oracle import avt_oracle as O
+    cores = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(cores)
+    D, L, H = VIT[args.model]
+    orc = O.OracleBaseModel(O.OracleTIMMModel(vit=O.OracleViT(D, L, H)),
+                            O.OracleAVTh(D, inter_dim=2048, n_layer=6, n_head=4), D, {'action': NUM_CLASSES}, dropout=0.2)
+    orc.train()
+    opt = torch.optim.SGD(orc.parameters(), lr=1e-4, momentum=0.9, nesterov=True, weight_decay=1e-6)
+    g = torch.Generator().manual_seed(42)
+    B = 1
+    video = torch.rand((B, args.frames, 3, 1, 224, 224), generator=g) * 2 - 1
+    target = torch.randint(0, NUM_CLASSES, (B,), generator=g)
+    sub = torch.randint(-1, NUM_CLASSES, (B, args.frames, 1), generator=g)
+    wts = {'cls_action': 1.0, 'past_cls_action': 1.0, 'feat': 1.0}
+    times = []
+    for it in range(3):
+        t0 = time.time()
+        out, aux = orc(video, target_shape=target.shape)
+        losses, _ = O.basic_loss_accuracy(out, {'action': target}, {'action': sub})
+        losses.update(aux)
+        tot = O.total_loss(losses, wts)
+        opt.zero_grad()
+        tot.backward()
+        opt.step()
+        times.append(time.time() - t0)
+    t = sum(times[1:]) / len(times[1:])
+    return {'value': round(B / t, 4), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+            'sample': f'B={B} clip x {args.frames} frames, 1 warm-up + 2 timed fwd+bwd+SGD steps of the fp32 oracle '
+                      f'({t:.2f} s/step, {flops_per_clip(D, L, args.frames) * B / t / 1e9:.0f} GFLOP/s)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
+    ap.add_argument('--frames', type=int, default=10)
+    ap.add_argument('--model', default='vit_base_patch16_224', choices=list(VIT))
+    ap.add_argument('--bucket-mb', type=int, default=256)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-gemm-trace', action='store_true')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from avt_amd import ops
+    from avt_amd.common import utils
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
+    dist_on, rank, world, local = utils.init_distributed_mode('nccl')
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    trainer, data = build(args, device, world)
+
+    def sync():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(data)
+    sync()
+    trace = None if args.no_gemm_trace else []
+    ops.GEMM_TRACE = trace
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _, _, _ = trainer.step(data)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.GEMM_TRACE = None
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if dist_on:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
+    loss_val = float(loss)
+
+    if rank == 0:
+        D, L, _ = VIT[args.model]
+        fclip = flops_per_clip(D, L, args.frames)
+        clips = args.batch * world * args.steps / elapsed
+        per_variant = {}
+        if trace:
+            for name, fl, e0, e1 in trace:
+                d = per_variant.setdefault(name, [0.0, 0.0, 0])
+                d[0] += fl
+                d[1] += e0.elapsed_time(e1) * 1e-3
+                d[2] += 1
+        dom = {k: v for k, v in per_variant.items() if k.startswith('gemm_kernel<128')}
+        fl = sum(v[0] for v in dom.values())
+        tm = sum(v[1] for v in dom.values())
+        n_launch = sum(v[2] for v in dom.values())
+        roof = None
+        if tm > 0:
+            ach = fl / tm / 1e12
+            roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<128,128,*> (bf16 MFMA GEMM, all layouts/epilogues)',
+                    'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4),
+                    'traffic': None, 'launches': n_launch, 'avg_launch_us': round(tm / n_launch * 1e6, 2),
+                    'avg_launch_gflop': round(fl / n_launch / 1e9, 3),
+                    'share_of_step_time': round(tm / elapsed, 3),
+                    'per_variant_tflops': {k: round(v[0] / v[1] / 1e12, 1) for k, v in per_variant.items() if v[1] > 0}}
+        out = {'metric': 'training clips/sec (ViT-B/16+AVT-h, 10x224^2 frames)' if args.model.startswith('vit_base') else f'training clips/sec ({args.model}+AVT-h)',
+               'value': round(clips, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+               'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+               'config': {'workload': f'{args.model} + AVT-h(2048x6x4) fwd+bwd+SGD-nesterov, T={args.frames} x 224^2, C={NUM_CLASSES}, '
+                                      f'{args.batch} clips/GPU, dropout 0.1/0.2 on, fp32 master weights / bf16 MFMA',
+                          'clips_per_gpu': args.batch, 'global_batch': args.batch * world, 'frames': args.frames,
+                          'parallelism': f'dp{world}', 'gflop_per_clip': round(fclip / 1e9, 2), 'final_loss': round(loss_val, 4)},
+               'step_mfma_frac': round(clips / world * fclip / (MFMA_PEAK_TFLOPS * 1e12), 4),
+               'roofline': roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
