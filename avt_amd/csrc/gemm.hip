@@ -11,15 +11,18 @@
 // ROW index are read with gfx950's transposing ds_read_b64_tr_b16, so no transposed copy of any tensor ever
 // exists in HBM.
 //
-// Structure (v1): 256 threads = 4 waves (2x2), block tile BMxBNx64, v_mfma_f32_32x32x16_bf16, operands staged
-// global->LDS by LDS-DMA (buffer_load ... lds, 16 B/lane; out-of-range rows arrive as zeros through the buffer
-// descriptor's bounds check), XOR-swizzled through the per-lane SOURCE address so the LDS image stays
+// Structure: block tile BMxBNx64 computed by WGM x WGN waves (256x256 by 2x4 waves = 512 threads, one block per CU,
+// for the big ViT GEMMs; 128x128 and 64x64 by 2x2 waves for small outputs), v_mfma_f32_32x32x16_bf16, operands
+// staged global->LDS by LDS-DMA (buffer_load ... lds, 16 B/lane; out-of-range rows arrive as zeros through the
+// buffer descriptor's bounds check), XOR-swizzled through the per-lane SOURCE address so the LDS image stays
 // lane-linear, double-buffered with one barrier per K tile, XCD-aware tile order.
 // Epilogue 0 (activations): accumulators are staged through LDS so every lane owns 4 consecutive columns of
 //   one row: + bias, GELU (erf|tanh) with optional pre-activation second output, multiply by GELU'(aux),
 //   dropout, + residual (optionally row-periodic), per-column sums (bias gradients), bf16 or fp32 store.
 // Epilogue 1 (weight gradients): fp32 atomic accumulation straight from the accumulator layout (split-K over
 //   the reduction axis fills the chip when the output has few tiles).
+#include <cstdlib>
+#include <type_traits>
 #include "common.hpp"
 #include "../../include/avt_hip.h"
 
@@ -37,9 +40,11 @@ struct GemmParams {
   int tiles_m, tiles_n;
   uint32_t a_bytes, b_bytes;     // buffer-descriptor bounds
   uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
+  int wide_ok;                   // all epilogue leading dims are multiples of 8 -> 16-byte accesses allowed
+  long long* dbg;                // lab only: per-block phase timestamps (s_memtime), NULL in production
 };
 
-constexpr int BK = 64;
+constexpr int BK64 = 64;
 
 // XCD-aware bijective remap of the linear block id: XCD x (= id % 8 by dispatch order) owns a contiguous
 // range of logical tiles, so tiles sharing an A row-panel sit behind the same L2.
@@ -51,48 +56,55 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 }
 
 // ---- operand tile loaders (LDS-DMA, swizzle on the source address) ------------------------------------
-// k-major operand: LDS tile [BR][64] bf16 (128-B rows); 16-B chunk c of row r lives at chunk c ^ ((r>>1)&7).
-template <int BR>
+// k-major operand: LDS tile [BR][BK] bf16 (BK*2-byte rows).  The 16-B chunk c of row r lives at chunk
+// c ^ ((r>>1)&7) for BK=64 (128-B rows) and c ^ ((r>>2)&3) for BK=32 (64-B rows): the 16 rows a ds_read_b128 lane
+// group touches then land on 16 distinct 16-B slots of the 256-B bank row.
+template <int BK>
+__device__ __forceinline__ int kmajor_swz(int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+template <int BR, int NW, int BK>
 __device__ __forceinline__ void stage_kmajor(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int row0, int k0, int ld,
                                              int K, int wave, int lane) {
+  constexpr int CPR = BK / 8;            // 16-B chunks per row
+  constexpr int RPI = 64 / CPR;          // rows per wave instruction
 #pragma unroll
-  for (int j = 0; j < BR / 32; ++j) {
-    int r = j * 32 + wave * 8 + (lane >> 3);
-    int c = (lane & 7) ^ ((r >> 1) & 7);
+  for (int j = 0; j < BR / (NW * RPI); ++j) {
+    int r = j * (NW * RPI) + wave * RPI + lane / CPR;
+    int c = (lane % CPR) ^ kmajor_swz<BK>(r);
     int kcol = k0 + c * 8;
     uint32_t off = (uint32_t)(((size_t)(row0 + r) * (size_t)ld + (size_t)kcol) * 2);
     if (kcol >= K) off = 0xFFFFFFF0u;                     // forces the bounds check -> zeros
-    char* dst = lds_tile + (j * 32 + wave * 8) * 128;     // wave-uniform base; lane l lands at +16*l
+    char* dst = lds_tile + (j * (NW * RPI) + wave * RPI) * (BK * 2);   // wave-uniform base; lane l lands at +16*l
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(dst), 16, off, 0, 0, 0);
   }
 }
-// reduction-index-as-row operand: LDS tile [64][BR] bf16; chunk swizzle keeps the 4 rows of a tr-read on
-// distinct 64-B bank segments (BR=128: c ^ ((r&3)<<2); BR=64: c ^ (((r>>1)&1)<<2)).
+// reduction-index-as-row operand: LDS tile [BK][BR] bf16; chunk swizzle keeps the 4 rows of a tr-read on
+// distinct 64-B bank segments (BR>=128: c ^ ((r&3)<<2); BR=64: c ^ (((r>>1)&1)<<2)).
 template <int BR>
-__device__ __forceinline__ int kstrided_swz(int r) { return BR == 128 ? ((r & 3) << 2) : (((r >> 1) & 1) << 2); }
-template <int BR>
+__device__ __forceinline__ int kstrided_swz(int r) { return BR >= 128 ? ((r & 3) << 2) : (((r >> 1) & 1) << 2); }
+template <int BR, int NW, int BK>
 __device__ __forceinline__ void stage_kstrided(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int col0, int k0, int ld,
                                                int ncols, int wave, int lane) {
   constexpr int CPR = BR / 8;            // 16-B chunks per row
   constexpr int RPI = 64 / CPR;          // rows per wave instruction
 #pragma unroll
-  for (int j = 0; j < 64 / (4 * RPI); ++j) {
-    int r = j * 4 * RPI + wave * RPI + lane / CPR;
+  for (int j = 0; j < BK / (NW * RPI); ++j) {
+    int r = j * NW * RPI + wave * RPI + lane / CPR;
     int c = (lane % CPR) ^ kstrided_swz<BR>(r);
     int col = col0 + c * 8;
     uint32_t off = (uint32_t)(((size_t)(k0 + r) * (size_t)ld + (size_t)col) * 2);
     if (col >= ncols) off = 0xFFFFFFF0u;
-    char* dst = lds_tile + (j * 4 * RPI + wave * RPI) * (BR * 2);
+    char* dst = lds_tile + (j * NW * RPI + wave * RPI) * (BR * 2);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(dst), 16, off, 0, 0, 0);
   }
 }
 
 // ---- fragment reads --------------------------------------------------------------------------------------
 // Both forms give lane l the 8 values k = ks*16 + (l>>5)*8 + e, e = 0..7, of operand row (tile*32 + (l&31)).
+template <int BK>
 __device__ __forceinline__ bf16x8_t frag_kmajor(const char* lds_tile, int tile, int ks, int lane) {
   int r = tile * 32 + (lane & 31);
-  int c = (ks * 2 + (lane >> 5)) ^ ((r >> 1) & 7);
-  return *(const bf16x8_t*)(lds_tile + r * 128 + c * 16);
+  int c = (ks * 2 + (lane >> 5)) ^ kmajor_swz<BK>(r);
+  return *(const bf16x8_t*)(lds_tile + r * (BK * 2) + c * 16);
 }
 template <int BR>
 __device__ __forceinline__ bf16x8_t frag_kstrided(const char* lds_tile, int tile, int ks, int lane) {
@@ -110,20 +122,170 @@ __device__ __forceinline__ bf16x8_t frag_kstrided(const char* lds_tile, int tile
   return u.v;
 }
 
-template <int BM, int BN, bool A_KMAJOR, bool B_KMAJOR, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  constexpr int WM = BM / 2, WN = BN / 2;          // wave tile
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int TM, int TN, int WM, int WN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[TM][TN], char* lds, int wave, int lane,
+                                              int row0, int col0) {
+  // row0/col0: global coordinates of this wave's tile origin
+  constexpr int PT = TM >= 2 ? 2 : 1;              // MFMA row-tiles per epilogue pass
+  if (EPI == 1) {
+    // weight-gradient epilogue: fp32 accumulate into C (atomics; C is pre-zeroed or holds the running sum)
+    float* C = (float*)p.C;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int n = col0 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int m = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < p.M && n < p.N) unsafeAtomicAdd(&C[(size_t)m * p.ldc + n], acc[i][j][r]);
+        }
+      }
+    return;
+  } else {
+    // activation epilogue: registers -> wave-private fp32 LDS patch (PT*32 rows x WN) -> 8-column strips per lane
+    // (16-B bf16 / 2 x 16-B fp32 stores: the store tail is issue-bound per instruction, so wide stores halve it)
+    float* patch = (float*)(lds) + wave * (PT * 32 * WN);
+    constexpr int LPR = WN / 8;          // lanes per row
+    constexpr int RPI = 64 / LPR;        // rows per iteration
+    const int cl = (lane % LPR) * 8;
+    const int n = col0 + cl;
+    const bool ncol_ok = n < p.N;        // N % 8 == 0 (or N % 4 with the narrow path) is a host-checked precondition
+    const bool wide = p.wide_ok && (n + 8 <= p.N);
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias && ncol_ok) {
+      f32x4_t b = *(const f32x4_t*)(p.bias + n);
+      bias8[0] = b[0]; bias8[1] = b[1]; bias8[2] = b[2]; bias8[3] = b[3];
+      if (n + 4 < p.N) { f32x4_t c = *(const f32x4_t*)(p.bias + n + 4); bias8[4] = c[0]; bias8[5] = c[1]; bias8[6] = c[2]; bias8[7] = c[3]; }
+    }
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ps = 0; ps < TM / PT; ++ps) {
+#pragma unroll
+      for (int i = 0; i < PT; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            int nl = j * 32 + (lane & 31);
+            patch[ml * WN + nl] = acc[ps * PT + i][j][r];
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // W consecutive columns starting at column offset `co` of this lane's 8-column strip, row m (patch row ml)
+      auto body = [&](auto W_, int co, int ml, int m) {
+        constexpr int W = decltype(W_)::value;
+        const int nn = n + co;
+        float v[W];
+#pragma unroll
+        for (int q = 0; q < W / 4; ++q) {
+          f32x4_t t4 = *(const f32x4_t*)(patch + ml * WN + cl + co + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e] + bias8[co + 4 * q + e];
+        }
+        auto load_bf = [&](const bf16_t* ptr, float* h) {
+          if (W == 8) {
+            u32x4_t a = *(const u32x4_t*)ptr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[2 * e] = bflo(a[e]); h[2 * e + 1] = bfhi(a[e]); }
+          } else {
+            u32x2_t a = *(const u32x2_t*)ptr;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { h[2 * e] = bflo(a[e]); h[2 * e + 1] = bfhi(a[e]); }
+          }
+        };
+        auto store_bf = [&](bf16_t* ptr, const float* x) {
+          if (W == 8) {
+            u32x4_t o; o[0] = pack2bf(x[0], x[1]); o[1] = pack2bf(x[2], x[3]); o[2] = pack2bf(x[4], x[5]); o[3] = pack2bf(x[6], x[7]);
+            *(u32x4_t*)ptr = o;
+          } else {
+            u32x2_t o; o[0] = pack2bf(x[0], x[1]); o[1] = pack2bf(x[2], x[3]);
+            *(u32x2_t*)ptr = o;
+          }
+        };
+        if (p.act >= 3) {
+          float h[W];
+          load_bf(p.aux + (size_t)m * p.ldaux + nn, h);
+#pragma unroll
+          for (int e = 0; e < W; ++e) v[e] *= (p.act == 3) ? dgelu_erf(h[e]) : dgelu_tanh(h[e]);
+        }
+        if (p.C2) store_bf(p.C2 + (size_t)m * p.ldc2 + nn, v);
+        if (p.act == 1) {
+#pragma unroll
+          for (int e = 0; e < W; ++e) v[e] = gelu_erf(v[e]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int e = 0; e < W; ++e) v[e] = gelu_tanh(v[e]);
+        }
+        if (p.drop_thresh) {
+#pragma unroll
+          for (int e = 0; e < W; ++e)
+            v[e] = drop_keep(p.drop_seed, (uint64_t)m * (uint64_t)p.N + (uint64_t)(nn + e), p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
+        }
+        if (p.res) {
+          int mr = p.res_period ? (m % p.res_period) : m;
+          float h[W];
+          load_bf(p.res + (size_t)mr * p.ldres + nn, h);
+#pragma unroll
+          for (int e = 0; e < W; ++e) v[e] += h[e];
+        }
+        if (p.colsum) {
+#pragma unroll
+          for (int e = 0; e < W; ++e) csum[co + e] += v[e];
+        }
+        if (p.out_f32) {
+          float* crow = (float*)p.C + (size_t)m * p.ldc + nn;
+#pragma unroll
+          for (int q = 0; q < W / 4; ++q) *(f32x4_t*)(crow + 4 * q) = (f32x4_t){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        } else {
+          store_bf((bf16_t*)p.C + (size_t)m * p.ldc + nn, v);
+        }
+      };
+#pragma unroll 2
+      for (int itr = 0; itr < PT * 32 / RPI; ++itr) {
+        int ml = itr * RPI + lane / LPR;
+        int m = row0 + ps * PT * 32 + ml;
+        if (m < p.M && ncol_ok) {
+          if (wide) body(std::integral_constant<int, 8>{}, 0, ml, m);
+          else {
+            body(std::integral_constant<int, 4>{}, 0, ml, m);
+            if (n + 4 < p.N) body(std::integral_constant<int, 4>{}, 4, ml, m);
+          }
+        }
+      }
+    }
+    if (p.colsum) {
+      // lanes sharing (lane % LPR) own the same 8 columns: fold the RPI row groups, one atomic per column
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) csum[e] += __shfl_xor(csum[e], o, 64);
+      }
+      if (lane < LPR && ncol_ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.N) unsafeAtomicAdd(&p.colsum[n + e], csum[e]);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool A_KMAJOR, bool B_KMAJOR, int EPI>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmParams p) {
+  constexpr int NW = WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;      // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;        // 32x32 MFMA tiles per wave
   constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;
   constexpr int STAGE = A_TILE + B_TILE;
-  constexpr int EPI_BYTES = (EPI == 0) ? 4 * WM * WN * 4 : 0;
-  constexpr int LDS_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+  extern __shared__ __attribute__((aligned(16))) char lds[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
 
   const int ntile = p.tiles_m * p.tiles_n;
   const int bid = blockIdx.x;
@@ -148,155 +310,292 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  constexpr int NL = (BM + BN) * BK * 2 / (NW * 1024);   // LDS-DMA instructions per stage per wave
   auto stage = [&](int buf, int kt) {
     char* base = lds + buf * STAGE;
     int k0 = kt * BK;
-    if (A_KMAJOR) stage_kmajor<BM>(ra, base, tm0, k0, p.lda, p.K, wave, lane);
-    else stage_kstrided<BM>(ra, base, tm0, k0, p.lda, p.M, wave, lane);
-    if (B_KMAJOR) stage_kmajor<BN>(rb, base + A_TILE, tn0, k0, p.ldb, p.K, wave, lane);
-    else stage_kstrided<BN>(rb, base + A_TILE, tn0, k0, p.ldb, p.N, wave, lane);
+    if (A_KMAJOR) stage_kmajor<BM, NW, BK>(ra, base, tm0, k0, p.lda, p.K, wave, lane);
+    else stage_kstrided<BM, NW, BK>(ra, base, tm0, k0, p.lda, p.M, wave, lane);
+    if (B_KMAJOR) stage_kmajor<BN, NW, BK>(rb, base + A_TILE, tn0, k0, p.ldb, p.K, wave, lane);
+    else stage_kstrided<BN, NW, BK>(rb, base + A_TILE, tn0, k0, p.ldb, p.N, wave, lane);
   };
 
-  if (nk > 0) {
-    stage(0, kt_begin);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
+  long long t_start = 0, t_loop = 0;
+  if (p.dbg) t_start = __builtin_readcyclecounter();
+  // NSTAGE-deep LDS ring, one barrier per K tile: iteration `it` waits (counted vmcnt) until its own tile has
+  // landed while up to NSTAGE-2 younger tiles stay in flight across the barrier, then refills the slot that was
+  // consumed in iteration it-1 with tile it+NSTAGE-1, then computes.
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) stage(s, kt_begin + s);
+  int slot = 0;
   for (int it = 0; it < nk; ++it) {
-    const int cur = it & 1;
-    if (it + 1 < nk) stage(cur ^ 1, kt_begin + it + 1);
-    const char* la = lds + cur * STAGE;
+    if (NSTAGE >= 3 && it + NSTAGE - 2 < nk) wait_vmcnt<(NSTAGE - 2) * NL>();
+    else if (NSTAGE >= 4 && it + NSTAGE - 3 < nk) wait_vmcnt<(NSTAGE >= 4 ? (NSTAGE - 3) * NL : 0)>();
+    else wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    if (it + NSTAGE - 1 < nk) {
+      int fill = slot + NSTAGE - 1; if (fill >= NSTAGE) fill -= NSTAGE;
+      stage(fill, kt_begin + it + NSTAGE - 1);
+    }
+    const char* la = lds + slot * STAGE;
     const char* lb = la + A_TILE;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8_t af[TM], bfr[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        af[i] = A_KMAJOR ? frag_kmajor(la, wm * TM + i, ks, lane) : frag_kstrided<BM>(la, wm * TM + i, ks, lane);
+        af[i] = A_KMAJOR ? frag_kmajor<BK>(la, wm * TM + i, ks, lane) : frag_kstrided<BM>(la, wm * TM + i, ks, lane);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        bfr[j] = B_KMAJOR ? frag_kmajor(lb, wn * TN + j, ks, lane) : frag_kstrided<BN>(lb, wn * TN + j, ks, lane);
+        bfr[j] = B_KMAJOR ? frag_kmajor<BK>(lb, wn * TN + j, ks, lane) : frag_kstrided<BN>(lb, wn * TN + j, ks, lane);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (++slot == NSTAGE) slot = 0;
   }
+  asm volatile("s_barrier" ::: "memory");   // every wave is done reading the ring before the epilogue reuses it
+  if (p.dbg) t_loop = __builtin_readcyclecounter();
 
-  if (EPI == 1) {
-    // weight-gradient epilogue: fp32 accumulate into C (atomics; C is pre-zeroed or holds the running sum)
-    float* C = (float*)p.C;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        int n = tn0 + wn * WN + j * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int m = tm0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < p.M && n < p.N) unsafeAtomicAdd(&C[(size_t)m * p.ldc + n], acc[i][j][r]);
-        }
-      }
-    return;
-  } else {
-    // activation epilogue: registers -> wave-private fp32 LDS patch -> row-major 4-column strips per lane
-    float* patch = (float*)(lds) + wave * (WM * WN);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          int nl = j * 32 + (lane & 31);
-          patch[ml * WN + nl] = acc[i][j][r];
-        }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    constexpr int LPR = WN / 4;          // lanes per row
-    constexpr int RPI = 64 / LPR;        // rows per iteration
-    const int cl = (lane % LPR) * 4;
-    const int n = tn0 + wn * WN + cl;
-    const bool ncol_ok = n < p.N;        // N % 4 == 0 is a host-checked precondition
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && ncol_ok) { f32x4_t b = *(const f32x4_t*)(p.bias + n); bias4[0] = b[0]; bias4[1] = b[1]; bias4[2] = b[2]; bias4[3] = b[3]; }
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int itr = 0; itr < WM / RPI; ++itr) {
-      int ml = itr * RPI + lane / LPR;
-      int m = tm0 + wm * WM + ml;
-      if (m < p.M && ncol_ok) {
-        f32x4_t v4 = *(const f32x4_t*)(patch + ml * WN + cl);
-        float v[4] = {v4[0] + bias4[0], v4[1] + bias4[1], v4[2] + bias4[2], v4[3] + bias4[3]};
-        if (p.act >= 3) {
-          u32x2_t a = *(const u32x2_t*)(p.aux + (size_t)m * p.ldaux + n);
-          float h[4] = {bflo(a[0]), bfhi(a[0]), bflo(a[1]), bfhi(a[1])};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= (p.act == 3) ? dgelu_erf(h[e]) : dgelu_tanh(h[e]);
-        }
-        if (p.C2) {
-          u32x2_t o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-          *(u32x2_t*)(p.C2 + (size_t)m * p.ldc2 + n) = o;
-        }
-        if (p.act == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-        } else if (p.act == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-        }
-        if (p.drop_thresh) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v[e] = drop_keep(p.drop_seed, (uint64_t)m * (uint64_t)p.N + (uint64_t)(n + e), p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
-        }
-        if (p.res) {
-          int mr = p.res_period ? (m % p.res_period) : m;
-          u32x2_t a = *(const u32x2_t*)(p.res + (size_t)mr * p.ldres + n);
-          v[0] += bflo(a[0]); v[1] += bfhi(a[0]); v[2] += bflo(a[1]); v[3] += bfhi(a[1]);
-        }
-        if (p.colsum) { csum[0] += v[0]; csum[1] += v[1]; csum[2] += v[2]; csum[3] += v[3]; }
-        if (p.out_f32) {
-          f32x4_t o = {v[0], v[1], v[2], v[3]};
-          *(f32x4_t*)((float*)p.C + (size_t)m * p.ldc + n) = o;
-        } else {
-          u32x2_t o; o[0] = pack2bf(v[0], v[1]); o[1] = pack2bf(v[2], v[3]);
-          *(u32x2_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
-        }
-      }
-    }
-    if (p.colsum) {
-      // lanes sharing (lane % LPR) own the same 4 columns: fold the RPI row groups, one atomic per column
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-#pragma unroll
-        for (int o = LPR; o < 64; o <<= 1) csum[e] += __shfl_xor(csum[e], o, 64);
-      }
-      if (lane < LPR && ncol_ok) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(&p.colsum[n + e], csum[e]);
-      }
-    }
+  gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
+  if (p.dbg && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    long long t_end = __builtin_readcyclecounter();
+    p.dbg[bid * 4 + 0] = t_start; p.dbg[bid * 4 + 1] = t_loop; p.dbg[bid * 4 + 2] = t_end; p.dbg[bid * 4 + 3] = nk;
   }
 }
 
-template <int BM, int BN, bool AK, bool BK_, int EPI>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE>
+constexpr int lds_bytes(int epi) {
+  constexpr int ring = NSTAGE * (BM + BN) * BK * 2;
+  constexpr int TM = BM / WGM / 32;
+  constexpr int PT = TM >= 2 ? 2 : 1;
+  constexpr int patch = WGM * WGN * PT * 32 * (BN / WGN) * 4;
+  return (epi == 0 && patch > ring) ? patch : ring;
+}
+
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool AK, bool BK_, int EPI>
 int launch(const GemmParams& p, hipStream_t s) {
   int grid = p.tiles_m * p.tiles_n * p.splitk;
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, AK, BK_, EPI>), dim3(grid), dim3(256), 0, s, p);
+  constexpr int smem = lds_bytes<BM, BN, WGM, WGN, BK, NSTAGE>(EPI);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI>), dim3(grid), dim3(64 * WGM * WGN), smem, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
 }
 
-template <int BM, int BN, int EPI>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, int EPI>
 int dispatch_layout(const GemmParams& p, int a_kmajor, int b_kmajor, hipStream_t s) {
-  if (a_kmajor && b_kmajor) return launch<BM, BN, true, true, EPI>(p, s);
-  if (a_kmajor && !b_kmajor) return launch<BM, BN, true, false, EPI>(p, s);
-  if (!a_kmajor && !b_kmajor) return launch<BM, BN, false, false, EPI>(p, s);
-  return launch<BM, BN, false, true, EPI>(p, s);
+  if (a_kmajor && b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, true, EPI>(p, s);
+  if (a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, false, EPI>(p, s);
+  if (!a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, false, EPI>(p, s);
+  return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, true, EPI>(p, s);
+}
+
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE>
+int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
+  p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+  const int nk = (p.K + BK - 1) / BK;
+  if (splitk <= 0) {                 // auto: about two blocks' worth of work per CU slot
+    splitk = 1;
+    if (epi == 1) {
+      long tiles = (long)p.tiles_m * p.tiles_n;
+      long target = (BM * BN >= 256 * 256) ? 512 : 768;
+      int kmin = 256 / BK;          // at least 256 reduction steps per split
+      while (tiles * splitk < target && splitk * 2 * kmin <= nk && splitk < 64) splitk *= 2;
+    }
+  }
+  if (splitk > nk) splitk = nk;
+  p.splitk = splitk;
+  return epi ? dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 1>(p, a_kmajor, b_kmajor, s)
+             : dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 0>(p, a_kmajor, b_kmajor, s);
+}
+
+// ---- ping-pong kernel: 256x256 tile, 8 waves = two groups of four, half-K-tile ring ---------------------------
+// Group g owns the 128-row half g of the tile (wave tile 128x64).  Waves w and w+4 share a SIMD; the groups run the
+// same program one phase apart, so on every SIMD one wave issues its 16 MFMAs from registers (compute phase) while
+// the other reads its next fragments from LDS and issues its share of the LDS-DMA (load phase).  LDS holds four
+// half-K-tile slots (32 k each: A [256][32] + B [256][32] = 32 KB); a slot is refilled as soon as both groups have
+// read it, 1.5 K tiles ahead of its next use.  Four phases (one barrier each) per 64-deep K tile t:
+//     P0: G0 reads (t,h0), stages A(t+1,h1) | G1 computes (t-1,h1)        P1: G0 computes (t,h0) | G1 reads (t,h0), stages B(t+1,h1)
+//     P2: G0 reads (t,h1), stages A(t+2,h0) | G1 computes (t,h0)          P3: G0 computes (t,h1) | G1 reads (t,h1), stages B(t+2,h0)
+// Every wave keeps its two youngest 4-instruction DMA batches in flight across the barriers (s_waitcnt vmcnt(8)).
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); if (ABL != 3 && ABL != 4) asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, BK = 64, HK = 32, WM = 128, WN = 64, TM = 4, TN = 2;
+  constexpr int A_HALF = BM * HK * 2, B_HALF = BN * HK * 2, SLOT = A_HALF + B_HALF;   // 16 + 16 KB
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int split = bid / ntile;
+  const int t = xcd_remap(bid - split * ntile, ntile);
+  const int tm0 = (t / p.tiles_n) * BM;
+  const int tn0 = (t % p.tiles_n) * BN;
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
+  const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
+  const int nk = kt_end - kt_begin;
+
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  bf16x8_t af[2][TM], bfr[2][TN];
+
+  // group 0 stages A half-tiles, group 1 stages B half-tiles (4 waves x 4 instructions = 16 KB each)
+  auto stage_half = [&](int kt_rel, int h) {       // K tile (relative), half h -> slot ((kt&1)*2 + h)
+    if (kt_rel >= nk || ABL == 1 || ABL == 4) return;
+    char* base = lds + ((kt_rel & 1) * 2 + h) * SLOT;
+    const int k0 = (kt_begin + kt_rel) * BK + h * HK;
+    if (grp == 0) {
+      if (A_KMAJOR) stage_kmajor<BM, 4, HK>(ra, base, tm0, k0, p.lda, p.K, wn, lane);
+      else stage_kstrided<BM, 4, HK>(ra, base, tm0, k0, p.lda, p.M, wn, lane);
+    } else {
+      if (B_KMAJOR) stage_kmajor<BN, 4, HK>(rb, base + A_HALF, tn0, k0, p.ldb, p.K, wn, lane);
+      else stage_kstrided<BN, 4, HK>(rb, base + A_HALF, tn0, k0, p.ldb, p.N, wn, lane);
+    }
+  };
+  bool first_frag = true;
+  auto load_frags = [&](int kt_rel, int h) {
+    if ((ABL == 2 || ABL == 4) && !first_frag) { asm volatile("" ::: "memory"); return; }
+    first_frag = false;
+    const char* la = lds + ((kt_rel & 1) * 2 + h) * SLOT;
+    const char* lb = la + A_HALF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[ks][i] = A_KMAJOR ? frag_kmajor<HK>(la, grp * TM + i, ks, lane) : frag_kstrided<BM>(la, grp * TM + i, ks, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bfr[ks][j] = B_KMAJOR ? frag_kmajor<HK>(lb, wn * TN + j, ks, lane) : frag_kstrided<BN>(lb, wn * TN + j, ks, lane);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  auto compute = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // wait until this wave's share of every half-tile older than its two youngest batches has landed
+  auto wait_ring = [&](int it) {
+    if (it + 2 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>();
+  };
+
+  stage_half(0, 0); stage_half(0, 1); stage_half(1, 0);
+  wait_ring(-1);
+  PP_BARRIER();
+  if (grp == 0) {
+    for (int it = 0; it < nk; ++it) {
+      stage_half(it + 1, 1);            // P0
+      load_frags(it, 0);
+      PP_BARRIER();
+      compute();                        // P1
+      wait_ring(it);
+      PP_BARRIER();
+      stage_half(it + 2, 0);            // P2
+      load_frags(it, 1);
+      PP_BARRIER();
+      compute();                        // P3
+      wait_ring(it + 1);
+      PP_BARRIER();
+    }
+    PP_BARRIER();                       // partner's trailing compute phase
+  } else {
+    for (int it = 0; it < nk; ++it) {
+      if (it > 0) compute();            // P0
+      PP_BARRIER();
+      stage_half(it + 1, 1);            // P1
+      load_frags(it, 0);
+      wait_ring(it);
+      PP_BARRIER();
+      compute();                        // P2
+      PP_BARRIER();
+      stage_half(it + 2, 0);            // P3
+      load_frags(it, 1);
+      wait_ring(it + 1);
+      PP_BARRIER();
+    }
+    if (nk > 0) compute();
+    PP_BARRIER();
+  }
+  gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + grp * WM, tn0 + wn * WN);
+}
+
+template <bool AK, bool BK_, int EPI, int ABL = 0>
+int launch_pp(const GemmParams& p, hipStream_t s) {
+  int grid = p.tiles_m * p.tiles_n * p.splitk;
+  constexpr int smem = 2 * (256 + 256) * 64 * 2;       // 128 KiB ring == 8 waves x 16 KiB epilogue patches
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AK, BK_, EPI, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_pp_kernel<AK, BK_, EPI, ABL>), dim3(grid), dim3(512), smem, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+int dispatch_pp(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
+  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
+  const int nk = (p.K + 63) / 64;
+  if (splitk <= 0) {
+    splitk = 1;
+    if (epi == 1) {
+      long tiles = (long)p.tiles_m * p.tiles_n;
+      while (tiles * splitk < 512 && splitk * 2 * 4 <= nk && splitk < 64) splitk *= 2;
+    }
+  }
+  if (splitk > nk) splitk = nk;
+  p.splitk = splitk;
+  if (epi == 0) {
+    if (a_kmajor && b_kmajor) {
+      static int abl = -1;
+      if (abl < 0) { const char* e = getenv("AVT_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
+      switch (abl) {          // lab-only variants (wrong results by construction): what does each piece cost?
+        case 1: return launch_pp<true, true, 0, 1>(p, s);
+        case 2: return launch_pp<true, true, 0, 2>(p, s);
+        case 3: return launch_pp<true, true, 0, 3>(p, s);
+        case 4: return launch_pp<true, true, 0, 4>(p, s);
+        default: break;
+      }
+      return launch_pp<true, true, 0>(p, s);
+    }
+    if (a_kmajor && !b_kmajor) return launch_pp<true, false, 0>(p, s);
+    if (!a_kmajor && !b_kmajor) return launch_pp<false, false, 0>(p, s);
+    return launch_pp<false, true, 0>(p, s);
+  }
+  if (a_kmajor && b_kmajor) return launch_pp<true, true, 1>(p, s);
+  if (a_kmajor && !b_kmajor) return launch_pp<true, false, 1>(p, s);
+  if (!a_kmajor && !b_kmajor) return launch_pp<false, false, 1>(p, s);
+  return launch_pp<false, true, 1>(p, s);
 }
 
 }  // namespace
@@ -322,6 +621,7 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldres = ldres; p.ldaux = ldaux;
   p.res_period = res_period; p.act = act; p.out_f32 = (out_mode == 1);
   p.drop_thresh = drop_threshold(drop_p); p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed;
+  { static const char* e = getenv("AVT_GEMM_DBG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
   size_t a_rows = a_kmajor ? (size_t)M : (size_t)K, b_rows = b_kmajor ? (size_t)N : (size_t)K;
   size_t ab = a_rows * (size_t)lda * 2, bb = b_rows * (size_t)ldb * 2;
   AVT_CHECK(ab < 0xFFFFFFF0ull && bb < 0xFFFFFFF0ull, "avt_gemm_bf16: operand larger than 4 GiB");
@@ -329,25 +629,31 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
   hipStream_t s = (hipStream_t)stream;
   const int epi = (out_mode == 2) ? 1 : 0;
   if (epi == 0) {
-    AVT_CHECK(N % 4 == 0 && ldc % 4 == 0, "avt_gemm_bf16: N and ldc must be multiples of 4 for the activation epilogue");
+    AVT_CHECK(N % 4 == 0 && ldc % 4 == 0 && (!C2 || ldc2 % 4 == 0) && (!res || ldres % 4 == 0) && (!aux || ldaux % 4 == 0),
+              "avt_gemm_bf16: N and ldc/ldc2/ldres/ldaux must be multiples of 4 for the activation epilogue");
+    p.wide_ok = (ldc % 8 == 0) && (!C2 || ldc2 % 8 == 0) && (!res || ldres % 8 == 0) && (!aux || ldaux % 8 == 0);
     AVT_CHECK(splitk <= 1, "avt_gemm_bf16: split-K needs out_mode 2");
   } else {
     AVT_CHECK(!bias && !act && !C2 && !res && !colsum && drop_p == 0.f, "avt_gemm_bf16: accumulate mode has no fused epilogue");
   }
-  int bm = 128;
-  if (tile == 64 || (tile == 0 && epi == 0 && (long)((M + 127) / 128) * ((N + 127) / 128) < 192)) bm = 64;
-  if (epi == 1) bm = (tile == 64) ? 64 : 128;
-  p.tiles_m = (M + bm - 1) / bm; p.tiles_n = (N + bm - 1) / bm;
-  int nk = (K + BK - 1) / BK;
-  if (splitk <= 0) {                 // auto: fill ~2 waves of the 256 CUs x 2 blocks
-    splitk = 1;
-    if (epi == 1) {
-      long tiles = (long)p.tiles_m * p.tiles_n;
-      while (tiles * splitk < 768 && splitk * 2 <= nk / 4 && splitk < 64) splitk *= 2;
+  int bm = tile;
+  if (bm == 0) {
+    long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (epi == 0) bm = (t256 >= 200) ? 256 : (t128 >= 192 ? 128 : 64);
+    else {
+      long sk = ((K + 63) / 64) / 4; if (sk < 1) sk = 1; if (sk > 64) sk = 64;
+      bm = (t256 * sk >= 256 && t256 < 4096) ? 256 : 128;
     }
   }
-  if (splitk > nk) splitk = nk;
-  p.splitk = splitk;
-  if (bm == 128) return epi ? dispatch_layout<128, 128, 1>(p, a_kmajor, b_kmajor, s) : dispatch_layout<128, 128, 0>(p, a_kmajor, b_kmajor, s);
-  return epi ? dispatch_layout<64, 64, 1>(p, a_kmajor, b_kmajor, s) : dispatch_layout<64, 64, 0>(p, a_kmajor, b_kmajor, s);
+  switch (bm) {
+    case 64:  return dispatch_epi<64, 64, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
+    case 128: return dispatch_epi<128, 128, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
+    case 256: return dispatch_epi<256, 256, 2, 4, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
+    case 384: return dispatch_epi<128, 256, 1, 4, 32, 3>(p, epi, a_kmajor, b_kmajor, splitk, s);   // 2 blocks/CU, 3-deep ring
+    case 512: return dispatch_pp(p, epi, a_kmajor, b_kmajor, splitk, s);                            // ping-pong 256x256
+    default: break;
+  }
+  avt_set_error("avt_gemm_bf16: tile must be 0, 64, 128, 256 or 384 (got %d)", tile);
+  return -1;
 }

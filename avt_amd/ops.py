@@ -23,12 +23,19 @@ def _stream():
 def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile):
     """Mirror of the tile choice in avt_gemm_bf16 (csrc/gemm.hip): names the kernel template a call lands on."""
     epi = 1 if out_mode == OUT_ACCUM_F32 else 0
-    bm = 128
-    if epi == 0 and (tile == 64 or (tile == 0 and ((M + 127) // 128) * ((N + 127) // 128) < 192)):
-        bm = 64
-    if epi == 1:
-        bm = 64 if tile == 64 else 128
-    return f'gemm_kernel<{bm},{bm},{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
+    bm = tile
+    if bm == 0:
+        t256 = ((M + 255) // 256) * ((N + 255) // 256)
+        t128 = ((M + 127) // 128) * ((N + 127) // 128)
+        if epi == 0:
+            bm = 256 if t256 >= 200 else (128 if t128 >= 192 else 64)
+        else:
+            sk = min(max(((K + 63) // 64) // 4, 1), 64)
+            bm = 256 if (t256 * sk >= 256 and t256 < 4096) else 128
+    shape = {64: '64,64,2,2,64,2', 128: '128,128,2,2,64,2', 256: '256,256,2,4,64,2', 384: '128,256,1,4,32,3', 512: 'pp'}[bm]
+    if bm == 512:
+        return f'gemm_pp_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
+    return f'gemm_kernel<{shape},{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
 
 
 def _p(t):
