@@ -141,7 +141,8 @@ def _num(x):
     return x
 
 
-def _resolve_str(s, root, depth=0):
+def _resolve_str(s, root, depth=0, path=()):
+    """``path`` = key path of the node holding ``s`` (needed for OmegaConf-style relative keys ``${.a}`` / ``${..a}``)."""
     if depth > 20:
         raise ValueError(f'interpolation too deep: {s}')
     pat = re.compile(r'\$\{([^${}]+)\}')
@@ -155,24 +156,31 @@ def _resolve_str(s, root, depth=0):
             if name == 'hydra':
                 val = os.getcwd()
             else:
-                args = [_resolve_str(a.strip(), root, depth + 1) for a in argstr.split(',')]
+                args = [_resolve_str(a.strip(), root, depth + 1, path) for a in argstr.split(',')]
                 val = _RESOLVERS[name](*args)
         elif expr == 'cwd':
             val = os.getcwd()
         else:
-            val = _resolve_str(_get(root, expr), root, depth + 1)
+            if expr.startswith('.'):
+                ndots = len(expr) - len(expr.lstrip('.'))
+                base = list(path[:-1])
+                base = base[:len(base) - (ndots - 1)] if ndots > 1 else base
+                target = '.'.join(base + [expr.lstrip('.')])
+            else:
+                target = expr
+            val = _resolve_str(_get(root, target), root, depth + 1, tuple(target.split('.')))
         if m.start() == 0 and m.end() == len(s):
             return val
         s = s[:m.start()] + str(val) + s[m.end():]
 
 
-def _resolve(node, root):
+def _resolve(node, root, path=()):
     if isinstance(node, dict):
-        return {k: _resolve(v, root) for k, v in node.items()}
+        return {k: _resolve(v, root, path + (k,)) for k, v in node.items()}
     if isinstance(node, list):
-        return [_resolve(v, root) for v in node]
+        return [_resolve(v, root, path) for v in node]
     if isinstance(node, str) and '${' in node:
-        v = _resolve_str(node, root)
+        v = _resolve_str(node, root, 0, path)
         if isinstance(v, str):
             try:
                 parsed = yaml.safe_load(v)
@@ -180,7 +188,7 @@ def _resolve(node, root):
                     v = parsed
             except yaml.YAMLError:
                 pass
-        return v if isinstance(v, str) else _resolve(v, root)
+        return v if isinstance(v, str) else _resolve(v, root, path)
     return node
 
 

@@ -1,0 +1,113 @@
+"""CPU (-m "not gpu"): the oracle (oracle/avt_oracle.py) against the golden vectors produced by the reference's own
+modules (oracle/make_golden.py, run in the build container).  fp32 vs fp32: tolerance 1e-4 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import LOSS_WTS, build_oracle_model, load_golden, oracle_step, rel
+from oracle import avt_oracle as O
+
+
+def test_g1_tiny_head(golden_dir):
+    g = load_golden(os.path.join(golden_dir, 'g1_tiny_head.npz'))
+    orc = build_oracle_model('feat', 32, 64, 2, 4, 17)
+    O.closed_form_fill_(list(orc.named_parameters()))
+    out, losses, accs, tot = oracle_step(orc, g['in/video'], g['in/target'], g['in/sub'])
+    for k in ['logits/action', 'past_logits/action', 'future', 'past', 'backbone', 'backbone_mean', 'temp_agg',
+              'temp_agg_projected', 'future_projected', 'future_agg']:
+        assert out[k].shape == g[f'out/{k}'].shape, k
+        assert rel(out[k], g[f'out/{k}']) < 1e-4, k
+    assert set(k[4:] for k in g if k.startswith('out/')) == set(out.keys())          # the reference's exact key set
+    for k in ['cls_action', 'past_cls_action', 'feat']:
+        assert rel(losses[k], g[f'loss/{k}']) < 1e-4
+    assert abs(float(tot) - float(g['total_loss'])) < 1e-5
+    assert float(accs['acc1/action']) == float(g['acc/acc1/action']) and float(accs['acc5/action']) == float(g['acc/acc5/action'])
+    params = dict(orc.named_parameters())
+    for k in [k for k in g if k.startswith('grad/')]:
+        assert rel(params[k[5:]].grad, g[k]) < 1e-4, k
+    # two SGD-nesterov steps with the oracle's update rule vs torch.optim.SGD run on the reference model
+    bufs = {n: torch.zeros_like(p) for n, p in params.items()}
+    with torch.no_grad():
+        for n, p in params.items():
+            O.sgd_nesterov_step(p, p.grad, bufs[n], 0.05, 0.9, 1e-6, first=True)
+    _, _, _, tot2 = oracle_step(orc, g['in/video'], g['in/target'], g['in/sub'])
+    assert abs(float(tot2) - float(g['step2/total_loss'])) < 1e-4
+    with torch.no_grad():
+        for n, p in params.items():
+            O.sgd_nesterov_step(p, p.grad, bufs[n], 0.05, 0.9, 1e-6, first=False)
+    for n in ['classifiers.action.weight', 'future_predictor.encoder.weight']:
+        assert rel(params[n], g[f'post2/{n}']) < 1e-4
+
+
+def test_g2_full_head(golden_dir):
+    g = load_golden(os.path.join(golden_dir, 'g2_full_head.npz'))
+    from oracle.make_golden import synth_batch
+    orc = build_oracle_model('feat', 1024, 2048, 6, 4, 3806)
+    O.closed_form_fill_(list(orc.named_parameters()))
+    video, target, sub = synth_batch(2, 10, 3806, (1024, 1, 1, 1), seed=2)
+    out, losses, accs, tot = oracle_step(orc, video, target, sub)
+    assert rel(out['logits/action'], g['out/logits/action']) < 1e-4
+    assert abs(float(tot) - float(g['total_loss'])) / abs(float(g['total_loss'])) < 1e-5
+    for n, p in orc.named_parameters():
+        assert abs(float(p.grad.norm()) - float(g[f'gradnorm/{n}'])) / (float(g[f'gradnorm/{n}']) + 1e-12) < 1e-3, n
+
+
+def test_g3_tiny_vit(golden_dir):
+    g = load_golden(os.path.join(golden_dir, 'g3_tiny_vit.npz'))
+    orc = build_oracle_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
+    O.closed_form_fill_(list(orc.named_parameters()))
+    out, losses, accs, tot = oracle_step(orc, g['in/video'], g['in/target'], g['in/sub'])
+    assert rel(out['logits/action'], g['out/logits/action']) < 1e-4
+    assert rel(out['backbone'], g['out/backbone']) < 1e-4
+    assert abs(float(tot) - float(g['total_loss'])) < 1e-4
+    gq = orc.backbone.model.blocks[0].attn.qkv.weight.grad
+    assert rel(gq[:128], g['grad/hf_query0']) < 1e-3        # HF ViT's own autograd on its q projection
+
+
+def test_g3b_vitb_cls(golden_dir):
+    g = load_golden(os.path.join(golden_dir, 'g3b_vitb_cls.npz'))
+    vit = O.OracleViT(768, 12, 12)
+    O.closed_form_fill_(list(vit.named_parameters()))
+    assert sum(p.numel() for p in vit.parameters()) == 85798656
+    gen = torch.Generator().manual_seed(4)
+    frames = torch.rand((2, 3, 224, 224), generator=gen) * 2 - 1
+    with torch.no_grad():
+        f = vit(frames)
+    assert rel(f, g['cls_hf']) < 1e-4
+
+
+def test_g4_lr_schedules(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'g4_lr_schedules.npz'))
+    for key in z.files:
+        W, C, I, B, N = [float(x[1:]) for x in key.split('_')]
+        ref = z[key]
+        mine = O.lr_schedule(B * N, int(W * I), int(C * I), len(ref))
+        assert np.abs(np.asarray(mine) - ref).max() < 1e-12, key
+
+
+def test_g5_ops(golden_dir):
+    g = load_golden(os.path.join(golden_dir, 'g5_ops.npz'))
+    x = g['x']
+    assert rel(torch.nn.functional.layer_norm(x, (48,), g['ln_w'], g['ln_b'], 1e-6), g['ln_eps1e-6']) < 1e-6
+    assert rel(torch.nn.functional.gelu(x), g['gelu_erf']) < 1e-6
+    assert rel(O.gelu_new(x), g['gelu_new']) < 1e-6
+    assert rel(O.multidim_cross_entropy(g['ce_logits'], g['ce_target']), g['ce_loss']) < 1e-6
+    a1, a5 = O.topk_accuracy(g['ce_logits'], g['ce_target'], (1, 5))
+    assert float(a1) == float(g['acc1']) and float(a5) == float(g['acc5'])
+    assert float(O.topk_accuracy(g['ce_logits'], torch.full_like(g['ce_target'], -1), (1,))[0]) == float(g['acc1_all_ignored'])
+
+
+def test_causality_of_the_head():
+    """SURVEY 8a10 probe: perturbing the last frame changes `future` only; `past` is unchanged."""
+    orc = build_oracle_model('feat', 32, 64, 2, 4, 17)
+    O.closed_form_fill_(list(orc.named_parameters()))
+    orc.eval()
+    g = torch.Generator().manual_seed(0)
+    v = torch.rand((1, 6, 32, 1, 1, 1), generator=g)
+    v2 = v.clone(); v2[:, -1] += 1.0
+    with torch.no_grad():
+        a, _ = orc(v, target_shape=(1,)); b, _ = orc(v2, target_shape=(1,))
+    assert float((a['past'] - b['past']).abs().max()) == 0.0
+    assert float((a['future'] - b['future']).abs().max()) > 0
