@@ -1,0 +1,77 @@
+"""-m gpu: the real data-parallel step (arena + backward segment hooks + bucketed all-reduce + fused SGD grad_scale) on
+two ranks sharing cuda:0 over gloo (RCCL needs one device per rank; the 1-GPU box has one), against a single-process
+step on the concatenated batch: averaged-gradient training must give the same parameters."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+root = sys.argv[1]; sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'tests'))
+from helpers import build_hip_model, LOSS_WTS
+from avt_amd.config import Cfg
+from avt_amd.func.train import Trainer
+from avt_amd.func.train_eval_ops import Basic
+from avt_amd.optim import FusedSGD
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+if world > 1:
+    dist.init_process_group('gloo', init_method='env://', rank=rank, world_size=world)
+torch.manual_seed(0)                       # identical init on every rank (broadcast must be a no-op then)
+model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
+with torch.no_grad():
+    for n, p in model.named_parameters():
+        if p.ndim >= 2: p.normal_(0, 0.1)
+if rank == 1:                              # perturb: broadcast from rank 0 must repair it
+    with torch.no_grad(): model.classifiers.action.bias.add_(1.0)
+opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-4, arena=model.arena)
+op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
+tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=world > 1, bucket_bytes=64 << 10)
+g = torch.Generator().manual_seed(9)
+B = 4
+video = torch.rand((B, 4, 3, 1, 32, 32), generator=g) * 2 - 1
+target = torch.randint(0, 17, (B,), generator=g); sub = torch.randint(-1, 17, (B, 4, 1), generator=g)
+sl = slice(rank * B // world, (rank + 1) * B // world)
+data = {'video': video[sl].cuda(), 'target': {'action': target[sl].cuda()}, 'target_subclips': {'action': sub[sl].cuda()}}
+model.train()
+for m in model.modules():                   # deterministic parity: dropout off
+    if isinstance(m, torch.nn.Dropout): m.p = 0.0
+model.future_predictor.embd_pdrop = model.future_predictor.attn_pdrop = model.future_predictor.resid_pdrop = 0.0
+for _ in range(3):
+    tr.step(data)
+torch.cuda.synchronize()
+if rank == 0:
+    torch.save({k: v.cpu() for k, v in model.state_dict().items()}, sys.argv[2])
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+print('OK', rank)
+'''
+
+
+def _run(world, out, tmp_path, port):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(out)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    for p in procs:
+        o = p.communicate(timeout=600)[0]
+        assert p.returncode == 0 and 'OK' in o, o[-3000:]
+
+
+def test_two_rank_training_matches_single_process(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    _run(1, tmp_path / 'single.pt', tmp_path, 29551)
+    _run(2, tmp_path / 'ddp.pt', tmp_path, 29552)
+    a, b = torch.load(tmp_path / 'single.pt'), torch.load(tmp_path / 'ddp.pt')
+    worst = 0.0
+    for k in a:
+        e = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-12))
+        worst = max(worst, e)
+        assert e < 2e-2, (k, e)          # bf16 activations; batch split changes rounding, not the maths
