@@ -40,6 +40,7 @@ struct GemmParams {
   int tiles_m, tiles_n;
   uint32_t a_bytes, b_bytes;     // buffer-descriptor bounds
   uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
+  int stagger;                   // cycles over which the first wave of workgroups spreads its start (0 = off)
   int wide_ok;                   // all epilogue leading dims are multiples of 8 -> 16-byte accesses allowed
   long long* dbg;                // lab only: per-block phase timestamps (s_memtime), NULL in production
 };
@@ -59,8 +60,36 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // k-major operand: LDS tile [BR][BK] bf16 (BK*2-byte rows).  The 16-B chunk c of row r lives at chunk
 // c ^ ((r>>1)&7) for BK=64 (128-B rows) and c ^ ((r>>2)&3) for BK=32 (64-B rows): the 16 rows a ds_read_b128 lane
 // group touches then land on 16 distinct 16-B slots of the 256-B bank row.
+template <int BR>
+__device__ __forceinline__ int kstrided_swz_fwd(int r) { return BR >= 128 ? ((r & 3) << 2) : (((r >> 1) & 1) << 2); }
 template <int BK>
 __device__ __forceinline__ int kmajor_swz(int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
+template <int BR, int NW, int BK>
+__device__ __forceinline__ void stage_kmajor_part(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int row0, int k0, int ld,
+                                                  int K, int wave, int lane, int j) {
+  constexpr int CPR = BK / 8;
+  constexpr int RPI = 64 / CPR;
+  int r = j * (NW * RPI) + wave * RPI + lane / CPR;
+  int c = (lane % CPR) ^ kmajor_swz<BK>(r);
+  int kcol = k0 + c * 8;
+  uint32_t off = (uint32_t)(((size_t)(row0 + r) * (size_t)ld + (size_t)kcol) * 2);
+  if (kcol >= K) off = 0xFFFFFFF0u;
+  char* dst = lds_tile + (j * (NW * RPI) + wave * RPI) * (BK * 2);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(dst), 16, off, 0, 0, 0);
+}
+template <int BR, int NW, int BK>
+__device__ __forceinline__ void stage_kstrided_part(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int col0, int k0, int ld,
+                                                    int ncols, int wave, int lane, int j) {
+  constexpr int CPR = BR / 8;
+  constexpr int RPI = 64 / CPR;
+  int r = j * NW * RPI + wave * RPI + lane / CPR;
+  int c = (lane % CPR) ^ kstrided_swz_fwd<BR>(r);
+  int col = col0 + c * 8;
+  uint32_t off = (uint32_t)(((size_t)(k0 + r) * (size_t)ld + (size_t)col) * 2);
+  if (col >= ncols) off = 0xFFFFFFF0u;
+  char* dst = lds_tile + (j * NW * RPI + wave * RPI) * (BR * 2);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(dst), 16, off, 0, 0, 0);
+}
 template <int BR, int NW, int BK>
 __device__ __forceinline__ void stage_kmajor(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int row0, int k0, int ld,
                                              int K, int wave, int lane) {
@@ -120,6 +149,16 @@ __device__ __forceinline__ bf16x8_t frag_kstrided(const char* lds_tile, int tile
     u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
   }
   return u.v;
+}
+
+// De-synchronise the chip: all CUs start together and would otherwise hit their output-store tails together (a burst at
+// the HBM write rate while the MFMA pipes idle).  The workgroups of the FIRST dispatch wave start spread over
+// `cycles`; every CU keeps its offset afterwards because it picks up its next tile when it finishes the previous one.
+__device__ __forceinline__ void stagger_start(int cycles, int bid) {
+  if (cycles <= 0 || bid >= 256) return;
+  const long long target = (long long)cycles * ((bid >> 3) & 31) / 32;
+  const long long t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < target) __builtin_amdgcn_s_sleep(16);
 }
 
 template <int N>
@@ -273,7 +312,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool A_KMAJOR, bool B_KMAJOR, int EPI>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPREAD = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmParams p) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;      // wave tile
@@ -298,6 +337,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmParams p) {
   const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
   const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
   const int nk = kt_end - kt_begin;
+  stagger_start(p.stagger, bid);
 
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
@@ -334,26 +374,70 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmParams p) {
     else if (NSTAGE >= 4 && it + NSTAGE - 3 < nk) wait_vmcnt<(NSTAGE >= 4 ? (NSTAGE - 3) * NL : 0)>();
     else wait_vmcnt<0>();
     asm volatile("s_barrier" ::: "memory");
-    if (it + NSTAGE - 1 < nk) {
-      int fill = slot + NSTAGE - 1; if (fill >= NSTAGE) fill -= NSTAGE;
-      stage(fill, kt_begin + it + NSTAGE - 1);
-    }
+    int fill = slot + NSTAGE - 1; if (fill >= NSTAGE) fill -= NSTAGE;
+    const bool more = (it + NSTAGE - 1 < nk);
+    if (!SPREAD && more) stage(fill, kt_begin + it + NSTAGE - 1);
     const char* la = lds + slot * STAGE;
     const char* lb = la + A_TILE;
+    if (!SPREAD) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8_t af[TM], bfr[TN];
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8_t af[TM], bfr[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = A_KMAJOR ? frag_kmajor<BK>(la, wm * TM + i, ks, lane) : frag_kstrided<BM>(la, wm * TM + i, ks, lane);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bfr[j] = B_KMAJOR ? frag_kmajor<BK>(lb, wn * TN + j, ks, lane) : frag_kstrided<BN>(lb, wn * TN + j, ks, lane);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
+          af[i] = A_KMAJOR ? frag_kmajor<BK>(la, wm * TM + i, ks, lane) : frag_kstrided<BM>(la, wm * TM + i, ks, lane);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          bfr[j] = B_KMAJOR ? frag_kmajor<BK>(lb, wn * TN + j, ks, lane) : frag_kstrided<BN>(lb, wn * TN + j, ks, lane);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // software-pipelined k-steps: fragments of step ks+1 are requested before the MFMAs of step ks, and the LDS-DMA
+      // refill of the other stage is dribbled out between the MFMA groups (3+3+2 of the 8 instructions in steps 0..2,
+      // leaving step 3 as landing time) instead of a burst that stalls every wave at the top of the tile.
+      constexpr int KS = BK / 16;
+      constexpr int RA = A_KMAJOR ? BM / (NW * (64 / (BK / 8))) : BK / (NW * (64 / (BM / 8)));   // A rounds
+      constexpr int RB = B_KMAJOR ? BN / (NW * (64 / (BK / 8))) : BK / (NW * (64 / (BN / 8)));   // B rounds
+      char* fbase = lds + fill * STAGE;
+      const int fk0 = (kt_begin + it + NSTAGE - 1) * BK;
+      auto dma_part = [&](int q) {
+        if (!more) return;
+        if (q < RA) {
+          if (A_KMAJOR) stage_kmajor_part<BM, NW, BK>(ra, fbase, tm0, fk0, p.lda, p.K, wave, lane, q);
+          else stage_kstrided_part<BM, NW, BK>(ra, fbase, tm0, fk0, p.lda, p.M, wave, lane, q);
+        } else if (q < RA + RB) {
+          if (B_KMAJOR) stage_kmajor_part<BN, NW, BK>(rb, fbase + A_TILE, tn0, fk0, p.ldb, p.K, wave, lane, q - RA);
+          else stage_kstrided_part<BN, NW, BK>(rb, fbase + A_TILE, tn0, fk0, p.ldb, p.N, wave, lane, q - RA);
+        }
+      };
+      bf16x8_t af[2][TM], bfr[2][TN];
+      auto ldf = [&](int ks, int b) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          af[b][i] = A_KMAJOR ? frag_kmajor<BK>(la, wm * TM + i, ks, lane) : frag_kstrided<BM>(la, wm * TM + i, ks, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bfr[b][j] = B_KMAJOR ? frag_kmajor<BK>(lb, wn * TN + j, ks, lane) : frag_kstrided<BN>(lb, wn * TN + j, ks, lane);
+      };
+      constexpr int NPART = RA + RB;
+      constexpr int PER = (NPART + KS - 2) / (KS - 1);        // parts per k-step over the first KS-1 steps
+      ldf(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) ldf(ks + 1, (ks + 1) & 1);
+#pragma unroll
+        for (int q = 0; q < PER; ++q)
+          if (ks < KS - 1 && ks * PER + q < NPART) dma_part(ks * PER + q);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+      }
     }
     if (++slot == NSTAGE) slot = 0;
   }
@@ -377,30 +461,30 @@ constexpr int lds_bytes(int epi) {
   return (epi == 0 && patch > ring) ? patch : ring;
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool AK, bool BK_, int EPI>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool AK, bool BK_, int EPI, bool SPREAD = false>
 int launch(const GemmParams& p, hipStream_t s) {
   int grid = p.tiles_m * p.tiles_n * p.splitk;
   constexpr int smem = lds_bytes<BM, BN, WGM, WGN, BK, NSTAGE>(EPI);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI>), dim3(grid), dim3(64 * WGM * WGN), smem, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI, SPREAD>), dim3(grid), dim3(64 * WGM * WGN), smem, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, int EPI>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, int EPI, bool SPREAD = false>
 int dispatch_layout(const GemmParams& p, int a_kmajor, int b_kmajor, hipStream_t s) {
-  if (a_kmajor && b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, true, EPI>(p, s);
-  if (a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, false, EPI>(p, s);
-  if (!a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, false, EPI>(p, s);
-  return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, true, EPI>(p, s);
+  if (a_kmajor && b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, true, EPI, SPREAD>(p, s);
+  if (a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, false, EPI, SPREAD>(p, s);
+  if (!a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, false, EPI, SPREAD>(p, s);
+  return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, true, EPI, SPREAD>(p, s);
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool SPREAD = false>
 int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
   const int nk = (p.K + BK - 1) / BK;
@@ -415,8 +499,8 @@ int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk,
   }
   if (splitk > nk) splitk = nk;
   p.splitk = splitk;
-  return epi ? dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 1>(p, a_kmajor, b_kmajor, s)
-             : dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 0>(p, a_kmajor, b_kmajor, s);
+  return epi ? dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 1, SPREAD>(p, a_kmajor, b_kmajor, s)
+             : dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 0, SPREAD>(p, a_kmajor, b_kmajor, s);
 }
 
 // ---- ping-pong kernel: 256x256 tile, 8 waves = two groups of four, half-K-tile ring ---------------------------
@@ -428,7 +512,7 @@ int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk,
 //     P0: G0 reads (t,h0), stages A(t+1,h1) | G1 computes (t-1,h1)        P1: G0 computes (t,h0) | G1 reads (t,h0), stages B(t+1,h1)
 //     P2: G0 reads (t,h1), stages A(t+2,h0) | G1 computes (t,h0)          P3: G0 computes (t,h1) | G1 reads (t,h1), stages B(t+2,h0)
 // Every wave keeps its two youngest 4-instruction DMA batches in flight across the barriers (s_waitcnt vmcnt(8)).
-#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); if (ABL != 3 && ABL != 4) asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); { PP_T0(); if (ABL != 3 && ABL != 4) asm volatile("s_barrier" ::: "memory"); PP_T1(c_bar); } __builtin_amdgcn_sched_barrier(0); } while (0)
 template <bool A_KMAJOR, bool B_KMAJOR, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
   constexpr int BM = 256, BN = 256, BK = 64, HK = 32, WM = 128, WN = 64, TM = 4, TN = 2;
@@ -461,10 +545,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   bf16x8_t af[2][TM], bfr[2][TN];
+  long long c_wait = 0, c_bar = 0, c_comp = 0, c_load = 0, c_t0 = 0, c_dma = 0;
+  const bool prof = (p.dbg != nullptr);
+  if (prof) c_t0 = __builtin_readcyclecounter();
+#define PP_T0() long long t__ = prof ? __builtin_readcyclecounter() : 0
+#define PP_T1(acc_) do { if (prof) acc_ += __builtin_readcyclecounter() - t__; } while (0)
 
   // group 0 stages A half-tiles, group 1 stages B half-tiles (4 waves x 4 instructions = 16 KB each)
   auto stage_half = [&](int kt_rel, int h) {       // K tile (relative), half h -> slot ((kt&1)*2 + h)
     if (kt_rel >= nk || ABL == 1 || ABL == 4) return;
+    PP_T0();
     char* base = lds + ((kt_rel & 1) * 2 + h) * SLOT;
     const int k0 = (kt_begin + kt_rel) * BK + h * HK;
     if (grp == 0) {
@@ -474,11 +564,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
       if (B_KMAJOR) stage_kmajor<BN, 4, HK>(rb, base + A_HALF, tn0, k0, p.ldb, p.K, wn, lane);
       else stage_kstrided<BN, 4, HK>(rb, base + A_HALF, tn0, k0, p.ldb, p.N, wn, lane);
     }
+    PP_T1(c_dma);
   };
   bool first_frag = true;
   auto load_frags = [&](int kt_rel, int h) {
     if ((ABL == 2 || ABL == 4) && !first_frag) { asm volatile("" ::: "memory"); return; }
     first_frag = false;
+    PP_T0();
     const char* la = lds + ((kt_rel & 1) * 2 + h) * SLOT;
     const char* lb = la + A_HALF;
 #pragma unroll
@@ -490,9 +582,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
       for (int j = 0; j < TN; ++j)
         bfr[ks][j] = B_KMAJOR ? frag_kmajor<HK>(lb, wn * TN + j, ks, lane) : frag_kstrided<BN>(lb, wn * TN + j, ks, lane);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PP_T1(c_load);
   };
   auto compute = [&]() {
+    PP_T0();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -502,28 +595,35 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    if (prof) { asm volatile("s_nop 0" ::: "memory"); }
+    PP_T1(c_comp);
   };
   // wait until this wave's share of every half-tile older than its two youngest batches has landed
   auto wait_ring = [&](int it) {
+    PP_T0();
     if (it + 2 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>();
+    PP_T1(c_wait);
   };
 
+  // load phase = fragment reads (asynchronous) -> this wave's share of the LDS-DMA refill -> ring wait -> lgkmcnt(0)
+  auto load_phase = [&](int it, int h) {
+    load_frags(it, h);
+    if (h == 0) stage_half(it + 1, 1); else stage_half(it + 2, 0);
+    wait_ring(it + h);
+    { PP_T0(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PP_T1(c_load); }
+  };
   stage_half(0, 0); stage_half(0, 1); stage_half(1, 0);
   wait_ring(-1);
   PP_BARRIER();
   if (grp == 0) {
     for (int it = 0; it < nk; ++it) {
-      stage_half(it + 1, 1);            // P0
-      load_frags(it, 0);
+      load_phase(it, 0);                // P0
       PP_BARRIER();
       compute();                        // P1
-      wait_ring(it);
       PP_BARRIER();
-      stage_half(it + 2, 0);            // P2
-      load_frags(it, 1);
+      load_phase(it, 1);                // P2
       PP_BARRIER();
       compute();                        // P3
-      wait_ring(it + 1);
       PP_BARRIER();
     }
     PP_BARRIER();                       // partner's trailing compute phase
@@ -531,21 +631,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
     for (int it = 0; it < nk; ++it) {
       if (it > 0) compute();            // P0
       PP_BARRIER();
-      stage_half(it + 1, 1);            // P1
-      load_frags(it, 0);
-      wait_ring(it);
+      load_phase(it, 0);                // P1
       PP_BARRIER();
       compute();                        // P2
       PP_BARRIER();
-      stage_half(it + 2, 0);            // P3
-      load_frags(it, 1);
-      wait_ring(it + 1);
+      load_phase(it, 1);                // P3
       PP_BARRIER();
     }
     if (nk > 0) compute();
     PP_BARRIER();
   }
+  long long c_loop_end = prof ? __builtin_readcyclecounter() : 0;
   gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + grp * WM, tn0 + wn * WN);
+  if (prof && lane == 0 && (wave == 0 || wave == 4)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    long long* d = p.dbg + ((size_t)bid * 2 + grp) * 8;
+    d[0] = c_wait; d[1] = c_bar; d[2] = c_comp; d[3] = c_load; d[4] = c_loop_end - c_t0; d[5] = __builtin_readcyclecounter() - c_loop_end; d[6] = nk; d[7] = c_dma;
+  }
 }
 
 template <bool AK, bool BK_, int EPI, int ABL = 0>
@@ -621,6 +723,7 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldres = ldres; p.ldaux = ldaux;
   p.res_period = res_period; p.act = act; p.out_f32 = (out_mode == 1);
   p.drop_thresh = drop_threshold(drop_p); p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed;
+  { static const char* e2 = getenv("AVT_GEMM_STAGGER"); p.stagger = e2 ? atoi(e2) : 0; }
   { static const char* e = getenv("AVT_GEMM_DBG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
   size_t a_rows = a_kmajor ? (size_t)M : (size_t)K, b_rows = b_kmajor ? (size_t)N : (size_t)K;
   size_t ab = a_rows * (size_t)lda * 2, bb = b_rows * (size_t)ldb * 2;
@@ -651,6 +754,8 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
     case 128: return dispatch_epi<128, 128, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 256: return dispatch_epi<256, 256, 2, 4, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 384: return dispatch_epi<128, 256, 1, 4, 32, 3>(p, epi, a_kmajor, b_kmajor, splitk, s);   // 2 blocks/CU, 3-deep ring
+    case 257: return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);        // spread DMA + pipelined fragments
+    case 129: return dispatch_epi<128, 128, 2, 2, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 512: return dispatch_pp(p, epi, a_kmajor, b_kmajor, splitk, s);                            // ping-pong 256x256
     default: break;
   }
