@@ -164,11 +164,10 @@ __device__ __forceinline__ void stagger_start(int cycles, int bid) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int TM, int TN, int WM, int WN, int EPI>
+template <int TM, int TN, int WM, int WN, int EPI, int PR = (TM >= 2 ? 64 : 32)>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[TM][TN], char* lds, int wave, int lane,
                                               int row0, int col0) {
-  // row0/col0: global coordinates of this wave's tile origin
-  constexpr int PT = TM >= 2 ? 2 : 1;              // MFMA row-tiles per epilogue pass
+  // row0/col0: global coordinates of this wave's tile origin; PR = rows of the wave tile staged through LDS per pass
   if (EPI == 1) {
     // weight-gradient epilogue: fp32 accumulate into C (atomics; C is pre-zeroed or holds the running sum)
     float* C = (float*)p.C;
@@ -187,7 +186,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   } else {
     // activation epilogue: registers -> wave-private fp32 LDS patch (PT*32 rows x WN) -> 8-column strips per lane
     // (16-B bf16 / 2 x 16-B fp32 stores: the store tail is issue-bound per instruction, so wide stores halve it)
-    float* patch = (float*)(lds) + wave * (PT * 32 * WN);
+    float* patch = (float*)(lds) + wave * (PR * WN);
     constexpr int LPR = WN / 8;          // lanes per row
     constexpr int RPI = 64 / LPR;        // rows per iteration
     const int cl = (lane % LPR) * 8;
@@ -202,16 +201,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     }
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ps = 0; ps < TM / PT; ++ps) {
+    for (int ps = 0; ps < WM / PR; ++ps) {
 #pragma unroll
-      for (int i = 0; i < PT; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            int nl = j * 32 + (lane & 31);
-            patch[ml * WN + nl] = acc[ps * PT + i][j][r];
+            const int g8 = i * 4 + (r >> 2);                       // 8-row group of the wave tile this register lives in
+            if (g8 >= ps * (PR / 8) && g8 < (ps + 1) * (PR / 8)) {
+              int ml = g8 * 8 - ps * PR + (r & 3) + 4 * (lane >> 5);
+              int nl = j * 32 + (lane & 31);
+              patch[ml * WN + nl] = acc[i][j][r];
+            }
           }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       // W consecutive columns starting at column offset `co` of this lane's 8-column strip, row m (patch row ml)
@@ -284,9 +286,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
         }
       };
 #pragma unroll 2
-      for (int itr = 0; itr < PT * 32 / RPI; ++itr) {
+      for (int itr = 0; itr < PR / RPI; ++itr) {
         int ml = itr * RPI + lane / LPR;
-        int m = row0 + ps * PT * 32 + ml;
+        int m = row0 + ps * PR + ml;
         if (m < p.M && ncol_ok) {
           if (wide) body(std::integral_constant<int, 8>{}, 0, ml, m);
           else {
@@ -312,8 +314,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPREAD = false>
-__global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmParams p) {
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPREAD = false, int PR = 0, int MINW = 1>
+__global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;      // wave tile
   constexpr int TM = WM / 32, TN = WN / 32;        // 32x32 MFMA tiles per wave
@@ -365,6 +367,43 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmParams p) {
   // NSTAGE-deep LDS ring, one barrier per K tile: iteration `it` waits (counted vmcnt) until its own tile has
   // landed while up to NSTAGE-2 younger tiles stay in flight across the barrier, then refills the slot that was
   // consumed in iteration it-1 with tile it+NSTAGE-1, then computes.
+  constexpr int RA = A_KMAJOR ? BM / (NW * (64 / (BK / 8))) : BK / (NW * (64 / (BM / 8)));   // A LDS-DMA rounds per wave
+  constexpr int RB = B_KMAJOR ? BN / (NW * (64 / (BK / 8))) : BK / (NW * (64 / (BN / 8)));   // B rounds
+  uint32_t voffA[4] = {0u, 0u, 0u, 0u}, voffB[4] = {0u, 0u, 0u, 0u};   // RA, RB <= 4 (fixed size: a dependent-size array here makes hipcc drop the host stubs)
+  static_assert(RA <= 4 && RB <= 4, "voff arrays");
+  const bool hoist = SPREAD && (p.K % BK == 0 || (!A_KMAJOR && !B_KMAJOR));
+  if (SPREAD) {
+#pragma unroll
+    for (int q = 0; q < RA; ++q) {
+      if (A_KMAJOR) {
+        constexpr int CPR = BK / 8, RPI = 64 / CPR;
+        int r = q * (NW * RPI) + wave * RPI + lane / CPR;
+        int c = (lane % CPR) ^ kmajor_swz<BK>(r);
+        voffA[q] = (uint32_t)(((size_t)(tm0 + r) * (size_t)p.lda + (size_t)c * 8) * 2);
+      } else {
+        constexpr int CPR = BM / 8, RPI = 64 / CPR;
+        int r = q * NW * RPI + wave * RPI + lane / CPR;
+        int c = (lane % CPR) ^ kstrided_swz_fwd<BM>(r);
+        int col = tm0 + c * 8;
+        voffA[q] = (col >= p.M) ? 0xFFFFFFF0u : (uint32_t)(((size_t)r * (size_t)p.lda + (size_t)col) * 2);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+      if (B_KMAJOR) {
+        constexpr int CPR = BK / 8, RPI = 64 / CPR;
+        int r = q * (NW * RPI) + wave * RPI + lane / CPR;
+        int c = (lane % CPR) ^ kmajor_swz<BK>(r);
+        voffB[q] = (uint32_t)(((size_t)(tn0 + r) * (size_t)p.ldb + (size_t)c * 8) * 2);
+      } else {
+        constexpr int CPR = BN / 8, RPI = 64 / CPR;
+        int r = q * NW * RPI + wave * RPI + lane / CPR;
+        int c = (lane % CPR) ^ kstrided_swz_fwd<BN>(r);
+        int col = tn0 + c * 8;
+        voffB[q] = (col >= p.N) ? 0xFFFFFFF0u : (uint32_t)(((size_t)r * (size_t)p.ldb + (size_t)col) * 2);
+      }
+    }
+  }
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) stage(s, kt_begin + s);
@@ -400,10 +439,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmParams p) {
       // refill of the other stage is dribbled out between the MFMA groups (3+3+2 of the 8 instructions in steps 0..2,
       // leaving step 3 as landing time) instead of a burst that stalls every wave at the top of the tile.
       constexpr int KS = BK / 16;
-      constexpr int RA = A_KMAJOR ? BM / (NW * (64 / (BK / 8))) : BK / (NW * (64 / (BM / 8)));   // A rounds
-      constexpr int RB = B_KMAJOR ? BN / (NW * (64 / (BK / 8))) : BK / (NW * (64 / (BN / 8)));   // B rounds
       char* fbase = lds + fill * STAGE;
-      const int fk0 = (kt_begin + it + NSTAGE - 1) * BK;
+      const int fkt = kt_begin + it + NSTAGE - 1;
+      const int fk0 = fkt * BK;
+      // K advance lives in the (scalar) buffer descriptor: base += advance, bound -= advance, so the per-lane offsets
+      // (voffA/voffB, computed once before the loop) never change and the bounds check still zero-fills the M / K tails.
+      const size_t advA = A_KMAJOR ? (size_t)fk0 * 2 : (size_t)fk0 * (size_t)p.lda * 2;
+      const size_t advB = B_KMAJOR ? (size_t)fk0 * 2 : (size_t)fk0 * (size_t)p.ldb * 2;
+      __amdgpu_buffer_rsrc_t ra_t = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + advA), 0,
+                                                                      advA < p.a_bytes ? (uint32_t)(p.a_bytes - advA) : 0u, 0x00020000);
+      __amdgpu_buffer_rsrc_t rb_t = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + advB), 0,
+                                                                      advB < p.b_bytes ? (uint32_t)(p.b_bytes - advB) : 0u, 0x00020000);
       auto dma_part = [&](int q) {
         if (!more) return;
         if (q < RA) {
@@ -430,8 +476,24 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmParams p) {
       for (int ks = 0; ks < KS; ++ks) {
         if (ks + 1 < KS) ldf(ks + 1, (ks + 1) & 1);
 #pragma unroll
-        for (int q = 0; q < PER; ++q)
-          if (ks < KS - 1 && ks * PER + q < NPART) dma_part(ks * PER + q);
+        for (int q = 0; q < PER; ++q) {
+          const int part = ks * PER + q;
+          if (ks < KS - 1 && part < NPART) {
+            if (!hoist) dma_part(part);
+            else if (more) {
+              if (part < RA) {
+                constexpr int RPIA = A_KMAJOR ? 64 / (BK / 8) : 64 / (BM / 8);
+                char* dst = fbase + (part * NW * RPIA + wave * RPIA) * (A_KMAJOR ? BK * 2 : BM * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_t, AVT_LDS_PTR(dst), 16, voffA[part < RA ? part : 0], 0, 0, 0);
+              } else {
+                constexpr int RPIB = B_KMAJOR ? 64 / (BK / 8) : 64 / (BN / 8);
+                const int qb = part - RA;
+                char* dst = fbase + A_TILE + (qb * NW * RPIB + wave * RPIB) * (B_KMAJOR ? BK * 2 : BN * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_t, AVT_LDS_PTR(dst), 16, voffB[qb >= 0 && qb < RB ? qb : 0], 0, 0, 0);
+              }
+            }
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -444,7 +506,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmParams p) {
   asm volatile("s_barrier" ::: "memory");   // every wave is done reading the ring before the epilogue reuses it
   if (p.dbg) t_loop = __builtin_readcyclecounter();
 
-  gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
+  gemm_epilogue<TM, TN, WM, WN, EPI, (PR ? PR : (TM >= 2 ? 64 : 32))>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
   if (p.dbg && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     long long t_end = __builtin_readcyclecounter();
@@ -452,39 +514,39 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_kernel(GemmParams p) {
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, int PR = 0>
 constexpr int lds_bytes(int epi) {
   constexpr int ring = NSTAGE * (BM + BN) * BK * 2;
   constexpr int TM = BM / WGM / 32;
-  constexpr int PT = TM >= 2 ? 2 : 1;
-  constexpr int patch = WGM * WGN * PT * 32 * (BN / WGN) * 4;
+  constexpr int PRR = PR ? PR : (TM >= 2 ? 64 : 32);
+  constexpr int patch = WGM * WGN * PRR * (BN / WGN) * 4;
   return (epi == 0 && patch > ring) ? patch : ring;
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool AK, bool BK_, int EPI, bool SPREAD = false>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool AK, bool BK_, int EPI, bool SPREAD = false, int PR = 0, int MINW = 1>
 int launch(const GemmParams& p, hipStream_t s) {
   int grid = p.tiles_m * p.tiles_n * p.splitk;
-  constexpr int smem = lds_bytes<BM, BN, WGM, WGN, BK, NSTAGE>(EPI);
+  constexpr int smem = lds_bytes<BM, BN, WGM, WGN, BK, NSTAGE, PR>(EPI);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI, SPREAD, PR, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI, SPREAD>), dim3(grid), dim3(64 * WGM * WGN), smem, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI, SPREAD, PR, MINW>), dim3(grid), dim3(64 * WGM * WGN), smem, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, int EPI, bool SPREAD = false>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, int EPI, bool SPREAD = false, int PR = 0, int MINW = 1>
 int dispatch_layout(const GemmParams& p, int a_kmajor, int b_kmajor, hipStream_t s) {
-  if (a_kmajor && b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, true, EPI, SPREAD>(p, s);
-  if (a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, false, EPI, SPREAD>(p, s);
-  if (!a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, false, EPI, SPREAD>(p, s);
-  return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, true, EPI, SPREAD>(p, s);
+  if (a_kmajor && b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, true, EPI, SPREAD, PR, MINW>(p, s);
+  if (a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, false, EPI, SPREAD, PR, MINW>(p, s);
+  if (!a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, false, EPI, SPREAD, PR, MINW>(p, s);
+  return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, true, EPI, SPREAD, PR, MINW>(p, s);
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool SPREAD = false>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool SPREAD = false, int PR = 0, int MINW = 1>
 int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
   const int nk = (p.K + BK - 1) / BK;
@@ -499,8 +561,8 @@ int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk,
   }
   if (splitk > nk) splitk = nk;
   p.splitk = splitk;
-  return epi ? dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 1, SPREAD>(p, a_kmajor, b_kmajor, s)
-             : dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 0, SPREAD>(p, a_kmajor, b_kmajor, s);
+  return epi ? dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 1, SPREAD, PR, MINW>(p, a_kmajor, b_kmajor, s)
+             : dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 0, SPREAD, PR, MINW>(p, a_kmajor, b_kmajor, s);
 }
 
 // ---- ping-pong kernel: 256x256 tile, 8 waves = two groups of four, half-K-tile ring ---------------------------
@@ -700,6 +762,140 @@ int dispatch_pp(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
   return launch_pp<false, true, 1>(p, s);
 }
 
+// ---- deep-A kernel: 256x256x64, 8 waves, activation operand 2 tiles ahead -------------------------------------------
+// In the forward / data-gradient GEMMs the A operand (activations, hundreds of MB) streams from HBM while B (weights,
+// a few MB) sits in L2.  The whole 160 KiB LDS is spent asymmetrically: A ring = 3 stages x 32 KB (two K tiles of
+// HBM latency cover), B ring = 2 stages x 32 KB.  Issue order per K tile is B(t+1) then A(t+2), so "all but the RA
+// youngest LDS-DMA instructions" (s_waitcnt vmcnt(RA)) is exactly "tile t+1 has landed".
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
+__global__ __launch_bounds__(512) void gemm_deepa_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, BK = 64, NW = 8, WGN = 4, WM = 128, WN = 64, TM = 4, TN = 2, KS = 4;
+  constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;
+  constexpr int RA = 4, RB = 4;                        // LDS-DMA instructions per wave per A / B tile
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const lds_b = lds + 3 * A_TILE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int split = bid / ntile;
+  const int t = xcd_remap(bid - split * ntile, ntile);
+  const int tm0 = (t / p.tiles_n) * BM;
+  const int tn0 = (t % p.tiles_n) * BN;
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
+  const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
+  const int nk = kt_end - kt_begin;
+
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto a_part = [&](int kt_rel, int q) {
+    if (kt_rel >= nk) return;
+    char* base = lds + (kt_rel % 3) * A_TILE;
+    const int k0 = (kt_begin + kt_rel) * BK;
+    if (A_KMAJOR) stage_kmajor_part<BM, NW, BK>(ra, base, tm0, k0, p.lda, p.K, wave, lane, q);
+    else stage_kstrided_part<BM, NW, BK>(ra, base, tm0, k0, p.lda, p.M, wave, lane, q);
+  };
+  auto b_part = [&](int kt_rel, int q) {
+    if (kt_rel >= nk) return;
+    char* base = lds_b + (kt_rel & 1) * B_TILE;
+    const int k0 = (kt_begin + kt_rel) * BK;
+    if (B_KMAJOR) stage_kmajor_part<BN, NW, BK>(rb, base, tn0, k0, p.ldb, p.K, wave, lane, q);
+    else stage_kstrided_part<BN, NW, BK>(rb, base, tn0, k0, p.ldb, p.N, wave, lane, q);
+  };
+#pragma unroll
+  for (int q = 0; q < RA; ++q) a_part(0, q);
+#pragma unroll
+  for (int q = 0; q < RB; ++q) b_part(0, q);
+#pragma unroll
+  for (int q = 0; q < RA; ++q) a_part(1, q);
+
+  for (int it = 0; it < nk; ++it) {
+    if (it + 1 < nk) wait_vmcnt<RA>(); else wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    const char* la = lds + (it % 3) * A_TILE;
+    const char* lb = lds_b + (it & 1) * B_TILE;
+    bf16x8_t af[2][TM], bfr[2][TN];
+    auto ldf = [&](int ks, int b) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[b][i] = A_KMAJOR ? frag_kmajor<BK>(la, wm * TM + i, ks, lane) : frag_kstrided<BM>(la, wm * TM + i, ks, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bfr[b][j] = B_KMAJOR ? frag_kmajor<BK>(lb, wn * TN + j, ks, lane) : frag_kstrided<BN>(lb, wn * TN + j, ks, lane);
+    };
+    ldf(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) ldf(ks + 1, (ks + 1) & 1);
+      // dribble the 8 refill instructions over k-steps 0..2 (3 + 3 + 2): B(t+1) first, then A(t+2)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int part = ks * 3 + q;
+        if (ks < 3 && part < RA + RB) { if (part < RB) b_part(it + 1, part); else a_part(it + 2, part - RB); }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+    }
+  }
+  asm volatile("s_barrier" ::: "memory");
+  gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
+}
+
+template <bool AK, bool BK_, int EPI>
+int launch_deepa(const GemmParams& p, hipStream_t s) {
+  int grid = p.tiles_m * p.tiles_n * p.splitk;
+  constexpr int smem = 3 * 256 * 64 * 2 + 2 * 256 * 64 * 2;       // 160 KiB: the whole LDS of a CU
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_deepa_kernel<AK, BK_, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_deepa_kernel<AK, BK_, EPI>), dim3(grid), dim3(512), smem, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+int dispatch_deepa(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
+  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
+  const int nk = (p.K + 63) / 64;
+  if (splitk <= 0) {
+    splitk = 1;
+    if (epi == 1) {
+      long tiles = (long)p.tiles_m * p.tiles_n;
+      while (tiles * splitk < 512 && splitk * 2 * 4 <= nk && splitk < 64) splitk *= 2;
+    }
+  }
+  if (splitk > nk) splitk = nk;
+  p.splitk = splitk;
+  if (epi == 0) {
+    if (a_kmajor && b_kmajor) return launch_deepa<true, true, 0>(p, s);
+    if (a_kmajor && !b_kmajor) return launch_deepa<true, false, 0>(p, s);
+    if (!a_kmajor && !b_kmajor) return launch_deepa<false, false, 0>(p, s);
+    return launch_deepa<false, true, 0>(p, s);
+  }
+  if (a_kmajor && b_kmajor) return launch_deepa<true, true, 1>(p, s);
+  if (a_kmajor && !b_kmajor) return launch_deepa<true, false, 1>(p, s);
+  if (!a_kmajor && !b_kmajor) return launch_deepa<false, false, 1>(p, s);
+  return launch_deepa<false, true, 1>(p, s);
+}
+
 }  // namespace
 
 extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,
@@ -752,13 +948,11 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
   switch (bm) {
     case 64:  return dispatch_epi<64, 64, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 128: return dispatch_epi<128, 128, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
-    case 256: return dispatch_epi<256, 256, 2, 4, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
-    case 384: return dispatch_epi<128, 256, 1, 4, 32, 3>(p, epi, a_kmajor, b_kmajor, splitk, s);   // 2 blocks/CU, 3-deep ring
-    case 257: return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);        // spread DMA + pipelined fragments
-    case 129: return dispatch_epi<128, 128, 2, 2, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
+    case 256: return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);        // default big tile: spread DMA + pipelined fragments
+    case 258: return dispatch_deepa(p, epi, a_kmajor, b_kmajor, splitk, s);                          // A ring 3 deep, B ring 2 deep
     case 512: return dispatch_pp(p, epi, a_kmajor, b_kmajor, splitk, s);                            // ping-pong 256x256
     default: break;
   }
-  avt_set_error("avt_gemm_bf16: tile must be 0, 64, 128, 256 or 384 (got %d)", tile);
+  avt_set_error("avt_gemm_bf16: tile must be 0, 64, 128, 256 (default big tile), 258 (deep-A ring) or 512 (ping-pong) (got %d)", tile);
   return -1;
 }
