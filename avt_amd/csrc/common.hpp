@@ -21,7 +21,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {                      // round-
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// two fp32 -> packed bf16x2 in ONE instruction: clang selects gfx950's v_cvt_pk_bf16_f32 (round-to-nearest-even) for the
+// vector fptrunc, and -- unlike inline asm -- keeps track of the MFMA -> VALU wait states of its operands.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 

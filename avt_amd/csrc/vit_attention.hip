@@ -6,8 +6,8 @@
 // the backward recomputes P from the saved log-sum-exp.
 // All products run on v_mfma_f32_16x16x32_bf16.  Scores are produced TRANSPOSED (S^T = K Q^T, keys along
 // accumulator registers, queries along lanes) so that P^T / dS^T are already in the B-operand register layout
-// of the following P V / dS K products; the second operand of those products (V^T, K^T, Q^T, dO^T) is staged
-// into LDS transposed once per workgroup.
+// of the following P V / dS K products; the second operand of those products (V^T, K^T, Q^T, dO^T) is gathered from
+// the row-major LDS tiles with gfx950's transposing ds_read_b64_tr_b16, so nothing is ever transposed in memory.
 //   qkv layout: [frames*S, 3*D] with columns [q | k | v], each head-major (timm reshape(N,S,3,H,hd)).
 #include "common.hpp"
 #include "../../include/avt_hip.h"
@@ -70,6 +70,21 @@ __device__ __forceinline__ bf16x8_t frag_tr(const bf16_t* tr, int TS, int dt, in
   u.h[1] = *(const u32x2_t*)(p + 16);
   return u.v;
 }
+// Same operand as frag_tr but gathered from a swizzled ROW-MAJOR tile with gfx950's transposing LDS read: within a
+// 16-lane group, lane i supplies the address of block row (i>>2), columns 4*(i&3).., and receives column i of the
+// [4 rows][16 cols] block -- i.e. X[32t + 4g + j][dt*16 + i], j = 0..3 (and the same 16 rows further for the upper half).
+__device__ __forceinline__ bf16x8_t frag_tr_rm(const char* rm, int dt, int t, int lane) {
+  const int g = lane >> 4, i16 = lane & 15;
+  const int col = dt * 16 + (i16 & 3) * 4;
+  union { bf16x8_t v; s16x4_t h[2]; } u;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = 32 * t + 16 * h + 4 * g + (i16 >> 2);
+    const char* p = rm + rm_off(r, col >> 3) + (col & 7) * 2;
+    u.h[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+  }
+  return u.v;
+}
 __device__ __forceinline__ bf16x8_t pack_pair(f32x4_t a, f32x4_t b) {
   union { bf16x8_t v; uint32_t w[4]; } u;
   u.w[0] = pack2bf(a[0], a[1]); u.w[1] = pack2bf(a[2], a[3]);
@@ -90,16 +105,15 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
                                                                 float* __restrict__ lse, int S, int H, float scale) {
   constexpr int NP = (NKT + 1) / 2;          // key-tile pairs
   constexpr int KP = NP * 32;                // padded key count
-  constexpr int TS = KP + 8;                 // transposed row stride (elements)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Klds = smem;                         // [NKT*16][64] swizzled
-  bf16_t* Vt = (bf16_t*)(smem + NKT * 16 * 128);   // [64][TS]
+  char* Klds = smem;                         // [KP][64] swizzled row-major
+  char* Vlds = smem + KP * 128;              // [KP][64] swizzled row-major (consumed through transposing reads)
   const int D = H * HD, ld = 3 * D;
   const int frame = blockIdx.x / H, head = blockIdx.x % H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bf16_t* base = qkv + (size_t)frame * S * ld + head * HD;
-  stage_head(base + D, ld, S, Klds, NKT * 16, nullptr, 0, 0, tid, 64 * NKT);
-  stage_head(base + 2 * D, ld, S, nullptr, 0, Vt, TS, KP, tid, 64 * NKT);
+  stage_head(base + D, ld, S, Klds, KP, nullptr, 0, 0, tid, 64 * NKT);
+  stage_head(base + 2 * D, ld, S, Vlds, KP, nullptr, 0, 0, tid, 64 * NKT);
   __syncthreads();
 
   const int q0 = wave * 16, g = lane >> 4;
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   for (int t = 0; t < NP; ++t) {
     bf16x8_t pb = pack_pair(st[2 * t], st[2 * t + 1]);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(frag_tr(Vt, TS, dt, t, lane), pb, o[dt]);
+    for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(frag_tr_rm(Vlds, dt, t, lane), pb, o[dt]);
   }
   const int q = q0 + (lane & 15);
   if (q < S) {
@@ -163,19 +177,19 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
                                                                 bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
                                                                 int S, int H, float scale) {
   constexpr int NP = (NKT + 1) / 2;
-  constexpr int KP = NP * 32;
-  constexpr int TS = KP + 8;
-  constexpr int RM = NKT * 16 * 128;         // bytes of a row-major tile
-  constexpr int TR = 64 * TS * 2;            // bytes of a transposed tile
+  constexpr int KP = NP * 32;                // rows of every LDS tile (zero padded)
+  constexpr int RM = KP * 128;               // bytes of a row-major [KP][64] bf16 tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // phase A: [K rm | V rm | Kt]           phase B: [Q rm | dO rm | Qt | dOt]      tail: lse, Dq (fp32), bias partials
-  char* buf0 = smem;
-  char* buf1 = smem + RM;
-  bf16_t* tr0 = (bf16_t*)(smem + 2 * RM);
-  bf16_t* tr1 = (bf16_t*)(smem + 2 * RM + TR);
-  float* lse_s = (float*)(smem + 2 * RM + 2 * TR);
-  float* dq_s = lse_s + KP;
-  float* bias_s = dq_s + KP;                 // [3*64]
+  // Q, K, V, dO of this (frame, head), all swizzled row-major; operands that a product needs "transposed" are gathered
+  // with ds_read_b64_tr_b16 (frag_tr_rm), so no transposed copy is built.  Zero padding of rows >= S makes every
+  // padded key / query contribute exactly zero to dQ, dK, dV (no masks in the inner loops).
+  char* Qs = smem;
+  char* Ks = smem + RM;
+  char* Vs = smem + 2 * RM;
+  char* dOs = smem + 3 * RM;
+  float* lse_s = (float*)(smem + 4 * RM);
+  float* dq_s = lse_s + KP;                  // D[q] = sum_d dO[q,d] O[q,d]
+  float* bias_s = dq_s + KP;                 // [3*64] column sums of dq | dk | dv
   const int D = H * HD, ld = 3 * D;
   const int frame = blockIdx.x / H, head = blockIdx.x % H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = 64 * NKT;
@@ -189,15 +203,14 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
 
   for (int i = tid; i < KP; i += nthr) lse_s[i] = (i < S) ? lse_g[i] : 0.f;
   for (int i = tid; i < 192; i += nthr) bias_s[i] = 0.f;
-  stage_head(base + D, ld, S, buf0, NKT * 16, tr0, TS, KP, tid, nthr);          // K rm + Kt
-  stage_head(base + 2 * D, ld, S, buf1, NKT * 16, nullptr, 0, 0, tid, nthr);    // V rm
-  __syncthreads();
-
-  // ---------------- phase A: this wave's 16-query strip -> dQ -----------------------------------
+  stage_head(base, ld, S, Qs, KP, nullptr, 0, 0, tid, nthr);
+  stage_head(base + D, ld, S, Ks, KP, nullptr, 0, 0, tid, nthr);
+  stage_head(base + 2 * D, ld, S, Vs, KP, nullptr, 0, 0, tid, nthr);
+  stage_head(dobase, D, S, dOs, KP, nullptr, 0, 0, tid, nthr);
+  // D[q] for this wave's strip: dO rows from LDS would need the barrier first, so read them from global here
   {
     const int q0 = wave * 16, q = q0 + (lane & 15);
-    bf16x8_t bq[2], bdo[2], bo[2];
-    load_strip(base, ld, S, q0, lane, bq);
+    bf16x8_t bdo[2], bo[2];
     load_strip(dobase, D, S, q0, lane, bdo);
     load_strip(obase, D, S, q0, lane, bo);
     float dsum = 0.f;
@@ -206,8 +219,17 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
 #pragma unroll
       for (int e = 0; e < 8; ++e) dsum += (float)bdo[ks][e] * (float)bo[ks][e];
     dsum = gsum(dsum);
-    if (g == 0) dq_s[q] = dsum;              // q < KP always (q0 + 15 < NKT*16 <= KP)
-    const float lq = (q < S) ? lse_s[q] : 0.f;
+    if (g == 0) dq_s[q] = dsum;              // q < NKT*16 <= KP
+  }
+  __syncthreads();
+
+  // ---------------- phase A: this wave's 16-query strip -> dQ ------------------------------------------------------
+  {
+    const int q0 = wave * 16, q = q0 + (lane & 15);
+    bf16x8_t bq[2], bdo[2];                  // B operands: lane (j = q, g) holds X[q][ks*32 + g*8 ..]
+    bq[0] = frag_rm(Qs, wave, 0, lane); bq[1] = frag_rm(Qs, wave, 1, lane);
+    bdo[0] = frag_rm(dOs, wave, 0, lane); bdo[1] = frag_rm(dOs, wave, 1, lane);
+    const float dsum = dq_s[q], lq = lse_s[q];
     f32x4_t acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -220,21 +242,17 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
         dsv[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         if (kt < NKT) {
           f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s = mfma16(frag_rm(buf0, kt, 0, lane), bq[0], s);
-          s = mfma16(frag_rm(buf0, kt, 1, lane), bq[1], s);
-          dp = mfma16(frag_rm(buf1, kt, 0, lane), bdo[0], dp);
-          dp = mfma16(frag_rm(buf1, kt, 1, lane), bdo[1], dp);
+          s = mfma16(frag_rm(Ks, kt, 0, lane), bq[0], s);
+          s = mfma16(frag_rm(Ks, kt, 1, lane), bq[1], s);
+          dp = mfma16(frag_rm(Vs, kt, 0, lane), bdo[0], dp);
+          dp = mfma16(frag_rm(Vs, kt, 1, lane), bdo[1], dp);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int key = kt * 16 + 4 * g + r;
-            float pv = (key < S && q < S) ? __expf(s[r] * scale - lq) : 0.f;
-            dsv[u][r] = pv * (dp[r] - dsum) * scale;
-          }
+          for (int r = 0; r < 4; ++r) dsv[u][r] = __expf(s[r] * scale - lq) * (dp[r] - dsum) * scale;
         }
       }
       bf16x8_t b = pack_pair(dsv[0], dsv[1]);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(frag_tr(tr0, TS, dt, t, lane), b, acc[dt]);
+      for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(frag_tr_rm(Ks, dt, t, lane), b, acc[dt]);
     }
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -251,16 +269,12 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
       }
     }
   }
-  __syncthreads();
-  // ---------------- phase B: this wave's 16-key strip -> dK, dV ---------------------------------
-  stage_head(base, ld, S, buf0, NKT * 16, tr0, TS, KP, tid, nthr);              // Q rm + Qt
-  stage_head(dobase, D, S, buf1, NKT * 16, tr1, TS, KP, tid, nthr);             // dO rm + dOt
-  __syncthreads();
+  // ---------------- phase B: this wave's 16-key strip -> dK, dV (no barrier needed: LDS tiles are read-only) --------
   {
-    const int k0 = wave * 16, key = k0 + (lane & 15);
+    const int key = wave * 16 + (lane & 15);
     bf16x8_t bk[2], bv[2];
-    load_strip(base + D, ld, S, k0, lane, bk);
-    load_strip(base + 2 * D, ld, S, k0, lane, bv);
+    bk[0] = frag_rm(Ks, wave, 0, lane); bk[1] = frag_rm(Ks, wave, 1, lane);
+    bv[0] = frag_rm(Vs, wave, 0, lane); bv[1] = frag_rm(Vs, wave, 1, lane);
     f32x4_t adk[4], adv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -274,16 +288,17 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
         ds2[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         if (qt < NKT) {
           f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s = mfma16(frag_rm(buf0, qt, 0, lane), bk[0], s);
-          s = mfma16(frag_rm(buf0, qt, 1, lane), bk[1], s);
-          dp = mfma16(frag_rm(buf1, qt, 0, lane), bv[0], dp);
-          dp = mfma16(frag_rm(buf1, qt, 1, lane), bv[1], dp);
+          s = mfma16(frag_rm(Qs, qt, 0, lane), bk[0], s);
+          s = mfma16(frag_rm(Qs, qt, 1, lane), bk[1], s);
+          dp = mfma16(frag_rm(dOs, qt, 0, lane), bv[0], dp);
+          dp = mfma16(frag_rm(dOs, qt, 1, lane), bv[1], dp);
+          const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g);
+          const f32x4_t d4 = *(const f32x4_t*)(dq_s + qt * 16 + 4 * g);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            int qq = qt * 16 + 4 * g + r;
-            float p = (qq < S && key < S) ? __expf(s[r] * scale - lse_s[qq]) : 0.f;
+            float p = __expf(s[r] * scale - l4[r]);
             pv2[u][r] = p;
-            ds2[u][r] = p * (dp[r] - dq_s[qq]) * scale;
+            ds2[u][r] = p * (dp[r] - d4[r]) * scale;
           }
         }
       }
@@ -291,8 +306,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
       bf16x8_t bd = pack_pair(ds2[0], ds2[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        adv[dt] = mfma16(frag_tr(tr1, TS, dt, t, lane), bp, adv[dt]);
-        adk[dt] = mfma16(frag_tr(tr0, TS, dt, t, lane), bd, adk[dt]);
+        adv[dt] = mfma16(frag_tr_rm(dOs, dt, t, lane), bp, adv[dt]);
+        adk[dt] = mfma16(frag_tr_rm(Qs, dt, t, lane), bd, adk[dt]);
       }
     }
 #pragma unroll
@@ -321,8 +336,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
 
 int pick_nkt(int S) { int n = (S + 15) / 16; if (n <= 1) return 1; if (n <= 2) return 2; if (n <= 4) return 4; if (n <= 8) return 8; return 13; }
 
-template <int NKT> size_t fwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)NKT * 16 * 128 + 64 * (NP * 32 + 8) * 2; }
-template <int NKT> size_t bwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)2 * NKT * 16 * 128 + 2 * 64 * (NP * 32 + 8) * 2 + (2 * NP * 32 + 192) * 4; }
+template <int NKT> size_t fwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)2 * NP * 32 * 128; }
+template <int NKT> size_t bwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128 + (2 * NP * 32 + 192) * 4; }
 
 template <int NKT>
 int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, int H, float scale, hipStream_t s) {
