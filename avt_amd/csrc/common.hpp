@@ -58,6 +58,23 @@ __device__ __forceinline__ float dgelu_tanh(float x) {
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
 }
 
+// value and derivative together (one erf / one exp shared): the forward epilogue stores GELU'(h) for the backward pass
+__device__ __forceinline__ void gelu_erf_both(float x, float& y, float& dy) {
+  float ax = fabsf(x) * 0.70710678118654752f;
+  float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float ex = __expf(-ax * ax);                                   // = exp(-x^2/2)
+  float poly = fmaf(fmaf(fmaf(fmaf(1.061405429f, t, -1.453152027f), t, 1.421413741f), t, -0.284496736f), t, 0.254829592f) * t;
+  float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * ex, x));
+  y = x * cdf;
+  dy = cdf + x * 0.3989422804014327f * ex;
+}
+__device__ __forceinline__ void gelu_tanh_both(float x, float& y, float& dy) {
+  float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  float t = fast_tanh(u);
+  y = 0.5f * x * (1.0f + t);
+  dy = 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+}
+
 // Counter-based RNG for dropout: keep(seed, idx) is a pure function, so backward recomputes the mask.
 __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
   uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;

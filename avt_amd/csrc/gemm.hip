@@ -17,7 +17,7 @@
 // buffer descriptor's bounds check), XOR-swizzled through the per-lane SOURCE address so the LDS image stays
 // lane-linear, double-buffered with one barrier per K tile, XCD-aware tile order.
 // Epilogue 0 (activations): accumulators are staged through LDS so every lane owns 4 consecutive columns of
-//   one row: + bias, GELU (erf|tanh) with optional pre-activation second output, multiply by GELU'(aux),
+//   one row: + bias, GELU (erf|tanh) with GELU'(pre-activation) as optional second output, multiply by aux,
 //   dropout, + residual (optionally row-periodic), per-column sums (bias gradients), bf16 or fp32 store.
 // Epilogue 1 (weight gradients): fp32 atomic accumulation straight from the accumulator layout (split-K over
 //   the reduction axis fills the chip when the output has few tiles).
@@ -34,7 +34,7 @@ struct GemmParams {
   int M, N, K;
   int lda, ldb, ldc, ldc2, ldres, ldaux;
   int res_period;
-  int act;          // 0 none | 1 gelu_erf | 2 gelu_tanh | 3 *= gelu_erf'(aux) | 4 *= gelu_tanh'(aux)
+  int act;          // 0 none | 1 gelu_erf | 2 gelu_tanh (C2 = derivative) | 3 *= aux
   int out_f32;
   int splitk;
   int tiles_m, tiles_n;
@@ -247,19 +247,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
             *(u32x2_t*)ptr = o;
           }
         };
-        if (p.act >= 3) {
+        if (p.act == 3) {                       // backward of an activation: multiply by the saved derivative
           float h[W];
           load_bf(p.aux + (size_t)m * p.ldaux + nn, h);
 #pragma unroll
-          for (int e = 0; e < W; ++e) v[e] *= (p.act == 3) ? dgelu_erf(h[e]) : dgelu_tanh(h[e]);
+          for (int e = 0; e < W; ++e) v[e] *= h[e];
         }
-        if (p.C2) store_bf(p.C2 + (size_t)m * p.ldc2 + nn, v);
-        if (p.act == 1) {
+        if (p.act == 1 || p.act == 2) {         // GELU; the optional second output is GELU'(pre-activation) for backward
+          float d[W];
 #pragma unroll
-          for (int e = 0; e < W; ++e) v[e] = gelu_erf(v[e]);
-        } else if (p.act == 2) {
-#pragma unroll
-          for (int e = 0; e < W; ++e) v[e] = gelu_tanh(v[e]);
+          for (int e = 0; e < W; ++e) {
+            if (p.act == 1) gelu_erf_both(v[e], v[e], d[e]); else gelu_tanh_both(v[e], v[e], d[e]);
+          }
+          if (p.C2) store_bf(p.C2 + (size_t)m * p.ldc2 + nn, d);
+        } else if (p.C2) {
+          store_bf(p.C2 + (size_t)m * p.ldc2 + nn, v);
         }
         if (p.drop_thresh) {
 #pragma unroll
@@ -514,6 +516,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   }
 }
 
+// Split-K factor for the accumulate (weight-gradient) epilogue: one workgroup per CU, so pick the factor whose block count
+// best fills whole rounds of the 256 CUs (576 blocks = 2.25 rounds wastes a quarter of the chip; 504 = 1.97 rounds does
+// not), keeping at least `kmin` K tiles per split.
+static int pick_splitk(long tiles, int nk, int blocks_per_cu, int kmin) {
+  const long slots = 256L * blocks_per_cu;
+  int best = 1; double best_score = -1.0;
+  int smax = nk / kmin; if (smax < 1) smax = 1; if (smax > 96) smax = 96;
+  for (int s = 1; s <= smax; ++s) {
+    long blocks = tiles * s;
+    long rounds = (blocks + slots - 1) / slots;
+    double eff = (double)blocks / (double)(rounds * slots);
+    double score = eff - 0.004 * s;            // prefer fewer splits (less atomic traffic) at equal fill
+    if (blocks < slots / 2) score -= 0.5;      // never leave more than half the chip idle
+    if (score > best_score) { best_score = score; best = s; }
+  }
+  return best;
+}
+
 template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, int PR = 0>
 constexpr int lds_bytes(int epi) {
   constexpr int ring = NSTAGE * (BM + BN) * BK * 2;
@@ -552,12 +572,7 @@ int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk,
   const int nk = (p.K + BK - 1) / BK;
   if (splitk <= 0) {                 // auto: about two blocks' worth of work per CU slot
     splitk = 1;
-    if (epi == 1) {
-      long tiles = (long)p.tiles_m * p.tiles_n;
-      long target = (BM * BN >= 256 * 256) ? 512 : 768;
-      int kmin = 256 / BK;          // at least 256 reduction steps per split
-      while (tiles * splitk < target && splitk * 2 * kmin <= nk && splitk < 64) splitk *= 2;
-    }
+    if (epi == 1) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk, (BM * BN >= 256 * 256) ? 1 : 2, 512 / BK);
   }
   if (splitk > nk) splitk = nk;
   p.splitk = splitk;
@@ -732,10 +747,7 @@ int dispatch_pp(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
   const int nk = (p.K + 63) / 64;
   if (splitk <= 0) {
     splitk = 1;
-    if (epi == 1) {
-      long tiles = (long)p.tiles_m * p.tiles_n;
-      while (tiles * splitk < 512 && splitk * 2 * 4 <= nk && splitk < 64) splitk *= 2;
-    }
+    if (epi == 1) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk, 1, 8);
   }
   if (splitk > nk) splitk = nk;
   p.splitk = splitk;
@@ -877,10 +889,7 @@ int dispatch_deepa(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int split
   const int nk = (p.K + 63) / 64;
   if (splitk <= 0) {
     splitk = 1;
-    if (epi == 1) {
-      long tiles = (long)p.tiles_m * p.tiles_n;
-      while (tiles * splitk < 512 && splitk * 2 * 4 <= nk && splitk < 64) splitk *= 2;
-    }
+    if (epi == 1) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk, 1, 8);
   }
   if (splitk > nk) splitk = nk;
   p.splitk = splitk;
@@ -910,7 +919,7 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
   AVT_CHECK(lda % 8 == 0 && ldb % 8 == 0, "avt_gemm_bf16: lda/ldb must be multiples of 8 (got %d, %d)", lda, ldb);
   AVT_CHECK(K % 8 == 0 || (!a_kmajor && !b_kmajor), "avt_gemm_bf16: K must be a multiple of 8 for k-major operands (K=%d)", K);
   AVT_CHECK(out_mode >= 0 && out_mode <= 2, "avt_gemm_bf16: out_mode must be 0 (bf16), 1 (fp32) or 2 (fp32 atomic accumulate)");
-  AVT_CHECK(act >= 0 && act <= 4, "avt_gemm_bf16: bad act %d", act);
+  AVT_CHECK(act >= 0 && act <= 3, "avt_gemm_bf16: bad act %d", act);
   AVT_CHECK(act < 3 || aux, "avt_gemm_bf16: act %d needs aux", act);
   AVT_CHECK(drop_p >= 0.f && drop_p < 1.f, "avt_gemm_bf16: bad dropout p");
   GemmParams p{};

@@ -216,7 +216,7 @@ def _head_backward(m: AVTh, arena, saved, ddec):
         dy = ops.dropout(dh, pr, s0 + 3) if pr > 0 else dh
         ops.colsum(dy, gr(blk.mlp.c_proj.bias))
         ops.conv1d_wgrad(a, dy, gr(blk.mlp.c_proj.weight))
-        dpre = ops.conv1d_dgrad(dy, sh(blk.mlp.c_proj.weight), act=ops.ACT_DGELU_TANH, aux=pre, colsum=gr(blk.mlp.c_fc.bias))
+        dpre = ops.conv1d_dgrad(dy, sh(blk.mlp.c_proj.weight), act=ops.ACT_MUL_AUX, aux=pre, colsum=gr(blk.mlp.c_fc.bias))
         ops.conv1d_wgrad(l2, dpre, gr(blk.mlp.c_fc.weight))
         dl2 = ops.conv1d_dgrad(dpre, sh(blk.mlp.c_fc.weight))
         dh1 = ops.layernorm_bwd(dl2, h1, m2, r2, blk.ln_2.weight, gr(blk.ln_2.weight), gr(blk.ln_2.bias), dres=dh)

@@ -125,7 +125,7 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
         saved['blocks'][i] = None
         # x2 = act @ W2^T + b2 + x1          (db2 was accumulated by the producer of dx)
         ops.linear_wgrad(dx, act, gr(blk.mlp.fc2.weight))
-        dh = ops.linear_dgrad(dx, sh(blk.mlp.fc2.weight), act=ops.ACT_DGELU_ERF, aux=pre, colsum=gr(blk.mlp.fc1.bias))
+        dh = ops.linear_dgrad(dx, sh(blk.mlp.fc2.weight), act=ops.ACT_MUL_AUX, aux=pre, colsum=gr(blk.mlp.fc1.bias))
         del act, pre
         ops.linear_wgrad(dh, ln2, gr(blk.mlp.fc1.weight))
         dln2 = ops.linear_dgrad(dh, sh(blk.mlp.fc1.weight))

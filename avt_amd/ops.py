@@ -8,7 +8,7 @@ import torch
 from . import lib as _lib
 
 BF16 = torch.bfloat16
-ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_DGELU_ERF, ACT_DGELU_TANH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_MUL_AUX = 0, 1, 2, 3       # with c2=..., GELU stores its derivative there
 OUT_BF16, OUT_F32, OUT_ACCUM_F32 = 0, 1, 2
 
 

@@ -41,8 +41,9 @@ int avt_abi_version(void);
  *   rows, AVT-h encoder/decoder (models/future_prediction.py:80-81,163,190), GPT-2 c_attn/c_proj/c_fc [hf]
  *   (models/future_prediction.py:178-181), classifier (models/base_model.py:203-216, 222-238).
  * out_mode 0: bf16 C, 1: fp32 C, with the fused epilogue, applied in this order:
- *     v = acc + bias[n];  act 3|4: v *= gelu_erf'|gelu_tanh'(aux[m,n]);  C2[m,n] = v (optional pre-activation copy);
- *     act 1|2: v = gelu_erf|gelu_tanh(v);  dropout(drop_p, drop_seed, element index m*N+n);
+ *     v = acc + bias[n];  act 3: v *= aux[m,n] (backward of an activation whose derivative was saved);
+ *     act 1|2: C2[m,n] = gelu_erf'|gelu_tanh'(v) (optional, saved for backward), v = gelu_erf|gelu_tanh(v);
+ *     act 0 with C2: C2[m,n] = v;  dropout(drop_p, drop_seed, element index m*N+n);
  *     v += res[(res_period ? m % res_period : m), n];  colsum[n] += v (fp32 atomics);  C[m,n] = v
  * out_mode 2: C (fp32) += acc with atomics, no epilogue; splitk > 1 splits the reduction over workgroups
  *             (splitk <= 0 picks a factor that fills the chip).  Used for weight gradients.
