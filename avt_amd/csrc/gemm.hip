@@ -316,7 +316,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPREAD = false, int PR = 0, int MINW = 1>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool A_KMAJOR, bool B_KMAJOR, int EPI, bool SPREAD = false, int PR = 0, int MINW = 1, int NWL = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p) {
   constexpr int NW = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;      // wave tile
@@ -369,22 +369,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   // NSTAGE-deep LDS ring, one barrier per K tile: iteration `it` waits (counted vmcnt) until its own tile has
   // landed while up to NSTAGE-2 younger tiles stay in flight across the barrier, then refills the slot that was
   // consumed in iteration it-1 with tile it+NSTAGE-1, then computes.
-  constexpr int RA = A_KMAJOR ? BM / (NW * (64 / (BK / 8))) : BK / (NW * (64 / (BM / 8)));   // A LDS-DMA rounds per wave
-  constexpr int RB = B_KMAJOR ? BN / (NW * (64 / (BK / 8))) : BK / (NW * (64 / (BN / 8)));   // B rounds
-  uint32_t voffA[4] = {0u, 0u, 0u, 0u}, voffB[4] = {0u, 0u, 0u, 0u};   // RA, RB <= 4 (fixed size: a dependent-size array here makes hipcc drop the host stubs)
-  static_assert(RA <= 4 && RB <= 4, "voff arrays");
-  const bool hoist = SPREAD && (p.K % BK == 0 || (!A_KMAJOR && !B_KMAJOR));
+  // NL_W waves issue the in-loop LDS-DMA (all of them by default; with NWL = 4 only waves 0-3 -- one per SIMD -- so
+  // that on every SIMD one wave is never stalled in the texture-address queue while its partner feeds the MFMA pipe)
+  constexpr int NL_W = NWL ? NWL : NW;
+  constexpr int RA = A_KMAJOR ? BM / (NL_W * (64 / (BK / 8))) : BK / (NL_W * (64 / (BM / 8)));   // A LDS-DMA rounds per loading wave
+  constexpr int RB = B_KMAJOR ? BN / (NL_W * (64 / (BK / 8))) : BK / (NL_W * (64 / (BN / 8)));   // B rounds
+  uint32_t voffA[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, voffB[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};   // fixed size: a dependent-size array makes hipcc drop the host stubs
+  static_assert(RA <= 8 && RB <= 8, "voff arrays");
+  const bool loader = wave < NL_W;
+  const bool hoist = SPREAD && (NWL != 0 || p.K % BK == 0 || (!A_KMAJOR && !B_KMAJOR));   // NWL variants are only dispatched when K % BK == 0
   if (SPREAD) {
 #pragma unroll
     for (int q = 0; q < RA; ++q) {
       if (A_KMAJOR) {
         constexpr int CPR = BK / 8, RPI = 64 / CPR;
-        int r = q * (NW * RPI) + wave * RPI + lane / CPR;
+        int r = q * (NL_W * RPI) + wave * RPI + lane / CPR;
         int c = (lane % CPR) ^ kmajor_swz<BK>(r);
         voffA[q] = (uint32_t)(((size_t)(tm0 + r) * (size_t)p.lda + (size_t)c * 8) * 2);
       } else {
         constexpr int CPR = BM / 8, RPI = 64 / CPR;
-        int r = q * NW * RPI + wave * RPI + lane / CPR;
+        int r = q * NL_W * RPI + wave * RPI + lane / CPR;
         int c = (lane % CPR) ^ kstrided_swz_fwd<BM>(r);
         int col = tm0 + c * 8;
         voffA[q] = (col >= p.M) ? 0xFFFFFFF0u : (uint32_t)(((size_t)r * (size_t)p.lda + (size_t)col) * 2);
@@ -394,12 +398,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
     for (int q = 0; q < RB; ++q) {
       if (B_KMAJOR) {
         constexpr int CPR = BK / 8, RPI = 64 / CPR;
-        int r = q * (NW * RPI) + wave * RPI + lane / CPR;
+        int r = q * (NL_W * RPI) + wave * RPI + lane / CPR;
         int c = (lane % CPR) ^ kmajor_swz<BK>(r);
         voffB[q] = (uint32_t)(((size_t)(tn0 + r) * (size_t)p.ldb + (size_t)c * 8) * 2);
       } else {
         constexpr int CPR = BN / 8, RPI = 64 / CPR;
-        int r = q * NW * RPI + wave * RPI + lane / CPR;
+        int r = q * NL_W * RPI + wave * RPI + lane / CPR;
         int c = (lane % CPR) ^ kstrided_swz_fwd<BN>(r);
         int col = tn0 + c * 8;
         voffB[q] = (col >= p.N) ? 0xFFFFFFF0u : (uint32_t)(((size_t)r * (size_t)p.ldb + (size_t)col) * 2);
@@ -482,15 +486,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
           const int part = ks * PER + q;
           if (ks < KS - 1 && part < NPART) {
             if (!hoist) dma_part(part);
-            else if (more) {
+            else if (more && loader) {
               if (part < RA) {
                 constexpr int RPIA = A_KMAJOR ? 64 / (BK / 8) : 64 / (BM / 8);
-                char* dst = fbase + (part * NW * RPIA + wave * RPIA) * (A_KMAJOR ? BK * 2 : BM * 2);
+                char* dst = fbase + (part * NL_W * RPIA + wave * RPIA) * (A_KMAJOR ? BK * 2 : BM * 2);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_t, AVT_LDS_PTR(dst), 16, voffA[part < RA ? part : 0], 0, 0, 0);
               } else {
                 constexpr int RPIB = B_KMAJOR ? 64 / (BK / 8) : 64 / (BN / 8);
                 const int qb = part - RA;
-                char* dst = fbase + A_TILE + (qb * NW * RPIB + wave * RPIB) * (B_KMAJOR ? BK * 2 : BN * 2);
+                char* dst = fbase + A_TILE + (qb * NL_W * RPIB + wave * RPIB) * (B_KMAJOR ? BK * 2 : BN * 2);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_t, AVT_LDS_PTR(dst), 16, voffB[qb >= 0 && qb < RB ? qb : 0], 0, 0, 0);
               }
             }
@@ -543,30 +547,30 @@ constexpr int lds_bytes(int epi) {
   return (epi == 0 && patch > ring) ? patch : ring;
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool AK, bool BK_, int EPI, bool SPREAD = false, int PR = 0, int MINW = 1>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool AK, bool BK_, int EPI, bool SPREAD = false, int PR = 0, int MINW = 1, int NWL = 0>
 int launch(const GemmParams& p, hipStream_t s) {
   int grid = p.tiles_m * p.tiles_n * p.splitk;
   constexpr int smem = lds_bytes<BM, BN, WGM, WGN, BK, NSTAGE, PR>(EPI);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI, SPREAD, PR, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI, SPREAD, PR, MINW, NWL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI, SPREAD, PR, MINW>), dim3(grid), dim3(64 * WGM * WGN), smem, s, p);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, BK, NSTAGE, AK, BK_, EPI, SPREAD, PR, MINW, NWL>), dim3(grid), dim3(64 * WGM * WGN), smem, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, int EPI, bool SPREAD = false, int PR = 0, int MINW = 1>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, int EPI, bool SPREAD = false, int PR = 0, int MINW = 1, int NWL = 0>
 int dispatch_layout(const GemmParams& p, int a_kmajor, int b_kmajor, hipStream_t s) {
-  if (a_kmajor && b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, true, EPI, SPREAD, PR, MINW>(p, s);
-  if (a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, false, EPI, SPREAD, PR, MINW>(p, s);
-  if (!a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, false, EPI, SPREAD, PR, MINW>(p, s);
-  return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, true, EPI, SPREAD, PR, MINW>(p, s);
+  if (a_kmajor && b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, true, EPI, SPREAD, PR, MINW, NWL>(p, s);
+  if (a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, true, false, EPI, SPREAD, PR, MINW, NWL>(p, s);
+  if (!a_kmajor && !b_kmajor) return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, false, EPI, SPREAD, PR, MINW, NWL>(p, s);
+  return launch<BM, BN, WGM, WGN, BK, NSTAGE, false, true, EPI, SPREAD, PR, MINW, NWL>(p, s);
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool SPREAD = false, int PR = 0, int MINW = 1>
+template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool SPREAD = false, int PR = 0, int MINW = 1, int NWL = 0>
 int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
   const int nk = (p.K + BK - 1) / BK;
@@ -576,8 +580,8 @@ int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk,
   }
   if (splitk > nk) splitk = nk;
   p.splitk = splitk;
-  return epi ? dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 1, SPREAD, PR, MINW>(p, a_kmajor, b_kmajor, s)
-             : dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 0, SPREAD, PR, MINW>(p, a_kmajor, b_kmajor, s);
+  return epi ? dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 1, SPREAD, PR, MINW, NWL>(p, a_kmajor, b_kmajor, s)
+             : dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 0, SPREAD, PR, MINW, NWL>(p, a_kmajor, b_kmajor, s);
 }
 
 // ---- ping-pong kernel: 256x256 tile, 8 waves = two groups of four, half-K-tile ring ---------------------------
@@ -957,7 +961,10 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
   switch (bm) {
     case 64:  return dispatch_epi<64, 64, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 128: return dispatch_epi<128, 128, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
-    case 256: return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);        // default big tile: spread DMA + pipelined fragments
+    case 256:                                                                                     // default big tile: dribbled LDS-DMA issued by 4 loader waves
+      if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_epi<256, 256, 2, 4, 64, 2, true, 0, 1, 4>(p, epi, a_kmajor, b_kmajor, splitk, s);
+      return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
+    case 2568: return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);       // all 8 waves issue LDS-DMA
     case 258: return dispatch_deepa(p, epi, a_kmajor, b_kmajor, splitk, s);                          // A ring 3 deep, B ring 2 deep
     case 512: return dispatch_pp(p, epi, a_kmajor, b_kmajor, splitk, s);                            // ping-pong 256x256
     default: break;

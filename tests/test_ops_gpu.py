@@ -49,7 +49,7 @@ def test_gemm_plain(ops, M, N, K, layout):
         out = ops.gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=False, out_mode=ops.OUT_F32)
     torch.cuda.synchronize()
     assert relerr(out, ref) < 2e-3, relerr(out, ref)
-    for tile in (64, 128, 256, 512, 258):
+    for tile in (64, 128, 256, 512, 258, 2568):
         o2 = ops.gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=(layout == 'NT'), out_mode=ops.OUT_BF16, tile=tile)
         torch.cuda.synchronize()
         assert relerr(o2, ref) < 1e-2, (tile, relerr(o2, ref))
@@ -61,7 +61,7 @@ def test_gemm_tn_accumulate(ops, M, P, Q):
     """weight-gradient form: C[P,Q] += A[M,P]^T B[M,Q] (fp32 atomics, split-K); run twice -> 2x; tol 2e-3."""
     a, b = rnd((M, P), 1.0, 3), rnd((M, Q), 1.0, 4)
     ref = a.float().t() @ b.float()
-    for splitk, tile in ((0, 0), (1, 128), (3, 64), (2, 256), (0, 512), (3, 512), (3, 258)):
+    for splitk, tile in ((0, 0), (1, 128), (3, 64), (2, 256), (0, 512), (3, 512), (3, 258), (0, 2568)):
         c = torch.zeros((P, Q), device='cuda', dtype=torch.float32)
         ops.gemm(a, b, P, Q, M, a_kmajor=False, b_kmajor=False, out=c, out_mode=ops.OUT_ACCUM_F32, splitk=splitk, tile=tile)
         ops.gemm(a, b, P, Q, M, a_kmajor=False, b_kmajor=False, out=c, out_mode=ops.OUT_ACCUM_F32, splitk=splitk, tile=tile)
@@ -100,7 +100,7 @@ def test_gemm_epilogue_bias_act_res(ops, act):
     ref = post + res.float()
     c2 = torch.empty((M, N), device='cuda', dtype=torch.bfloat16)
     cs = torch.zeros(N, device='cuda', dtype=torch.float32)
-    for tile in (0, 256, 512, 258):
+    for tile in (0, 256, 512, 258, 2568):
         cs.zero_()
         out = ops.gemm(a, b, M, N, K, bias=bias, act=act, c2=c2, res=res, colsum=cs, tile=tile)
         torch.cuda.synchronize()
