@@ -9,6 +9,7 @@
 // of the following P V / dS K products; the second operand of those products (V^T, K^T, Q^T, dO^T) is gathered from
 // the row-major LDS tiles with gfx950's transposing ds_read_b64_tr_b16, so nothing is ever transposed in memory.
 //   qkv layout: [frames*S, 3*D] with columns [q | k | v], each head-major (timm reshape(N,S,3,H,hd)).
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/avt_hip.h"
 
@@ -41,6 +42,22 @@ __device__ __forceinline__ void stage_head(const bf16_t* __restrict__ src, int l
         tr[(c * 8 + 2 * e + 1) * TS + r] = (bf16_t)(w[e] >> 16);
       }
     }
+  }
+}
+
+
+// Asynchronous variant for the row-major tiles: LDS-DMA (buffer_load ... lds, 16 B per lane, 8 rows x 128 B per wave
+// instruction).  The LDS image is lane-linear, so the bank swizzle is applied to the SOURCE chunk index; rows >= S get an
+// out-of-range offset and arrive as zeros.  All requests of a workgroup are in flight together; the caller waits once.
+__device__ __forceinline__ void stage_head_dma(const bf16_t* src, int ld, int S, char* rm, int RP, int wave, int nwaves, int lane) {
+  __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7FFFFFF0u, 0x00020000);
+  for (int j = wave; j < RP / 8; j += nwaves) {
+    const int r = j * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    uint32_t off = (uint32_t)(((size_t)r * (size_t)ld + (size_t)c * 8) * 2);
+    if (r >= S) off = 0xFFFFFFF0u;
+    char* dst = rm + __builtin_amdgcn_readfirstlane(j) * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(dst), 16, off, 0, 0, 0);
   }
 }
 
@@ -112,13 +129,14 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   const int frame = blockIdx.x / H, head = blockIdx.x % H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bf16_t* base = qkv + (size_t)frame * S * ld + head * HD;
-  stage_head(base + D, ld, S, Klds, KP, nullptr, 0, 0, tid, 64 * NKT);
-  stage_head(base + 2 * D, ld, S, Vlds, KP, nullptr, 0, 0, tid, 64 * NKT);
-  __syncthreads();
-
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  stage_head_dma(base + D, ld, S, Klds, KP, wv, NKT, lane);
+  stage_head_dma(base + 2 * D, ld, S, Vlds, KP, wv, NKT, lane);
   const int q0 = wave * 16, g = lane >> 4;
   bf16x8_t bq[2];
   load_strip(base, ld, S, q0, lane, bq);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   f32x4_t st[2 * NP];
 #pragma unroll
   for (int kt = 0; kt < 2 * NP; ++kt) st[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -138,13 +156,14 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   }
   mx = gmax(mx);
   const float sl = scale * LOG2E;
+  const float mxs = mx * sl;
   float sum = 0.f;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       int key = kt * 16 + 4 * g + r;
-      float pv = (key < S) ? exp2f((st[kt][r] - mx) * sl) : 0.f;
+      float pv = (key < S) ? __builtin_amdgcn_exp2f(fmaf(st[kt][r], sl, -mxs)) : 0.f;
       st[kt][r] = pv;
       sum += pv;
     }
@@ -175,7 +194,8 @@ template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                 const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                 bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
-                                                                int S, int H, float scale) {
+                                                                int S, int H, float scale, long long* dbg) {
+  long long tc0 = dbg ? __builtin_readcyclecounter() : 0, tc1 = 0, tc2 = 0;
   constexpr int NP = (NKT + 1) / 2;
   constexpr int KP = NP * 32;                // rows of every LDS tile (zero padded)
   constexpr int RM = KP * 128;               // bytes of a row-major [KP][64] bf16 tile
@@ -201,12 +221,13 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
   bf16_t* dbase = dqkv + row0 * ld + head * HD;
   const float* lse_g = lse + ((size_t)frame * H + head) * S;
 
-  for (int i = tid; i < KP; i += nthr) lse_s[i] = (i < S) ? lse_g[i] : 0.f;
+  for (int i = tid; i < KP; i += nthr) lse_s[i] = (i < S) ? lse_g[i] * LOG2E : 0.f;      // stored pre-multiplied by log2(e)
   for (int i = tid; i < 192; i += nthr) bias_s[i] = 0.f;
-  stage_head(base, ld, S, Qs, KP, nullptr, 0, 0, tid, nthr);
-  stage_head(base + D, ld, S, Ks, KP, nullptr, 0, 0, tid, nthr);
-  stage_head(base + 2 * D, ld, S, Vs, KP, nullptr, 0, 0, tid, nthr);
-  stage_head(dobase, D, S, dOs, KP, nullptr, 0, 0, tid, nthr);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  stage_head_dma(base, ld, S, Qs, KP, wv, NKT, lane);
+  stage_head_dma(base + D, ld, S, Ks, KP, wv, NKT, lane);
+  stage_head_dma(base + 2 * D, ld, S, Vs, KP, wv, NKT, lane);
+  stage_head_dma(dobase, D, S, dOs, KP, wv, NKT, lane);
   // D[q] for this wave's strip: dO rows from LDS would need the barrier first, so read them from global here
   {
     const int q0 = wave * 16, q = q0 + (lane & 15);
@@ -219,9 +240,11 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
 #pragma unroll
       for (int e = 0; e < 8; ++e) dsum += (float)bdo[ks][e] * (float)bo[ks][e];
     dsum = gsum(dsum);
-    if (g == 0) dq_s[q] = dsum;              // q < NKT*16 <= KP
+    if (g == 0) dq_s[q] = dsum * scale;      // stored pre-multiplied by `scale`; q < NKT*16 <= KP
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (dbg) tc1 = __builtin_readcyclecounter();
 
   // ---------------- phase A: this wave's 16-query strip -> dQ ------------------------------------------------------
   {
@@ -229,7 +252,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
     bf16x8_t bq[2], bdo[2];                  // B operands: lane (j = q, g) holds X[q][ks*32 + g*8 ..]
     bq[0] = frag_rm(Qs, wave, 0, lane); bq[1] = frag_rm(Qs, wave, 1, lane);
     bdo[0] = frag_rm(dOs, wave, 0, lane); bdo[1] = frag_rm(dOs, wave, 1, lane);
-    const float dsum = dq_s[q], lq = lse_s[q];
+    const float sl = scale * LOG2E;
+    const float dss = dq_s[q], lq2 = lse_s[q];          // folded constants: p = exp2(s*sl - lq2), ds = p*(dp*scale - dss)
     f32x4_t acc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -247,7 +271,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
           dp = mfma16(frag_rm(Vs, kt, 0, lane), bdo[0], dp);
           dp = mfma16(frag_rm(Vs, kt, 1, lane), bdo[1], dp);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dsv[u][r] = __expf(s[r] * scale - lq) * (dp[r] - dsum) * scale;
+          for (int r = 0; r < 4; ++r) dsv[u][r] = __builtin_amdgcn_exp2f(fmaf(s[r], sl, -lq2)) * fmaf(dp[r], scale, -dss);
         }
       }
       bf16x8_t b = pack_pair(dsv[0], dsv[1]);
@@ -269,9 +293,11 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
       }
     }
   }
+  if (dbg) tc2 = __builtin_readcyclecounter();
   // ---------------- phase B: this wave's 16-key strip -> dK, dV (no barrier needed: LDS tiles are read-only) --------
   {
     const int key = wave * 16 + (lane & 15);
+    const float slb = scale * LOG2E;
     bf16x8_t bk[2], bv[2];
     bk[0] = frag_rm(Ks, wave, 0, lane); bk[1] = frag_rm(Ks, wave, 1, lane);
     bv[0] = frag_rm(Vs, wave, 0, lane); bv[1] = frag_rm(Vs, wave, 1, lane);
@@ -292,13 +318,13 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
           s = mfma16(frag_rm(Qs, qt, 1, lane), bk[1], s);
           dp = mfma16(frag_rm(dOs, qt, 0, lane), bv[0], dp);
           dp = mfma16(frag_rm(dOs, qt, 1, lane), bv[1], dp);
-          const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g);
-          const f32x4_t d4 = *(const f32x4_t*)(dq_s + qt * 16 + 4 * g);
+          const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g);      // pre-scaled by log2(e)
+          const f32x4_t d4 = *(const f32x4_t*)(dq_s + qt * 16 + 4 * g);       // pre-scaled by `scale`
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float p = __expf(s[r] * scale - l4[r]);
+            float p = __builtin_amdgcn_exp2f(fmaf(s[r], slb, -l4[r]));
             pv2[u][r] = p;
-            ds2[u][r] = p * (dp[r] - d4[r]) * scale;
+            ds2[u][r] = p * fmaf(dp[r], scale, -d4[r]);
           }
         }
       }
@@ -332,6 +358,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
     __syncthreads();
     for (int i = tid; i < 192; i += nthr) unsafeAtomicAdd(&dbias[(i >> 6) * D + head * HD + (i & 63)], bias_s[i]);
   }
+  if (dbg && lane == 0) {
+    long long* d = dbg + ((size_t)blockIdx.x * 16 + wave) * 4;
+    d[0] = tc1 - tc0; d[1] = tc2 - tc1; d[2] = __builtin_readcyclecounter() - tc2;
+  }
 }
 
 int pick_nkt(int S) { int n = (S + 15) / 16; if (n <= 1) return 1; if (n <= 2) return 2; if (n <= 4) return 4; if (n <= 8) return 8; return 13; }
@@ -353,7 +383,9 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
   size_t sm = bwd_smem<NKT>();
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
-  hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT>), dim3(frames * H), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, S, H, scale);
+  static const char* e = getenv("AVT_ATTN_DBG_PTR");
+  long long* dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr;
+  hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT>), dim3(frames * H), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, S, H, scale, dbg);
   return 0;
 }
 
