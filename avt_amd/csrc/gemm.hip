@@ -164,6 +164,154 @@ __device__ __forceinline__ void stagger_start(int cycles, int bid) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// ---- activation epilogue, factored so that it can run in one go or be dribbled out under the next tile's K loop ------
+// Per-lane state: the lane owns 8 consecutive output columns (n .. n+7) of every row it touches.
+struct EpiLane {
+  int n, cl; bool ncol_ok, wide;
+  float bias8[8]; float csum[8];
+};
+// reload the bias strip (used by the dribbled epilogue, which cannot afford to keep it in registers across a K loop)
+__device__ __forceinline__ void epi_load_bias(EpiLane& e, const GemmParams& p) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) e.bias8[q] = 0.f;
+  if (p.bias && e.ncol_ok) {
+    f32x4_t b = *(const f32x4_t*)(p.bias + e.n);
+    e.bias8[0] = b[0]; e.bias8[1] = b[1]; e.bias8[2] = b[2]; e.bias8[3] = b[3];
+    if (e.n + 4 < p.N) { f32x4_t c = *(const f32x4_t*)(p.bias + e.n + 4); e.bias8[4] = c[0]; e.bias8[5] = c[1]; e.bias8[6] = c[2]; e.bias8[7] = c[3]; }
+  }
+}
+template <int WN>
+__device__ __forceinline__ void epi_setup(EpiLane& e, const GemmParams& p, int lane, int col0) {
+  constexpr int LPR = WN / 8;
+  e.cl = (lane % LPR) * 8;
+  e.n = col0 + e.cl;
+  e.ncol_ok = e.n < p.N;                 // N % 4 == 0 is a host-checked precondition
+  e.wide = p.wide_ok && (e.n + 8 <= p.N);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { e.bias8[q] = 0.f; e.csum[q] = 0.f; }
+  if (p.bias && e.ncol_ok) {
+    f32x4_t b = *(const f32x4_t*)(p.bias + e.n);
+    e.bias8[0] = b[0]; e.bias8[1] = b[1]; e.bias8[2] = b[2]; e.bias8[3] = b[3];
+    if (e.n + 4 < p.N) { f32x4_t c = *(const f32x4_t*)(p.bias + e.n + 4); e.bias8[4] = c[0]; e.bias8[5] = c[1]; e.bias8[6] = c[2]; e.bias8[7] = c[3]; }
+  }
+}
+// W (8 or 4) consecutive columns starting at column offset `co` of the lane's strip; `src` = patch row + cl (fp32), row m
+template <int W>
+__device__ __forceinline__ void epi_cols(EpiLane& e, const GemmParams& p, const float* src, int co, int m) {
+  const int nn = e.n + co;
+  float v[W];
+#pragma unroll
+  for (int q = 0; q < W / 4; ++q) {
+    f32x4_t t4 = *(const f32x4_t*)(src + co + 4 * q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[4 * q + k] = t4[k] + e.bias8[co + 4 * q + k];
+  }
+  auto load_bf = [&](const bf16_t* ptr, float* h) {
+    if (W == 8) {
+      u32x4_t a = *(const u32x4_t*)ptr;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { h[2 * k] = bflo(a[k]); h[2 * k + 1] = bfhi(a[k]); }
+    } else {
+      u32x2_t a = *(const u32x2_t*)ptr;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { h[2 * k] = bflo(a[k]); h[2 * k + 1] = bfhi(a[k]); }
+    }
+  };
+  auto store_bf = [&](bf16_t* ptr, const float* x) {
+    if (W == 8) {
+      u32x4_t o; o[0] = pack2bf(x[0], x[1]); o[1] = pack2bf(x[2], x[3]); o[2] = pack2bf(x[4], x[5]); o[3] = pack2bf(x[6], x[7]);
+      *(u32x4_t*)ptr = o;
+    } else {
+      u32x2_t o; o[0] = pack2bf(x[0], x[1]); o[1] = pack2bf(x[2], x[3]);
+      *(u32x2_t*)ptr = o;
+    }
+  };
+  if (p.act == 3) {                       // backward of an activation: multiply by the saved derivative
+    float h[W];
+    load_bf(p.aux + (size_t)m * p.ldaux + nn, h);
+#pragma unroll
+    for (int k = 0; k < W; ++k) v[k] *= h[k];
+  }
+  if (p.act == 1 || p.act == 2) {         // GELU; the optional second output is GELU'(pre-activation) for backward
+    float d[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      if (p.act == 1) gelu_erf_both(v[k], v[k], d[k]); else gelu_tanh_both(v[k], v[k], d[k]);
+    }
+    if (p.C2) store_bf(p.C2 + (size_t)m * p.ldc2 + nn, d);
+  } else if (p.C2) {
+    store_bf(p.C2 + (size_t)m * p.ldc2 + nn, v);
+  }
+  if (p.drop_thresh) {
+#pragma unroll
+    for (int k = 0; k < W; ++k)
+      v[k] = drop_keep(p.drop_seed, (uint64_t)m * (uint64_t)p.N + (uint64_t)(nn + k), p.drop_thresh) ? v[k] * p.drop_scale : 0.f;
+  }
+  if (p.res) {
+    int mr = p.res_period ? (m % p.res_period) : m;
+    float h[W];
+    load_bf(p.res + (size_t)mr * p.ldres + nn, h);
+#pragma unroll
+    for (int k = 0; k < W; ++k) v[k] += h[k];
+  }
+  if (p.colsum) {
+#pragma unroll
+    for (int k = 0; k < W; ++k) e.csum[co + k] += v[k];
+  }
+  if (p.out_f32) {
+    float* crow = (float*)p.C + (size_t)m * p.ldc + nn;
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) *(f32x4_t*)(crow + 4 * q) = (f32x4_t){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+  } else {
+    store_bf((bf16_t*)p.C + (size_t)m * p.ldc + nn, v);
+  }
+}
+// one patch row (local row ml of the pass, global row m)
+template <int WN>
+__device__ __forceinline__ void epi_row(EpiLane& e, const GemmParams& p, const float* patch, int ml, int m) {
+  if (m < p.M && e.ncol_ok) {
+    const float* src = patch + ml * WN + e.cl;
+    if (e.wide) epi_cols<8>(e, p, src, 0, m);
+    else {
+      epi_cols<4>(e, p, src, 0, m);
+      if (e.n + 4 < p.N) epi_cols<4>(e, p, src, 4, m);
+    }
+  }
+}
+template <int WN>
+__device__ __forceinline__ void epi_flush_colsum(EpiLane& e, const GemmParams& p, int lane) {
+  if (!p.colsum) return;
+  constexpr int LPR = WN / 8;
+  // lanes sharing (lane % LPR) own the same 8 columns: fold the row groups, one atomic per column
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) e.csum[q] += __shfl_xor(e.csum[q], o, 64);
+  }
+  if (lane < LPR && e.ncol_ok) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (e.n + q < p.N) unsafeAtomicAdd(&p.colsum[e.n + q], e.csum[q]);
+  }
+}
+// accumulator registers of pass `ps` (rows [ps*PR, (ps+1)*PR) of the wave tile) -> wave-private fp32 LDS patch
+template <int TM, int TN, int WN, int PR>
+__device__ __forceinline__ void epi_write_pass(float* patch, f32x16_t (&acc)[TM][TN], int ps, int lane) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int g8 = i * 4 + (r >> 2);                       // 8-row group of the wave tile this register lives in
+        if (g8 >= ps * (PR / 8) && g8 < (ps + 1) * (PR / 8)) {
+          int ml = g8 * 8 - ps * PR + (r & 3) + 4 * (lane >> 5);
+          int nl = j * 32 + (lane & 31);
+          patch[ml * WN + nl] = acc[i][j][r];
+        }
+      }
+}
+
 template <int TM, int TN, int WM, int WN, int EPI, int PR = (TM >= 2 ? 64 : 32)>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[TM][TN], char* lds, int wave, int lane,
                                               int row0, int col0) {
@@ -184,135 +332,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
       }
     return;
   } else {
-    // activation epilogue: registers -> wave-private fp32 LDS patch (PT*32 rows x WN) -> 8-column strips per lane
+    // activation epilogue: registers -> wave-private fp32 LDS patch (PR rows x WN) -> 8-column strips per lane
     // (16-B bf16 / 2 x 16-B fp32 stores: the store tail is issue-bound per instruction, so wide stores halve it)
     float* patch = (float*)(lds) + wave * (PR * WN);
     constexpr int LPR = WN / 8;          // lanes per row
     constexpr int RPI = 64 / LPR;        // rows per iteration
-    const int cl = (lane % LPR) * 8;
-    const int n = col0 + cl;
-    const bool ncol_ok = n < p.N;        // N % 8 == 0 (or N % 4 with the narrow path) is a host-checked precondition
-    const bool wide = p.wide_ok && (n + 8 <= p.N);
-    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.bias && ncol_ok) {
-      f32x4_t b = *(const f32x4_t*)(p.bias + n);
-      bias8[0] = b[0]; bias8[1] = b[1]; bias8[2] = b[2]; bias8[3] = b[3];
-      if (n + 4 < p.N) { f32x4_t c = *(const f32x4_t*)(p.bias + n + 4); bias8[4] = c[0]; bias8[5] = c[1]; bias8[6] = c[2]; bias8[7] = c[3]; }
-    }
-    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    EpiLane e;
+    epi_setup<WN>(e, p, lane, col0);
 #pragma unroll
     for (int ps = 0; ps < WM / PR; ++ps) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int g8 = i * 4 + (r >> 2);                       // 8-row group of the wave tile this register lives in
-            if (g8 >= ps * (PR / 8) && g8 < (ps + 1) * (PR / 8)) {
-              int ml = g8 * 8 - ps * PR + (r & 3) + 4 * (lane >> 5);
-              int nl = j * 32 + (lane & 31);
-              patch[ml * WN + nl] = acc[i][j][r];
-            }
-          }
+      epi_write_pass<TM, TN, WN, PR>(patch, acc, ps, lane);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // W consecutive columns starting at column offset `co` of this lane's 8-column strip, row m (patch row ml)
-      auto body = [&](auto W_, int co, int ml, int m) {
-        constexpr int W = decltype(W_)::value;
-        const int nn = n + co;
-        float v[W];
-#pragma unroll
-        for (int q = 0; q < W / 4; ++q) {
-          f32x4_t t4 = *(const f32x4_t*)(patch + ml * WN + cl + co + 4 * q);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[4 * q + e] = t4[e] + bias8[co + 4 * q + e];
-        }
-        auto load_bf = [&](const bf16_t* ptr, float* h) {
-          if (W == 8) {
-            u32x4_t a = *(const u32x4_t*)ptr;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { h[2 * e] = bflo(a[e]); h[2 * e + 1] = bfhi(a[e]); }
-          } else {
-            u32x2_t a = *(const u32x2_t*)ptr;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) { h[2 * e] = bflo(a[e]); h[2 * e + 1] = bfhi(a[e]); }
-          }
-        };
-        auto store_bf = [&](bf16_t* ptr, const float* x) {
-          if (W == 8) {
-            u32x4_t o; o[0] = pack2bf(x[0], x[1]); o[1] = pack2bf(x[2], x[3]); o[2] = pack2bf(x[4], x[5]); o[3] = pack2bf(x[6], x[7]);
-            *(u32x4_t*)ptr = o;
-          } else {
-            u32x2_t o; o[0] = pack2bf(x[0], x[1]); o[1] = pack2bf(x[2], x[3]);
-            *(u32x2_t*)ptr = o;
-          }
-        };
-        if (p.act == 3) {                       // backward of an activation: multiply by the saved derivative
-          float h[W];
-          load_bf(p.aux + (size_t)m * p.ldaux + nn, h);
-#pragma unroll
-          for (int e = 0; e < W; ++e) v[e] *= h[e];
-        }
-        if (p.act == 1 || p.act == 2) {         // GELU; the optional second output is GELU'(pre-activation) for backward
-          float d[W];
-#pragma unroll
-          for (int e = 0; e < W; ++e) {
-            if (p.act == 1) gelu_erf_both(v[e], v[e], d[e]); else gelu_tanh_both(v[e], v[e], d[e]);
-          }
-          if (p.C2) store_bf(p.C2 + (size_t)m * p.ldc2 + nn, d);
-        } else if (p.C2) {
-          store_bf(p.C2 + (size_t)m * p.ldc2 + nn, v);
-        }
-        if (p.drop_thresh) {
-#pragma unroll
-          for (int e = 0; e < W; ++e)
-            v[e] = drop_keep(p.drop_seed, (uint64_t)m * (uint64_t)p.N + (uint64_t)(nn + e), p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
-        }
-        if (p.res) {
-          int mr = p.res_period ? (m % p.res_period) : m;
-          float h[W];
-          load_bf(p.res + (size_t)mr * p.ldres + nn, h);
-#pragma unroll
-          for (int e = 0; e < W; ++e) v[e] += h[e];
-        }
-        if (p.colsum) {
-#pragma unroll
-          for (int e = 0; e < W; ++e) csum[co + e] += v[e];
-        }
-        if (p.out_f32) {
-          float* crow = (float*)p.C + (size_t)m * p.ldc + nn;
-#pragma unroll
-          for (int q = 0; q < W / 4; ++q) *(f32x4_t*)(crow + 4 * q) = (f32x4_t){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-        } else {
-          store_bf((bf16_t*)p.C + (size_t)m * p.ldc + nn, v);
-        }
-      };
 #pragma unroll 2
       for (int itr = 0; itr < PR / RPI; ++itr) {
         int ml = itr * RPI + lane / LPR;
-        int m = row0 + ps * PR + ml;
-        if (m < p.M && ncol_ok) {
-          if (wide) body(std::integral_constant<int, 8>{}, 0, ml, m);
-          else {
-            body(std::integral_constant<int, 4>{}, 0, ml, m);
-            if (n + 4 < p.N) body(std::integral_constant<int, 4>{}, 4, ml, m);
-          }
-        }
+        epi_row<WN>(e, p, patch, ml, row0 + ps * PR + ml);
       }
     }
-    if (p.colsum) {
-      // lanes sharing (lane % LPR) own the same 8 columns: fold the RPI row groups, one atomic per column
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-#pragma unroll
-        for (int o = LPR; o < 64; o <<= 1) csum[e] += __shfl_xor(csum[e], o, 64);
-      }
-      if (lane < LPR && ncol_ok) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (n + e < p.N) unsafeAtomicAdd(&p.colsum[n + e], csum[e]);
-      }
-    }
+    epi_flush_colsum<WN>(e, p, lane);
   }
 }
 
