@@ -151,6 +151,13 @@ __device__ __forceinline__ bf16x8_t frag_kstrided(const char* lds_tile, int tile
   return u.v;
 }
 
+// One MFMA step.  (Kept behind a helper so that the operand order -- which decides whether a lane ends up holding a column
+// or a row of the output tile -- is chosen in one place per epilogue kind.)
+template <int EPI>
+__device__ __forceinline__ f32x16_t mma(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // De-synchronise the chip: all CUs start together and would otherwise hit their output-store tails together (a burst at
 // the HBM write rate while the MFMA pipes idle).  The workgroups of the FIRST dispatch wave start spread over
 // `cycles`; every CU keeps its offset afterwards because it picks up its next tile when it finishes the previous one.
@@ -946,6 +953,213 @@ int dispatch_deepa(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int split
   return launch_deepa<false, true, 1>(p, s);
 }
 
+// ---- 8-phase kernel: 256x256x64 tile, two wave groups half a phase apart, half-tile ring 1.5 K tiles deep ---------
+// The K tile is consumed in four phases, one 64x32 quadrant of the 128x64 wave tile each; every phase is
+//     L: ds_read the operand sub-tiles the quadrant still needs, issue 2 LDS-DMA instructions (1/8 of one 16-KB
+//        half-tile), s_waitcnt vmcnt(8), s_barrier
+//     M: s_waitcnt lgkmcnt(0), 8 x v_mfma_f32_32x32x16_bf16 at raised priority, s_barrier
+// Group 1 (waves 4-7, the partners of waves 0-3 on the four SIMDs) runs one barrier behind group 0, so on every SIMD
+// one wave is in M (matrix pipe) while the other is in L (LDS / texture-address pipes).
+// LDS = 8 half-tile slots of 16 KB (kind x K-tile parity).  Half-tile kinds are cut so that need order == stage order:
+//     A0h = rows {g*128 + 0..63},   A1h = rows {g*128 + 64..127}   (g = wave group, 128 rows each)
+//     B0h = cols {w*64 + 0..31},    B1h = cols {w*64 + 32..63}     (w = wave column 0..3, 128 cols each)
+// Quadrant order (A0,B0) (A0,B1) (A1,B1) (A1,B0); the phases of tile t read {A0h(t), B0h(t)}, B1h(t), A1h(t), nothing
+// (one A fragment set is live at a time, so the 128 accumulators + 64 fragment registers fit 256 VGPRs), and phase P
+// stages S(P+6) of the sequence S = A0h(0), B0h(0), B1h(0), A1h(0), A0h(1), ... -- every half-tile is in flight for
+// 5-6 phases and the slot it lands in was last read >= 2 phases earlier.  vmcnt(8) before the L barrier of phase P
+// retires this wave's share of S(P+2), all that phase P+1 reads (4 younger stages x 2 instructions stay in flight);
+// the M barrier that follows publishes it to both groups before anyone reads it.
+// Stages past the end of the reduction are still issued, with an out-of-range source (zero fill), so the counts hold.
+template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
+__global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
+  constexpr int BM = 256, BN = 256, BK = 64, WM = 128, WN = 64, TM = 4, TN = 2;
+  constexpr int HALF = 128 * BK * 2;                       // 16 KB
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int split = bid / ntile;
+  const int t_ = xcd_remap(bid - split * ntile, ntile);
+  const int tm0 = (t_ / p.tiles_n) * BM;
+  const int tn0 = (t_ % p.tiles_n) * BN;
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
+  const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
+  const int nk = kt_end - kt_begin;
+
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+
+  // per-lane source offsets (bytes) of this wave's two DMA instructions per half-tile, K tile 0
+  uint32_t offA[2][2], offB[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (A_KMAJOR) {
+        int r = j * 64 + wave * 8 + (lane >> 3);                         // LDS row of the half-tile
+        int c = (lane & 7) ^ kmajor_swz<BK>(r);
+        int row = tm0 + j * 128 + (r & 63) + h * 64;
+        offA[h][j] = (uint32_t)(((size_t)row * (size_t)p.lda + (size_t)(kt_begin * BK + c * 8)) * 2);
+      } else {
+        int r = j * 32 + wave * 4 + (lane >> 4);                         // k row
+        int cl = ((lane & 15) ^ kstrided_swz<128>(r)) * 8;               // LDS column of the half-tile
+        int col = tm0 + (cl >> 6) * 128 + (cl & 63) + h * 64;
+        offA[h][j] = (col < p.M) ? (uint32_t)(((size_t)(kt_begin * BK + r) * (size_t)p.lda + (size_t)col) * 2) : 0xFFFFFFF0u;
+      }
+      if (B_KMAJOR) {
+        int r = j * 64 + wave * 8 + (lane >> 3);
+        int c = (lane & 7) ^ kmajor_swz<BK>(r);
+        int row = tn0 + (r >> 5) * 64 + (r & 31) + h * 32;
+        offB[h][j] = (uint32_t)(((size_t)row * (size_t)p.ldb + (size_t)(kt_begin * BK + c * 8)) * 2);
+      } else {
+        int r = j * 32 + wave * 4 + (lane >> 4);
+        int cl = ((lane & 15) ^ kstrided_swz<128>(r)) * 8;
+        int col = tn0 + (cl >> 5) * 64 + (cl & 31) + h * 32;
+        offB[h][j] = (col < p.N) ? (uint32_t)(((size_t)(kt_begin * BK + r) * (size_t)p.ldb + (size_t)col) * 2) : 0xFFFFFFF0u;
+      }
+    }
+  const uint32_t kstepA = A_KMAJOR ? (uint32_t)(BK * 2) : (uint32_t)((size_t)BK * p.lda * 2);
+  const uint32_t kstepB = B_KMAJOR ? (uint32_t)(BK * 2) : (uint32_t)((size_t)BK * p.ldb * 2);
+  char* const dstA = lds + (A_KMAJOR ? wave * 8 * (BK * 2) : wave * 4 * 256);
+  char* const dstB = lds + (B_KMAJOR ? wave * 8 * (BK * 2) : wave * 4 * 256);
+  constexpr int JSTEP = 8192;                              // second DMA instruction lands 64 rows x 128 B (or 32 k rows x 256 B) further
+
+  // slot index = kind * 2 + (tile & 1); kinds 0 = A0h, 1 = B0h, 2 = B1h, 3 = A1h
+  auto stage_a = [&](int h, int tile) __attribute__((always_inline)) {
+    const bool valid = tile < nk;
+    char* d = dstA + ((h ? 3 : 0) * 2 + (tile & 1)) * HALF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      uint32_t off = offA[h][j] + (uint32_t)tile * kstepA;
+      if (!valid || offA[h][j] == 0xFFFFFFF0u) off = 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, AVT_LDS_PTR(d + j * JSTEP), 16, off, 0, 0, 0);
+    }
+  };
+  auto stage_b = [&](int h, int tile) __attribute__((always_inline)) {
+    const bool valid = tile < nk;
+    char* d = dstB + ((h ? 2 : 1) * 2 + (tile & 1)) * HALF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      uint32_t off = offB[h][j] + (uint32_t)tile * kstepB;
+      if (!valid || offB[h][j] == 0xFFFFFFF0u) off = 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, AVT_LDS_PTR(d + j * JSTEP), 16, off, 0, 0, 0);
+    }
+  };
+
+  bf16x8_t fa[2][4], fb0[4], fb1[4];
+  auto read_a = [&](bf16x8_t (&f)[2][4], int h, int par) __attribute__((always_inline)) {
+    const char* slot = lds + ((h ? 3 : 0) * 2 + par) * HALF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        f[i][ks] = A_KMAJOR ? frag_kmajor<BK>(slot + grp * 64 * (BK * 2), i, ks, lane) : frag_kstrided<128>(slot, grp * 2 + i, ks, lane);
+  };
+  auto read_b = [&](bf16x8_t (&f)[4], int h, int par) __attribute__((always_inline)) {
+    const char* slot = lds + ((h ? 2 : 1) * 2 + par) * HALF;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      f[ks] = B_KMAJOR ? frag_kmajor<BK>(slot + wn * 32 * (BK * 2), 0, ks, lane) : frag_kstrided<128>(slot, wn, ks, lane);
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define P8_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define P8_MFMA(FA, FB, I0, J)                                                                          \
+  do {                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                     \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
+        acc[(I0) + i][J] = mma<EPI>(FA[i][ks], FB[ks], acc[(I0) + i][J]);                                \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  } while (0)
+
+  // prologue: S(0..5)
+  stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0); stage_a(0, 1); stage_b(0, 1);
+  wait_vmcnt<8>();
+  P8_BARRIER();
+  if (grp == 1) P8_BARRIER();
+  for (int t = 0; t < nk; t += 2) {
+    // ---- even tile t (slot parity 0) ----
+    read_a(fa, 0, 0); read_b(fb0, 0, 0); stage_b(1, t + 1); wait_vmcnt<8>(); P8_BARRIER();
+    P8_MFMA(fa, fb0, 0, 0); P8_BARRIER();
+    read_b(fb1, 1, 0); stage_a(1, t + 1); wait_vmcnt<8>(); P8_BARRIER();
+    P8_MFMA(fa, fb1, 0, 1); P8_BARRIER();
+    read_a(fa, 1, 0); stage_a(0, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+    P8_MFMA(fa, fb1, 2, 1); P8_BARRIER();
+    stage_b(0, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+    P8_MFMA(fa, fb0, 2, 0); P8_BARRIER();
+    // ---- odd tile t+1 (slot parity 1); when nk is odd this runs once on zero-filled slots (no mid-loop exit: it would
+    //      split the accumulators' live ranges and cost a register copy of all of them per trip) ----
+    read_a(fa, 0, 1); read_b(fb0, 0, 1); stage_b(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+    P8_MFMA(fa, fb0, 0, 0); P8_BARRIER();
+    read_b(fb1, 1, 1); stage_a(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+    P8_MFMA(fa, fb1, 0, 1); P8_BARRIER();
+    read_a(fa, 1, 1); stage_a(0, t + 3); wait_vmcnt<8>(); P8_BARRIER();
+    P8_MFMA(fa, fb1, 2, 1); P8_BARRIER();
+    stage_b(0, t + 3); wait_vmcnt<8>(); P8_BARRIER();
+    P8_MFMA(fa, fb0, 2, 0); P8_BARRIER();
+  }
+  wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (grp == 0) P8_BARRIER();
+  P8_BARRIER();                                          // every LDS-DMA has landed and every fragment read retired: LDS is free
+  int lane_e = lane, m0_e = tm0 + grp * WM, n0_e = tn0 + wn * WN;
+  asm volatile("" : "+v"(lane_e), "+s"(m0_e), "+s"(n0_e));   // keep the epilogue's address arithmetic out of the K loop's register budget
+  gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane_e, m0_e, n0_e);
+#undef P8_MFMA
+#undef P8_BARRIER
+}
+
+template <bool AK, bool BK_, int EPI>
+int launch_8p(const GemmParams& p, hipStream_t s) {
+  int grid = p.tiles_m * p.tiles_n * p.splitk;
+  constexpr int smem = 8 * 128 * 64 * 2;               // 128 KiB ring == 8 waves x 16 KiB epilogue patches
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_8p_kernel<AK, BK_, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_8p_kernel<AK, BK_, EPI>), dim3(grid), dim3(512), smem, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
+  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
+  const int nk = (p.K + 63) / 64;
+  if (splitk <= 0) {
+    splitk = 1;
+    if (epi == 1) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk, 1, 8);
+  }
+  if (splitk > nk) splitk = nk;
+  p.splitk = splitk;
+  if (epi == 0) {
+    if (a_kmajor && b_kmajor) return launch_8p<true, true, 0>(p, s);
+    if (a_kmajor && !b_kmajor) return launch_8p<true, false, 0>(p, s);
+    if (!a_kmajor && !b_kmajor) return launch_8p<false, false, 0>(p, s);
+    return launch_8p<false, true, 0>(p, s);
+  }
+  if (a_kmajor && b_kmajor) return launch_8p<true, true, 1>(p, s);
+  if (a_kmajor && !b_kmajor) return launch_8p<true, false, 1>(p, s);
+  if (!a_kmajor && !b_kmajor) return launch_8p<false, false, 1>(p, s);
+  return launch_8p<false, true, 1>(p, s);
+}
+
 }  // namespace
 
 extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,
@@ -1002,6 +1216,9 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_epi<256, 256, 2, 4, 64, 2, true, 0, 1, 4>(p, epi, a_kmajor, b_kmajor, splitk, s);
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 2568: return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);       // all 8 waves issue LDS-DMA
+    case 808:                                                                                     // 8-phase schedule (needs K % 64 == 0 for k-major operands)
+      if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_8p(p, epi, a_kmajor, b_kmajor, splitk, s);
+      return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 258: return dispatch_deepa(p, epi, a_kmajor, b_kmajor, splitk, s);                          // A ring 3 deep, B ring 2 deep
     case 512: return dispatch_pp(p, epi, a_kmajor, b_kmajor, splitk, s);                            // ping-pong 256x256
     default: break;

@@ -23,10 +23,10 @@ for name, N, K in [('qkv', 2304, 768), ('proj', 768, 768), ('fc1', 3072, 768), (
     dw = torch.zeros((N, K), device='cuda')
     bias = torch.zeros(N, device='cuda')
     fl = 2.0 * M * N * K
-    for tile in (128, 256):
+    for tile in (256, 808):
         t = bench(lambda: ops.linear_fwd(x, w, bias=bias, tile=tile)); print(f'{name:5s} fwd   NT tile={tile} {fl/t/1e12:7.1f} TF/s  {t*1e6:8.1f} us')
         t = bench(lambda: ops.linear_dgrad(dy, w, tile=tile));          print(f'{name:5s} dgrad NN tile={tile} {fl/t/1e12:7.1f} TF/s  {t*1e6:8.1f} us')
-    for tile, sk in ((128, 0), (256, 0), (2568, 0)):
+    for tile, sk in ((256, 0), (808, 0)):
         t = bench(lambda: ops.linear_wgrad(dy, x, dw, splitk=sk, tile=tile));   print(f'{name:5s} wgrad TN tile={tile} splitk={sk:2d} {fl/t/1e12:7.1f} TF/s  {t*1e6:8.1f} us')
 Mh = B * 10
 for name, N, K in [('c_attn', 6144, 2048), ('c_proj', 2048, 2048), ('c_fc', 8192, 2048), ('mlp_proj', 2048, 8192)]:
