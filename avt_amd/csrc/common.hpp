@@ -36,12 +36,12 @@ __device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0
 // far below bf16 resolution, and it keeps the GEMM epilogue off the critical path.
 __device__ __forceinline__ float fast_erf(float x) {
   float ax = fabsf(x);
-  float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
   float poly = fmaf(fmaf(fmaf(fmaf(1.061405429f, t, -1.453152027f), t, 1.421413741f), t, -0.284496736f), t, 0.254829592f) * t;
   float r = 1.0f - poly * __expf(-ax * ax);
   return copysignf(r, x);
 }
-__device__ __forceinline__ float fast_tanh(float u) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * u)); }
+__device__ __forceinline__ float fast_tanh(float u) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u)); }
 
 // exact (erf) GELU -- timm Mlp act_layer=nn.GELU ; tanh GELU -- HF "gelu_new"
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
@@ -61,12 +61,35 @@ __device__ __forceinline__ float dgelu_tanh(float x) {
 // value and derivative together (one erf / one exp shared): the forward epilogue stores GELU'(h) for the backward pass
 __device__ __forceinline__ void gelu_erf_both(float x, float& y, float& dy) {
   float ax = fabsf(x) * 0.70710678118654752f;
-  float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
   float ex = __expf(-ax * ax);                                   // = exp(-x^2/2)
   float poly = fmaf(fmaf(fmaf(fmaf(1.061405429f, t, -1.453152027f), t, 1.421413741f), t, -0.284496736f), t, 0.254829592f) * t;
   float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * ex, x));
   y = x * cdf;
   dy = cdf + x * 0.3989422804014327f * ex;
+}
+// two elements at a time with packed fp32 arithmetic (v_pk_mul/fma/add_f32); erf(z) = z * P(z^2) on |z| <= 3 (degree-8
+// near-minimax fit, |error| <= 2.4e-5, i.e. below bf16 resolution of the outputs; |z| > 3 clamps to +-1), one v_exp_f32
+// per element for the density term of the derivative.
+__device__ __forceinline__ void gelu_erf_both2(f32x2_t x, f32x2_t& y, f32x2_t& dy) {
+  f32x2_t z = x * 0.70710678118654752f;
+  z[0] = __builtin_amdgcn_fmed3f(z[0], -3.0f, 3.0f); z[1] = __builtin_amdgcn_fmed3f(z[1], -3.0f, 3.0f);
+  const f32x2_t u = z * z;
+  f32x2_t pl = u * 4.074186322e-08f + -1.944813448e-06f;
+  pl = pl * u + 4.106037522e-05f;
+  pl = pl * u + -5.110356142e-04f;
+  pl = pl * u + 4.235421773e-03f;
+  pl = pl * u + -2.510284632e-02f;
+  pl = pl * u + 1.110793129e-01f;
+  pl = pl * u + -3.753148615e-01f;
+  pl = pl * u + 1.128268480e+00f;
+  f32x2_t er = z * pl;
+  er[0] = __builtin_amdgcn_fmed3f(er[0], -1.0f, 1.0f); er[1] = __builtin_amdgcn_fmed3f(er[1], -1.0f, 1.0f);
+  const f32x2_t cdf = er * 0.5f + 0.5f;
+  const f32x2_t a = x * x * (-0.5f * 1.4426950408889634f);           // exp(-x^2/2) = 2^a
+  f32x2_t ex; ex[0] = __builtin_amdgcn_exp2f(a[0]); ex[1] = __builtin_amdgcn_exp2f(a[1]);
+  y = x * cdf;
+  dy = x * 0.3989422804014327f * ex + cdf;
 }
 __device__ __forceinline__ void gelu_tanh_both(float x, float& y, float& dy) {
   float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);

@@ -56,6 +56,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return start + idx;
 }
 
+// One MFMA step; the operand order decides whether a lane ends up holding a column or a row of the output block:
+// EPI 0 (activation epilogue): B first, so block (i,j) comes out TRANSPOSED -- lane l holds output row i*32 + (l&31) and its
+//   16 registers are four groups q of 4 CONSECUTIVE columns j*32 + 8q + 4(l>>5) + (r&3): elementwise work, bf16 packing and
+//   the LDS hand-off all work on 8-/16-byte units instead of single floats.
+// EPI 1 (atomic accumulate): A first, lane l holds column j*32 + (l&31), so a wave's atomics hit 128 consecutive bytes.
+template <int EPI>
+__device__ __forceinline__ f32x16_t mma(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  return EPI == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // ---- operand tile loaders (LDS-DMA, swizzle on the source address) ------------------------------------
 // k-major operand: LDS tile [BR][BK] bf16 (BK*2-byte rows).  The 16-B chunk c of row r lives at chunk
 // c ^ ((r>>1)&7) for BK=64 (128-B rows) and c ^ ((r>>2)&3) for BK=32 (64-B rows): the 16 rows a ds_read_b128 lane
@@ -151,13 +161,6 @@ __device__ __forceinline__ bf16x8_t frag_kstrided(const char* lds_tile, int tile
   return u.v;
 }
 
-// One MFMA step.  (Kept behind a helper so that the operand order -- which decides whether a lane ends up holding a column
-// or a row of the output tile -- is chosen in one place per epilogue kind.)
-template <int EPI>
-__device__ __forceinline__ f32x16_t mma(bf16x8_t a, bf16x8_t b, f32x16_t c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
 // De-synchronise the chip: all CUs start together and would otherwise hit their output-store tails together (a burst at
 // the HBM write rate while the MFMA pipes idle).  The workgroups of the FIRST dispatch wave start spread over
 // `cycles`; every CU keeps its offset afterwards because it picks up its next tile when it finishes the previous one.
@@ -202,17 +205,13 @@ __device__ __forceinline__ void epi_setup(EpiLane& e, const GemmParams& p, int l
     if (e.n + 4 < p.N) { f32x4_t c = *(const f32x4_t*)(p.bias + e.n + 4); e.bias8[4] = c[0]; e.bias8[5] = c[1]; e.bias8[6] = c[2]; e.bias8[7] = c[3]; }
   }
 }
-// W (8 or 4) consecutive columns starting at column offset `co` of the lane's strip; `src` = patch row + cl (fp32), row m
+// W (8 or 4) consecutive columns starting at column offset `co` of the lane's strip; `src` = the strip's 8 values (fp32), row m
 template <int W>
-__device__ __forceinline__ void epi_cols(EpiLane& e, const GemmParams& p, const float* src, int co, int m) {
+__device__ __forceinline__ void epi_cols(EpiLane& e, const GemmParams& p, const float (&src)[8], int co, int m) {
   const int nn = e.n + co;
   float v[W];
 #pragma unroll
-  for (int q = 0; q < W / 4; ++q) {
-    f32x4_t t4 = *(const f32x4_t*)(src + co + 4 * q);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[4 * q + k] = t4[k] + e.bias8[co + 4 * q + k];
-  }
+  for (int k = 0; k < W; ++k) v[k] = src[co + k] + e.bias8[co + k];
   auto load_bf = [&](const bf16_t* ptr, float* h) {
     if (W == 8) {
       u32x4_t a = *(const u32x4_t*)ptr;
@@ -273,11 +272,9 @@ __device__ __forceinline__ void epi_cols(EpiLane& e, const GemmParams& p, const 
     store_bf((bf16_t*)p.C + (size_t)m * p.ldc + nn, v);
   }
 }
-// one patch row (local row ml of the pass, global row m)
-template <int WN>
-__device__ __forceinline__ void epi_row(EpiLane& e, const GemmParams& p, const float* patch, int ml, int m) {
+// one output row (global row m): the lane's 8 values of it
+__device__ __forceinline__ void epi_row(EpiLane& e, const GemmParams& p, const float (&src)[8], int m) {
   if (m < p.M && e.ncol_ok) {
-    const float* src = patch + ml * WN + e.cl;
     if (e.wide) epi_cols<8>(e, p, src, 0, m);
     else {
       epi_cols<4>(e, p, src, 0, m);
@@ -301,28 +298,122 @@ __device__ __forceinline__ void epi_flush_colsum(EpiLane& e, const GemmParams& p
       if (e.n + q < p.N) unsafeAtomicAdd(&p.colsum[e.n + q], e.csum[q]);
   }
 }
-// accumulator registers of pass `ps` (rows [ps*PR, (ps+1)*PR) of the wave tile) -> wave-private fp32 LDS patch
-template <int TM, int TN, int WN, int PR>
-__device__ __forceinline__ void epi_write_pass(float* patch, f32x16_t (&acc)[TM][TN], int ps, int lane) {
+// ---- general path: 32-row block of the wave tile -> wave-private fp32 LDS patch (4 consecutive columns = one ds_write_b128;
+// rows 272 B apart, so the 8 lanes of a store group and the 2 rows of a load group sit on disjoint banks)
+template <int TN> struct EpiBlk { f32x16_t t[TN]; };     // one 32-row block of the wave tile, passed by value (keeps the accumulators in registers)
+template <int TM, int TN, int I>
+__device__ __forceinline__ EpiBlk<TN> epi_take(const f32x16_t (&acc)[TM][TN]) {
+  EpiBlk<TN> b;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j) b.t[j] = acc[I < TM ? I : 0][j];
+  return b;
+}
+template <int TN, int WN>
+__device__ __forceinline__ void epi_write_block(float* patch, const EpiBlk<TN> blk_, int lane) {
+  const f32x16_t* blk = blk_.t;
+  constexpr int LDP = WN + 4;
+  float* dst = patch + (lane & 31) * LDP + 4 * (lane >> 5);
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int g8 = i * 4 + (r >> 2);                       // 8-row group of the wave tile this register lives in
-        if (g8 >= ps * (PR / 8) && g8 < (ps + 1) * (PR / 8)) {
-          int ml = g8 * 8 - ps * PR + (r & 3) + 4 * (lane >> 5);
-          int nl = j * 32 + (lane & 31);
-          patch[ml * WN + nl] = acc[i][j][r];
-        }
-      }
+    for (int q = 0; q < 4; ++q)
+      *(f32x4_t*)(dst + j * 32 + 8 * q) = (f32x4_t){blk[j][4 * q], blk[j][4 * q + 1], blk[j][4 * q + 2], blk[j][4 * q + 3]};
+}
+template <int TM, int TN, int WN>
+__device__ __forceinline__ void epi_write_block_i(float* patch, const f32x16_t (&acc)[TM][TN], int i, int lane) {
+  switch (i) {          // accumulator registers need compile-time indices
+    case 0: epi_write_block<TN, WN>(patch, epi_take<TM, TN, 0>(acc), lane); break;
+    case 1: if (TM > 1) epi_write_block<TN, WN>(patch, epi_take<TM, TN, 1>(acc), lane); break;
+    case 2: if (TM > 2) epi_write_block<TN, WN>(patch, epi_take<TM, TN, 2>(acc), lane); break;
+    case 3: if (TM > 3) epi_write_block<TN, WN>(patch, epi_take<TM, TN, 3>(acc), lane); break;
+    default: break;
+  }
 }
 
-template <int TM, int TN, int WM, int WN, int EPI, int PR = (TM >= 2 ? 64 : 32)>
+// ---- fast path (bias / GELU (+ GELU') only, bf16 output): all arithmetic in the accumulator layout with packed fp32 ops,
+// bf16 pairs through a [32][WN] bf16 patch (ds_write_b64 in, 16 B per lane out), one 16-byte global store per lane and row
+template <int TN, int WN, int ACT>
+__device__ __forceinline__ void epi_fast_block(const GemmParams& p, const EpiBlk<TN> blk_, char* patch_c, char* patch_d,
+                                               const float* bias_l, int lane, int m0, int col0) {
+  const f32x16_t* blk = blk_.t;
+  constexpr int LDB = WN * 2 + 8;                                  // patch row pitch (bytes): 16 store lanes -> 32 distinct banks
+  const int ml = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nl = j * 32 + 8 * q + 4 * h;
+      const f32x4_t b = *(const f32x4_t*)(bias_l + nl);
+      f32x2_t v0 = (f32x2_t){blk[j][4 * q], blk[j][4 * q + 1]} + (f32x2_t){b[0], b[1]};
+      f32x2_t v1 = (f32x2_t){blk[j][4 * q + 2], blk[j][4 * q + 3]} + (f32x2_t){b[2], b[3]};
+      if (ACT != 0) {
+        f32x2_t d0, d1;
+        if (ACT == 1) { gelu_erf_both2(v0, v0, d0); gelu_erf_both2(v1, v1, d1); }
+        else {
+          float y4[4], d4[4];
+          gelu_tanh_both(v0[0], y4[0], d4[0]); gelu_tanh_both(v0[1], y4[1], d4[1]);
+          gelu_tanh_both(v1[0], y4[2], d4[2]); gelu_tanh_both(v1[1], y4[3], d4[3]);
+          v0 = (f32x2_t){y4[0], y4[1]}; v1 = (f32x2_t){y4[2], y4[3]}; d0 = (f32x2_t){d4[0], d4[1]}; d1 = (f32x2_t){d4[2], d4[3]};
+        }
+        if (p.C2) *(u32x2_t*)(patch_d + ml * LDB + nl * 2) = (u32x2_t){pack2bf(d0[0], d0[1]), pack2bf(d1[0], d1[1])};
+      }
+      *(u32x2_t*)(patch_c + ml * LDB + nl * 2) = (u32x2_t){pack2bf(v0[0], v0[1]), pack2bf(v1[0], v1[1])};
+    }
+  constexpr int LPR = WN / 8, RPI = 64 / LPR, IT = 32 / RPI;
+  const int rl = lane / LPR, cl = (lane % LPR) * 8;
+  const int n = col0 + cl;
+  // with no activation the second output is the same tensor as the first (C2 = value before dropout, and the fast path has none)
+  const char* patch_2 = (ACT != 0) ? patch_d : patch_c;
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int row = it * RPI + rl, m = m0 + row;
+    const char* src = patch_c + row * LDB + cl * 2;
+    u32x2_t lo = *(const u32x2_t*)src, hi = *(const u32x2_t*)(src + 8);
+    u32x2_t lo2 = lo, hi2 = hi;
+    if (p.C2) { const char* s2 = patch_2 + row * LDB + cl * 2; lo2 = *(const u32x2_t*)s2; hi2 = *(const u32x2_t*)(s2 + 8); }
+    if (m < p.M && n < p.N) {
+      *(u32x4_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = (u32x4_t){lo[0], lo[1], hi[0], hi[1]};
+      if (p.C2) *(u32x4_t*)(p.C2 + (size_t)m * p.ldc2 + n) = (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]};
+    }
+  }
+}
+template <int TM, int TN, int WN, int ACT>
+__device__ __forceinline__ void epi_fast(const GemmParams& p, const f32x16_t (&acc)[TM][TN], char* wave_lds, int lane, int row0, int col0) {
+  constexpr int LDB = WN * 2 + 8;
+  float* bias_l = (float*)wave_lds;
+  char* patch_c = wave_lds + WN * 4;
+  char* patch_d = patch_c + 32 * LDB;
+  if (lane < WN) bias_l[lane] = (p.bias && col0 + lane < p.N) ? p.bias[col0 + lane] : 0.f;
+  if (ACT == 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      EpiBlk<TN> b;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b.t[j] = acc[i][j];
+      epi_fast_block<TN, WN, ACT>(p, b, patch_c, patch_d, bias_l, lane, row0 + i * 32, col0);
+    }
+  } else {
+    // the GELU arithmetic of one block is ~1.5 k instructions: keep ONE copy of it (instruction cache) and move the block
+    // into place instead (32 register copies per block)
+#pragma unroll 1
+    for (int i = 0; i < TM; ++i) {
+      EpiBlk<TN> b;
+      switch (i) {
+        case 0: b = epi_take<TM, TN, 0>(acc); break;
+        case 1: b = epi_take<TM, TN, 1>(acc); break;
+        case 2: b = epi_take<TM, TN, 2>(acc); break;
+        default: b = epi_take<TM, TN, 3>(acc); break;
+      }
+      epi_fast_block<TN, WN, ACT>(p, b, patch_c, patch_d, bias_l, lane, row0 + i * 32, col0);
+    }
+  }
+}
+
+template <int TM, int TN, int WM, int WN, int EPI, int PR = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[TM][TN], char* lds, int wave, int lane,
                                               int row0, int col0) {
-  // row0/col0: global coordinates of this wave's tile origin; PR = rows of the wave tile staged through LDS per pass
+  // row0/col0: global coordinates of this wave's tile origin
+  static_assert(WM == TM * 32 && WN == TN * 32 && TM <= 4, "wave tile geometry");
   if (EPI == 1) {
     // weight-gradient epilogue: fp32 accumulate into C (atomics; C is pre-zeroed or holds the running sum)
     float* C = (float*)p.C;
@@ -339,22 +430,43 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
       }
     return;
   } else {
-    // activation epilogue: registers -> wave-private fp32 LDS patch (PR rows x WN) -> 8-column strips per lane
-    // (16-B bf16 / 2 x 16-B fp32 stores: the store tail is issue-bound per instruction, so wide stores halve it)
-    float* patch = (float*)(lds) + wave * (PR * WN);
+    // The LDS pipe executes one wave's operations in order, so a wave-private patch needs no wait between writing it and
+    // reading it back, and a patch can be rewritten as soon as the reads of its previous contents have been ISSUED.
+    constexpr int LDP = WN + 4;
+    constexpr int WAVE_LDS = (32 * LDP * 4 > WN * 4 + 2 * 32 * (WN * 2 + 8)) ? 32 * LDP * 4 : WN * 4 + 2 * 32 * (WN * 2 + 8);
+    char* wave_lds = lds + wave * ((WAVE_LDS + 15) & ~15);
+    const bool fast = !p.res && p.act != 3 && !p.colsum && !p.out_f32 && !p.drop_thresh && p.wide_ok && (p.N % 8 == 0);
+    if (fast) {
+      if (p.act == 0) epi_fast<TM, TN, WN, 0>(p, acc, wave_lds, lane, row0, col0);
+      else if (p.act == 1) epi_fast<TM, TN, WN, 1>(p, acc, wave_lds, lane, row0, col0);
+      else epi_fast<TM, TN, WN, 2>(p, acc, wave_lds, lane, row0, col0);
+      return;
+    }
+    // general path: per 32-row block: request the rows of patch i (8-column strips), queue the writes of block i+1 behind
+    // them, then do the arithmetic and the global accesses of block i while those writes drain
     constexpr int LPR = WN / 8;          // lanes per row
     constexpr int RPI = 64 / LPR;        // rows per iteration
+    constexpr int IT = 32 / RPI;
+    float* patch = (float*)wave_lds;
     EpiLane e;
     epi_setup<WN>(e, p, lane, col0);
+    epi_write_block<TN, WN>(patch, epi_take<TM, TN, 0>(acc), lane);
+#pragma unroll 1
+    for (int i = 0; i < TM; ++i) {
+      float rows[IT][8];
 #pragma unroll
-    for (int ps = 0; ps < WM / PR; ++ps) {
-      epi_write_pass<TM, TN, WN, PR>(patch, acc, ps, lane);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 2
-      for (int itr = 0; itr < PR / RPI; ++itr) {
-        int ml = itr * RPI + lane / LPR;
-        epi_row<WN>(e, p, patch, ml, row0 + ps * PR + ml);
+      for (int itr = 0; itr < IT; ++itr) {
+        const float* src = patch + (itr * RPI + lane / LPR) * LDP + e.cl;
+        f32x4_t lo = *(const f32x4_t*)src, hi = *(const f32x4_t*)(src + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { rows[itr][k] = lo[k]; rows[itr][4 + k] = hi[k]; }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < TM) epi_write_block_i<TM, TN, WN>(patch, acc, i + 1, lane);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int itr = 0; itr < IT; ++itr)
+        epi_row(e, p, rows[itr], row0 + i * 32 + itr * RPI + lane / LPR);
     }
     epi_flush_colsum<WN>(e, p, lane);
   }
@@ -482,7 +594,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mma<EPI>(af[i], bfr[j], acc[i][j]);
       }
     } else {
       // software-pipelined k-steps: fragments of step ks+1 are requested before the MFMAs of step ks, and the LDS-DMA
@@ -548,7 +660,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mma<EPI>(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
       }
     }
     if (++slot == NSTAGE) slot = 0;
@@ -556,7 +668,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   asm volatile("s_barrier" ::: "memory");   // every wave is done reading the ring before the epilogue reuses it
   if (p.dbg) t_loop = __builtin_readcyclecounter();
 
-  gemm_epilogue<TM, TN, WM, WN, EPI, (PR ? PR : (TM >= 2 ? 64 : 32))>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
+  gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
   if (p.dbg && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     long long t_end = __builtin_readcyclecounter();
@@ -718,7 +830,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mma<EPI>(af[ks][i], bfr[ks][j], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
     if (prof) { asm volatile("s_nop 0" ::: "memory"); }
     PP_T1(c_comp);
@@ -910,7 +1022,7 @@ __global__ __launch_bounds__(512) void gemm_deepa_kernel(GemmParams p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mma<EPI>(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
     }
   }
   asm volatile("s_barrier" ::: "memory");
