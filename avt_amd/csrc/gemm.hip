@@ -1321,10 +1321,11 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
       bm = (t256 * sk >= 256 && t256 < 4096) ? 256 : 128;
     }
   }
+  if (tile == 0 && bm == 256 && (K % 64 == 0 || (!a_kmajor && !b_kmajor))) bm = 808;       // default big-tile kernel: the 8-phase schedule
   switch (bm) {
     case 64:  return dispatch_epi<64, 64, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 128: return dispatch_epi<128, 128, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
-    case 256:                                                                                     // default big tile: dribbled LDS-DMA issued by 4 loader waves
+    case 256:                                                                                     // one barrier per K tile, dribbled LDS-DMA issued by 4 loader waves
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_epi<256, 256, 2, 4, 64, 2, true, 0, 1, 4>(p, epi, a_kmajor, b_kmajor, splitk, s);
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 2568: return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);       // all 8 waves issue LDS-DMA
@@ -1335,6 +1336,6 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
     case 512: return dispatch_pp(p, epi, a_kmajor, b_kmajor, splitk, s);                            // ping-pong 256x256
     default: break;
   }
-  avt_set_error("avt_gemm_bf16: tile must be 0, 64, 128, 256 (default big tile), 258 (deep-A ring) or 512 (ping-pong) (got %d)", tile);
+  avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 64, 128, 256 (one barrier per K tile), 808 (8-phase), 258 (deep-A ring) or 512 (ping-pong) (got %d)", tile);
   return -1;
 }

@@ -156,14 +156,14 @@ def main():
                 d[0] += fl
                 d[1] += e0.elapsed_time(e1) * 1e-3
                 d[2] += 1
-        dom = {k: v for k, v in per_variant.items() if k.startswith(('gemm_kernel<128', 'gemm_kernel<256'))}
+        dom = {k: v for k, v in per_variant.items() if k.startswith(('gemm_kernel<128', 'gemm_kernel<256', 'gemm_8p_kernel'))}
         fl = sum(v[0] for v in dom.values())
         tm = sum(v[1] for v in dom.values())
         n_launch = sum(v[2] for v in dom.values())
         roof = None
         if tm > 0:
             ach = fl / tm / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'gemm_kernel<256,256,2,4,*> + <128,128,2,2,*> (bf16 MFMA GEMM, all layouts/epilogues)',
+            roof = {'bound': 'mfma', 'kernel': 'gemm_8p_kernel<*> (256x256x64, 8-phase) + gemm_kernel<256|128,*> (bf16 MFMA GEMM, all layouts/epilogues)',
                     'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4),
                     'traffic': None, 'launches': n_launch, 'avg_launch_us': round(tm / n_launch * 1e6, 2),
                     'avg_launch_gflop': round(fl / n_launch / 1e9, 3),

@@ -47,7 +47,7 @@ int avt_abi_version(void);
  *     v += res[(res_period ? m % res_period : m), n];  colsum[n] += v (fp32 atomics);  C[m,n] = v
  * out_mode 2: C (fp32) += acc with atomics, no epilogue; splitk > 1 splits the reduction over workgroups
  *             (splitk <= 0 picks a factor that fills the chip).  Used for weight gradients.
- * tile: 0 = choose, 64 | 128 = force the block tile.  Requirements: 16-B aligned pointers, lda/ldb % 8 == 0,
+ * tile: 0 = choose; 64 | 128 | 256 | 808 (256x256 tile, 8-phase schedule) force a kernel.  Requirements: 16-B aligned pointers, lda/ldb % 8 == 0,
  * K % 8 == 0 when an operand is k-major, N % 4 == 0 and ldc % 4 == 0 for out_mode 0/1. */
 int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,
                   void* C, int ldc, int M, int N, int K,
