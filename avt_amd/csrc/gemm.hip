@@ -206,23 +206,24 @@ __device__ __forceinline__ void epi_setup(EpiLane& e, const GemmParams& p, int l
   }
 }
 // W (8 or 4) consecutive columns starting at column offset `co` of the lane's strip; `src` = the strip's 8 values (fp32), row m
+struct EpiStrip { u32x4_t w; };        // 8 bf16 of a second operand (saved derivative / residual) for one row strip
+__device__ __forceinline__ EpiStrip epi_load_strip(const bf16_t* base, int ld, int m, const EpiLane& e, const GemmParams& p) {
+  EpiStrip s; s.w = (u32x4_t){0u, 0u, 0u, 0u};
+  const bf16_t* ptr = base + (size_t)m * ld + e.n;
+  if (e.wide) s.w = *(const u32x4_t*)ptr;
+  else {
+    u32x2_t a = *(const u32x2_t*)ptr; s.w[0] = a[0]; s.w[1] = a[1];
+    if (e.n + 4 < p.N) { u32x2_t b = *(const u32x2_t*)(ptr + 4); s.w[2] = b[0]; s.w[3] = b[1]; }
+  }
+  return s;
+}
 template <int W>
-__device__ __forceinline__ void epi_cols(EpiLane& e, const GemmParams& p, const float (&src)[8], int co, int m) {
+__device__ __forceinline__ void epi_cols(EpiLane& e, const GemmParams& p, const float (&src)[8], int co, int m,
+                                         const EpiStrip& aux_s, const EpiStrip& res_s) {
   const int nn = e.n + co;
   float v[W];
 #pragma unroll
   for (int k = 0; k < W; ++k) v[k] = src[co + k] + e.bias8[co + k];
-  auto load_bf = [&](const bf16_t* ptr, float* h) {
-    if (W == 8) {
-      u32x4_t a = *(const u32x4_t*)ptr;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { h[2 * k] = bflo(a[k]); h[2 * k + 1] = bfhi(a[k]); }
-    } else {
-      u32x2_t a = *(const u32x2_t*)ptr;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) { h[2 * k] = bflo(a[k]); h[2 * k + 1] = bfhi(a[k]); }
-    }
-  };
   auto store_bf = [&](bf16_t* ptr, const float* x) {
     if (W == 8) {
       u32x4_t o; o[0] = pack2bf(x[0], x[1]); o[1] = pack2bf(x[2], x[3]); o[2] = pack2bf(x[4], x[5]); o[3] = pack2bf(x[6], x[7]);
@@ -233,10 +234,8 @@ __device__ __forceinline__ void epi_cols(EpiLane& e, const GemmParams& p, const 
     }
   };
   if (p.act == 3) {                       // backward of an activation: multiply by the saved derivative
-    float h[W];
-    load_bf(p.aux + (size_t)m * p.ldaux + nn, h);
 #pragma unroll
-    for (int k = 0; k < W; ++k) v[k] *= h[k];
+    for (int k = 0; k < W; ++k) { uint32_t w = aux_s.w[(co + k) >> 1]; v[k] *= ((co + k) & 1) ? bfhi(w) : bflo(w); }
   }
   if (p.act == 1 || p.act == 2) {         // GELU; the optional second output is GELU'(pre-activation) for backward
     float d[W];
@@ -254,11 +253,8 @@ __device__ __forceinline__ void epi_cols(EpiLane& e, const GemmParams& p, const 
       v[k] = drop_keep(p.drop_seed, (uint64_t)m * (uint64_t)p.N + (uint64_t)(nn + k), p.drop_thresh) ? v[k] * p.drop_scale : 0.f;
   }
   if (p.res) {
-    int mr = p.res_period ? (m % p.res_period) : m;
-    float h[W];
-    load_bf(p.res + (size_t)mr * p.ldres + nn, h);
 #pragma unroll
-    for (int k = 0; k < W; ++k) v[k] += h[k];
+    for (int k = 0; k < W; ++k) { uint32_t w = res_s.w[(co + k) >> 1]; v[k] += ((co + k) & 1) ? bfhi(w) : bflo(w); }
   }
   if (p.colsum) {
 #pragma unroll
@@ -273,12 +269,17 @@ __device__ __forceinline__ void epi_cols(EpiLane& e, const GemmParams& p, const 
   }
 }
 // one output row (global row m): the lane's 8 values of it
-__device__ __forceinline__ void epi_row(EpiLane& e, const GemmParams& p, const float (&src)[8], int m) {
+// `prim` = the row's strip of the PRIMARY second operand (saved derivative when act == 3, else the residual): staged through
+// LDS by LDS-DMA when `staged`, else (narrow leading dimensions) loaded here; a residual next to act == 3 is always loaded here
+__device__ __forceinline__ void epi_row(EpiLane& e, const GemmParams& p, const float (&src)[8], int m, EpiStrip prim, bool staged) {
   if (m < p.M && e.ncol_ok) {
-    if (e.wide) epi_cols<8>(e, p, src, 0, m);
+    EpiStrip res_s = prim;
+    if (p.res && (p.act == 3 || !staged)) res_s = epi_load_strip(p.res, p.ldres, p.res_period ? (m % p.res_period) : m, e, p);
+    if (p.act == 3 && !staged) prim = epi_load_strip(p.aux, p.ldaux, m, e, p);
+    if (e.wide) epi_cols<8>(e, p, src, 0, m, prim, res_s);
     else {
-      epi_cols<4>(e, p, src, 0, m);
-      if (e.n + 4 < p.N) epi_cols<4>(e, p, src, 4, m);
+      epi_cols<4>(e, p, src, 0, m, prim, res_s);
+      if (e.n + 4 < p.N) epi_cols<4>(e, p, src, 4, m, prim, res_s);
     }
   }
 }
@@ -297,6 +298,13 @@ __device__ __forceinline__ void epi_flush_colsum(EpiLane& e, const GemmParams& p
     for (int q = 0; q < 8; ++q)
       if (e.n + q < p.N) unsafeAtomicAdd(&p.colsum[e.n + q], e.csum[q]);
   }
+}
+// per-wave LDS of the activation epilogue: general path = fp32 patch [32][WN+4] + 2 second-operand buffers [32][WN] bf16,
+// fast path = bias strip + 2 bf16 patches [32][WN*2+8 bytes]
+template <int WN> constexpr int epi_wave_lds() {
+  constexpr int general = 32 * (WN + 4) * 4 + 2 * 32 * WN * 2;
+  constexpr int fast = WN * 4 + 2 * 32 * (WN * 2 + 8);
+  return ((general > fast ? general : fast) + 15) & ~15;
 }
 // ---- general path: 32-row block of the wave tile -> wave-private fp32 LDS patch (4 consecutive columns = one ds_write_b128;
 // rows 272 B apart, so the 8 lanes of a store group and the 2 rows of a load group sit on disjoint banks)
@@ -433,8 +441,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     // The LDS pipe executes one wave's operations in order, so a wave-private patch needs no wait between writing it and
     // reading it back, and a patch can be rewritten as soon as the reads of its previous contents have been ISSUED.
     constexpr int LDP = WN + 4;
-    constexpr int WAVE_LDS = (32 * LDP * 4 > WN * 4 + 2 * 32 * (WN * 2 + 8)) ? 32 * LDP * 4 : WN * 4 + 2 * 32 * (WN * 2 + 8);
-    char* wave_lds = lds + wave * ((WAVE_LDS + 15) & ~15);
+    char* wave_lds = lds + wave * epi_wave_lds<WN>();
     const bool fast = !p.res && p.act != 3 && !p.colsum && !p.out_f32 && !p.drop_thresh && p.wide_ok && (p.N % 8 == 0);
     if (fast) {
       if (p.act == 0) epi_fast<TM, TN, WN, 0>(p, acc, wave_lds, lane, row0, col0);
@@ -442,31 +449,69 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
       else epi_fast<TM, TN, WN, 2>(p, acc, wave_lds, lane, row0, col0);
       return;
     }
-    // general path: per 32-row block: request the rows of patch i (8-column strips), queue the writes of block i+1 behind
-    // them, then do the arithmetic and the global accesses of block i while those writes drain
+    // general path, per 32-row block i: wait for the second operand of block i (LDS-DMA issued two blocks earlier: global ->
+    // LDS, no registers, lane l's 16 bytes land at buffer + 16 l, exactly its row strip), request it and the rows of patch i
+    // from LDS, start the DMA of block i+2 into the buffer just read, queue the patch writes of block i+1, then do the
+    // arithmetic and the global stores of block i.
     constexpr int LPR = WN / 8;          // lanes per row
-    constexpr int RPI = 64 / LPR;        // rows per iteration
+    constexpr int RPI = 64 / LPR;        // rows per iteration = rows per DMA instruction
     constexpr int IT = 32 / RPI;
     float* patch = (float*)wave_lds;
+    char* opbuf = wave_lds + 32 * LDP * 4;
+    constexpr int OPB = 32 * WN * 2;     // one buffer: 32 rows of the operand
     EpiLane e;
     epi_setup<WN>(e, p, lane, col0);
+    const bf16_t* prim_ptr = (p.act == 3) ? p.aux : p.res;
+    const int prim_ld = (p.act == 3) ? p.ldaux : p.ldres;
+    const int prim_period = (p.act == 3) ? 0 : p.res_period;
+    const bool staged = prim_ptr != nullptr && p.wide_ok && (p.N % 8 == 0);
+    __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)prim_ptr, 0, 0xFFFFFFF0u, 0x00020000);
+    const int rl = lane / LPR;
+    auto dma_block = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+      for (int itr = 0; itr < IT; ++itr) {
+        const int m = row0 + i * 32 + itr * RPI + rl;
+        const int mr = prim_period ? (m % prim_period) : m;
+        uint32_t off = (uint32_t)(((size_t)mr * (size_t)prim_ld + (size_t)e.n) * 2);
+        if (m >= p.M || !e.ncol_ok) off = 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, AVT_LDS_PTR(opbuf + (i & 1) * OPB + itr * 1024), 16, off, 0, 0, 0);
+      }
+    };
+    if (staged) { dma_block(0); if (TM > 1) dma_block(1); }
     epi_write_block<TN, WN>(patch, epi_take<TM, TN, 0>(acc), lane);
 #pragma unroll 1
     for (int i = 0; i < TM; ++i) {
+      // outstanding VMEM operations issued after DMA(i), counting one store per row strip (more stores only make the wait
+      // stricter than needed): i = 0: DMA(1);  i = 1: DMA(2), stores(0);  i >= 2: stores(i-2), DMA(i+1), stores(i-1)
+      if (staged) {
+        switch (i) {
+          case 0: if (TM > 1) wait_vmcnt<IT>(); else wait_vmcnt<0>(); break;
+          case 1: if (TM > 2) wait_vmcnt<2 * IT>(); else wait_vmcnt<IT>(); break;
+          case 2: if (TM > 3) wait_vmcnt<3 * IT>(); else wait_vmcnt<2 * IT>(); break;
+          default: wait_vmcnt<2 * IT>(); break;
+        }
+      }
       float rows[IT][8];
+      EpiStrip prim[IT];
 #pragma unroll
       for (int itr = 0; itr < IT; ++itr) {
-        const float* src = patch + (itr * RPI + lane / LPR) * LDP + e.cl;
+        const float* src = patch + (itr * RPI + rl) * LDP + e.cl;
         f32x4_t lo = *(const f32x4_t*)src, hi = *(const f32x4_t*)(src + 4);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { rows[itr][k] = lo[k]; rows[itr][4 + k] = hi[k]; }
+        prim[itr].w = (u32x4_t){0u, 0u, 0u, 0u};
+        if (staged) prim[itr].w = *(const u32x4_t*)(opbuf + (i & 1) * OPB + itr * 1024 + lane * 16);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (staged && i + 2 < TM) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer's previous contents are in registers
+        dma_block(i + 2);
+      }
       if (i + 1 < TM) epi_write_block_i<TM, TN, WN>(patch, acc, i + 1, lane);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int itr = 0; itr < IT; ++itr)
-        epi_row(e, p, rows[itr], row0 + i * 32 + itr * RPI + lane / LPR);
+        epi_row(e, p, rows[itr], row0 + i * 32 + itr * RPI + rl, prim[itr], staged);
     }
     epi_flush_colsum<WN>(e, p, lane);
   }
@@ -697,9 +742,7 @@ static int pick_splitk(long tiles, int nk, int blocks_per_cu, int kmin) {
 template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, int PR = 0>
 constexpr int lds_bytes(int epi) {
   constexpr int ring = NSTAGE * (BM + BN) * BK * 2;
-  constexpr int TM = BM / WGM / 32;
-  constexpr int PRR = PR ? PR : (TM >= 2 ? 64 : 32);
-  constexpr int patch = WGM * WGN * PRR * (BN / WGN) * 4;
+  constexpr int patch = WGM * WGN * epi_wave_lds<BN / WGN>();
   return (epi == 0 && patch > ring) ? patch : ring;
 }
 
@@ -890,7 +933,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
 template <bool AK, bool BK_, int EPI, int ABL = 0>
 int launch_pp(const GemmParams& p, hipStream_t s) {
   int grid = p.tiles_m * p.tiles_n * p.splitk;
-  constexpr int smem = 2 * (256 + 256) * 64 * 2;       // 128 KiB ring == 8 waves x 16 KiB epilogue patches
+  constexpr int smem = (EPI == 0 && 8 * epi_wave_lds<64>() > 2 * (256 + 256) * 64 * 2) ? 8 * epi_wave_lds<64>() : 2 * (256 + 256) * 64 * 2;   // 128 KiB ring | epilogue patches
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AK, BK_, EPI, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1239,7 +1282,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
 template <bool AK, bool BK_, int EPI>
 int launch_8p(const GemmParams& p, hipStream_t s) {
   int grid = p.tiles_m * p.tiles_n * p.splitk;
-  constexpr int smem = 8 * 128 * 64 * 2;               // 128 KiB ring == 8 waves x 16 KiB epilogue patches
+  constexpr int smem = (EPI == 0 && 8 * epi_wave_lds<64>() > 8 * 128 * 64 * 2) ? 8 * epi_wave_lds<64>() : 8 * 128 * 64 * 2;   // 128 KiB ring | 132 KiB epilogue
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_8p_kernel<AK, BK_, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
