@@ -300,10 +300,10 @@ __device__ __forceinline__ void epi_flush_colsum(EpiLane& e, const GemmParams& p
   }
 }
 // per-wave LDS of the activation epilogue: general path = fp32 patch [32][WN+4] + 2 second-operand buffers [32][WN] bf16,
-// fast path = bias strip + 2 bf16 patches [32][WN*2+8 bytes]
+// fast path = bias strip + 2 bf16 patches [32][WN*2+8 bytes] + 2 second-operand buffers [32][WN] bf16
 template <int WN> constexpr int epi_wave_lds() {
   constexpr int general = 32 * (WN + 4) * 4 + 2 * 32 * WN * 2;
-  constexpr int fast = WN * 4 + 2 * 32 * (WN * 2 + 8);
+  constexpr int fast = WN * 4 + 2 * 32 * (WN * 2 + 8) + 2 * 32 * WN * 2;     // + 2 second-operand buffers
   return ((general > fast ? general : fast) + 15) & ~15;
 }
 // ---- general path: 32-row block of the wave tile -> wave-private fp32 LDS patch (4 consecutive columns = one ds_write_b128;
@@ -417,6 +417,141 @@ __device__ __forceinline__ void epi_fast(const GemmParams& p, const f32x16_t (&a
   }
 }
 
+// ---- extended fast path: the same register-layout arithmetic plus everything that needs a second operand or an index:
+//   v = acc + bias;  act 3: v *= aux;  act 1|2: GELU (+ GELU' -> C2);  act 0 with C2: C2 = v;  dropout;  v += res;
+//   column sums;  C = bf16(v)
+// The second operand (aux when act == 3, else res) of block i is brought in by LDS-DMA two blocks ahead.  LDS-DMA lands
+// lane L's 16 bytes at buffer + 16 L, so the layout is chosen through the SOURCE address: position (row r, chunk pc) holds
+// chunk pc ^ ((r >> 1) & (LPR-1)) of row r, which makes the 8-byte reads of the accumulator layout (32 lanes = 32 rows, same
+// column) at most 2-way bank conflicted.  Column sums (bias gradients) are taken over the bf16-rounded outputs on their way
+// out (row-strip layout: 8 running sums per lane, folded across the lanes that share columns once per tile).
+template <int TM, int TN, int WN, int ACT>
+__device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t (&acc)[TM][TN], char* wave_lds, int lane, int row0, int col0) {
+  constexpr int LDB = WN * 2 + 8;
+  constexpr int LPR = WN / 8, RPI = 64 / LPR, IT = 32 / RPI;
+  constexpr int OPB = 32 * WN * 2;
+  float* bias_l = (float*)wave_lds;
+  char* patch_c = wave_lds + WN * 4;
+  char* patch_d = patch_c + 32 * LDB;
+  char* opbuf = patch_d + 32 * LDB;
+  if (lane < WN) bias_l[lane] = (p.bias && col0 + lane < p.N) ? p.bias[col0 + lane] : 0.f;
+  const int ml = lane & 31, h = lane >> 5;
+  const int rl = lane / LPR, pc = lane % LPR, cl = pc * 8;
+  const bf16_t* prim_ptr = (ACT == 3) ? p.aux : p.res;
+  const int prim_ld = (ACT == 3) ? p.ldaux : p.ldres;
+  const int prim_period = (ACT == 3) ? 0 : p.res_period;
+  const bool has_prim = prim_ptr != nullptr;
+  __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)prim_ptr, 0, 0xFFFFFFF0u, 0x00020000);
+  auto dma_block = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+    for (int itr = 0; itr < IT; ++itr) {
+      const int r = itr * RPI + rl;
+      const int m = row0 + i * 32 + r;
+      const int n = col0 + ((pc ^ ((r >> 1) & (LPR - 1))) * 8);
+      const int mr = prim_period ? (m % prim_period) : m;
+      uint32_t off = (uint32_t)(((size_t)mr * (size_t)prim_ld + (size_t)n) * 2);
+      if (m >= p.M || n >= p.N) off = 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, AVT_LDS_PTR(opbuf + (i & 1) * OPB + itr * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  if (has_prim) { dma_block(0); if (TM > 1) dma_block(1); }
+  float cs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cs[k] = 0.f;
+#pragma unroll 1
+  for (int i = 0; i < TM; ++i) {
+    EpiBlk<TN> b;
+    switch (i) {
+      case 0: b = epi_take<TM, TN, 0>(acc); break;
+      case 1: b = epi_take<TM, TN, 1>(acc); break;
+      case 2: b = epi_take<TM, TN, 2>(acc); break;
+      default: b = epi_take<TM, TN, 3>(acc); break;
+    }
+    if (has_prim) {          // see the general path for the counts
+      switch (i) {
+        case 0: if (TM > 1) wait_vmcnt<IT>(); else wait_vmcnt<0>(); break;
+        case 1: if (TM > 2) wait_vmcnt<2 * IT>(); else wait_vmcnt<IT>(); break;
+        case 2: if (TM > 3) wait_vmcnt<3 * IT>(); else wait_vmcnt<2 * IT>(); break;
+        default: wait_vmcnt<2 * IT>(); break;
+      }
+    }
+    const int m = row0 + i * 32 + ml;
+    u32x2_t opv[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        opv[j][q] = (u32x2_t){0u, 0u};
+        if (has_prim) opv[j][q] = *(const u32x2_t*)(opbuf + (i & 1) * OPB + ml * (WN * 2) + (((j * 4 + q) ^ ((ml >> 1) & (LPR - 1))) * 16) + h * 8);
+      }
+    if (has_prim && i + 2 < TM) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer's previous contents are in registers
+      dma_block(i + 2);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nl = j * 32 + 8 * q + 4 * h;
+        const f32x4_t bb = *(const f32x4_t*)(bias_l + nl);
+        f32x2_t v0 = (f32x2_t){b.t[j][4 * q], b.t[j][4 * q + 1]} + (f32x2_t){bb[0], bb[1]};
+        f32x2_t v1 = (f32x2_t){b.t[j][4 * q + 2], b.t[j][4 * q + 3]} + (f32x2_t){bb[2], bb[3]};
+        const f32x2_t o0 = (f32x2_t){bflo(opv[j][q][0]), bfhi(opv[j][q][0])}, o1 = (f32x2_t){bflo(opv[j][q][1]), bfhi(opv[j][q][1])};
+        if (ACT == 3) { v0 *= o0; v1 *= o1; }
+        if (ACT == 1 || ACT == 2) {
+          f32x2_t d0, d1;
+          if (ACT == 1) { gelu_erf_both2(v0, v0, d0); gelu_erf_both2(v1, v1, d1); }
+          else {
+            float y4[4], d4[4];
+            gelu_tanh_both(v0[0], y4[0], d4[0]); gelu_tanh_both(v0[1], y4[1], d4[1]);
+            gelu_tanh_both(v1[0], y4[2], d4[2]); gelu_tanh_both(v1[1], y4[3], d4[3]);
+            v0 = (f32x2_t){y4[0], y4[1]}; v1 = (f32x2_t){y4[2], y4[3]}; d0 = (f32x2_t){d4[0], d4[1]}; d1 = (f32x2_t){d4[2], d4[3]};
+          }
+          if (p.C2) *(u32x2_t*)(patch_d + ml * LDB + nl * 2) = (u32x2_t){pack2bf(d0[0], d0[1]), pack2bf(d1[0], d1[1])};
+        } else if (p.C2) {
+          *(u32x2_t*)(patch_d + ml * LDB + nl * 2) = (u32x2_t){pack2bf(v0[0], v0[1]), pack2bf(v1[0], v1[1])};
+        }
+        if (p.drop_thresh) {
+          const uint64_t idx = (uint64_t)m * (uint64_t)p.N + (uint64_t)(col0 + nl);
+          v0[0] = drop_keep(p.drop_seed, idx, p.drop_thresh) ? v0[0] * p.drop_scale : 0.f;
+          v0[1] = drop_keep(p.drop_seed, idx + 1, p.drop_thresh) ? v0[1] * p.drop_scale : 0.f;
+          v1[0] = drop_keep(p.drop_seed, idx + 2, p.drop_thresh) ? v1[0] * p.drop_scale : 0.f;
+          v1[1] = drop_keep(p.drop_seed, idx + 3, p.drop_thresh) ? v1[1] * p.drop_scale : 0.f;
+        }
+        if (ACT != 3 && has_prim) { v0 += o0; v1 += o1; }
+        *(u32x2_t*)(patch_c + ml * LDB + nl * 2) = (u32x2_t){pack2bf(v0[0], v0[1]), pack2bf(v1[0], v1[1])};
+      }
+    const int n = col0 + cl;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int row = it * RPI + rl, mm = row0 + i * 32 + row;
+      const char* src = patch_c + row * LDB + cl * 2;
+      u32x2_t lo = *(const u32x2_t*)src, hi = *(const u32x2_t*)(src + 8);
+      u32x2_t lo2 = lo, hi2 = hi;
+      if (p.C2) { const char* s2 = patch_d + row * LDB + cl * 2; lo2 = *(const u32x2_t*)s2; hi2 = *(const u32x2_t*)(s2 + 8); }
+      if (mm < p.M && n < p.N) {
+        *(u32x4_t*)((bf16_t*)p.C + (size_t)mm * p.ldc + n) = (u32x4_t){lo[0], lo[1], hi[0], hi[1]};
+        if (p.C2) *(u32x4_t*)(p.C2 + (size_t)mm * p.ldc2 + n) = (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]};
+        if (p.colsum) {
+          cs[0] += bflo(lo[0]); cs[1] += bfhi(lo[0]); cs[2] += bflo(lo[1]); cs[3] += bfhi(lo[1]);
+          cs[4] += bflo(hi[0]); cs[5] += bfhi(hi[0]); cs[6] += bflo(hi[1]); cs[7] += bfhi(hi[1]);
+        }
+      }
+    }
+  }
+  if (p.colsum) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
+    }
+    if (lane < LPR && col0 + cl < p.N) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) unsafeAtomicAdd(&p.colsum[col0 + cl + q], cs[q]);
+    }
+  }
+}
+
 template <int TM, int TN, int WM, int WN, int EPI, int PR = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[TM][TN], char* lds, int wave, int lane,
                                               int row0, int col0) {
@@ -442,11 +577,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     // reading it back, and a patch can be rewritten as soon as the reads of its previous contents have been ISSUED.
     constexpr int LDP = WN + 4;
     char* wave_lds = lds + wave * epi_wave_lds<WN>();
-    const bool fast = !p.res && p.act != 3 && !p.colsum && !p.out_f32 && !p.drop_thresh && p.wide_ok && (p.N % 8 == 0);
-    if (fast) {
-      if (p.act == 0) epi_fast<TM, TN, WN, 0>(p, acc, wave_lds, lane, row0, col0);
-      else if (p.act == 1) epi_fast<TM, TN, WN, 1>(p, acc, wave_lds, lane, row0, col0);
-      else epi_fast<TM, TN, WN, 2>(p, acc, wave_lds, lane, row0, col0);
+    const bool fast_ok = !p.out_f32 && p.wide_ok && (p.N % 8 == 0) && !(p.act == 3 && p.res);
+    if (fast_ok) {
+      const bool extra = p.res || p.act == 3 || p.colsum || p.drop_thresh;
+      if (!extra) {
+        if (p.act == 0) epi_fast<TM, TN, WN, 0>(p, acc, wave_lds, lane, row0, col0);
+        else if (p.act == 1) epi_fast<TM, TN, WN, 1>(p, acc, wave_lds, lane, row0, col0);
+        else epi_fast<TM, TN, WN, 2>(p, acc, wave_lds, lane, row0, col0);
+      } else {
+        if (p.act == 3) epi_fast_ext<TM, TN, WN, 3>(p, acc, wave_lds, lane, row0, col0);
+        else if (p.act == 0) epi_fast_ext<TM, TN, WN, 0>(p, acc, wave_lds, lane, row0, col0);
+        else if (p.act == 1) epi_fast_ext<TM, TN, WN, 1>(p, acc, wave_lds, lane, row0, col0);
+        else epi_fast_ext<TM, TN, WN, 2>(p, acc, wave_lds, lane, row0, col0);
+      }
       return;
     }
     // general path, per 32-row block i: wait for the second operand of block i (LDS-DMA issued two blocks earlier: global ->
