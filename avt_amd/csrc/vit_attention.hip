@@ -190,184 +190,231 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   }
 }
 
+// Backward: persistent workgroups (one per CU -- the four operand tiles of a head take 112 KB of LDS), each walking over
+// (frame, head) items.  Per item:
+//     barrier 1 (everyone is done with the previous item; K/V of this item -- requested during the previous item's phase B --
+//                have landed)  ->  request Q, dO (LDS-DMA) and fetch this wave's own Q / dO / O strips from global
+//     phase A: dQ of this wave's 16 queries (needs the K, V tiles + own strips)
+//     barrier 2 (Q, dO landed; nobody reads K/V tiles any more)  ->  request K, V of the NEXT item
+//     phase B: dK, dV of this wave's 16 keys (needs the Q, dO tiles + own K / V strips, taken before barrier 2)
+// so the global -> LDS latency of every tile hides behind the other phase.  Column sums of dq|dk|dv (the qkv bias gradient)
+// are kept in LDS per head for the whole kernel and flushed once.
 template <int NKT>
 __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                 const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                 bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
-                                                                int S, int H, float scale, long long* dbg) {
-  long long tc0 = dbg ? __builtin_readcyclecounter() : 0, tc1 = 0, tc2 = 0;
+                                                                int S, int H, int items, float scale, long long* dbg) {
+  long long tcs = 0, tca = 0, tcb = 0, tc0 = dbg ? __builtin_readcyclecounter() : 0;
   constexpr int NP = (NKT + 1) / 2;
   constexpr int KP = NP * 32;                // rows of every LDS tile (zero padded)
   constexpr int RM = KP * 128;               // bytes of a row-major [KP][64] bf16 tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // Q, K, V, dO of this (frame, head), all swizzled row-major; operands that a product needs "transposed" are gathered
+  // Q, K, V, dO of one (frame, head), all swizzled row-major; operands that a product needs "transposed" are gathered
   // with ds_read_b64_tr_b16 (frag_tr_rm), so no transposed copy is built.  Zero padding of rows >= S makes every
   // padded key / query contribute exactly zero to dQ, dK, dV (no masks in the inner loops).
   char* Qs = smem;
   char* Ks = smem + RM;
   char* Vs = smem + 2 * RM;
   char* dOs = smem + 3 * RM;
-  float* lse_s = (float*)(smem + 4 * RM);
-  float* dq_s = lse_s + KP;                  // D[q] = sum_d dO[q,d] O[q,d]
-  float* bias_s = dq_s + KP;                 // [3*64] column sums of dq | dk | dv
+  float* lse_s = (float*)(smem + 4 * RM);    // lse * log2(e)
+  float* dq_s = lse_s + KP;                  // D[q] * scale,  D[q] = sum_d dO[q,d] O[q,d]
+  float* bias_s = dq_s + KP;                 // [H][3*64] column sums of dq | dk | dv
   const int D = H * HD, ld = 3 * D;
-  const int frame = blockIdx.x / H, head = blockIdx.x % H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = 64 * NKT;
   const int g = lane >> 4;
-  const size_t row0 = (size_t)frame * S;
-  const bf16_t* base = qkv + row0 * ld + head * HD;
-  const bf16_t* obase = out + row0 * D + head * HD;
-  const bf16_t* dobase = dout + row0 * D + head * HD;
-  bf16_t* dbase = dqkv + row0 * ld + head * HD;
-  const float* lse_g = lse + ((size_t)frame * H + head) * S;
-
-  for (int i = tid; i < KP; i += nthr) lse_s[i] = (i < S) ? lse_g[i] * LOG2E : 0.f;      // stored pre-multiplied by log2(e)
-  for (int i = tid; i < 192; i += nthr) bias_s[i] = 0.f;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  stage_head_dma(base, ld, S, Qs, KP, wv, NKT, lane);
-  stage_head_dma(base + D, ld, S, Ks, KP, wv, NKT, lane);
-  stage_head_dma(base + 2 * D, ld, S, Vs, KP, wv, NKT, lane);
-  stage_head_dma(dobase, D, S, dOs, KP, wv, NKT, lane);
-  // D[q] for this wave's strip: dO rows from LDS would need the barrier first, so read them from global here
-  {
-    const int q0 = wave * 16, q = q0 + (lane & 15);
-    bf16x8_t bdo[2], bo[2];
-    load_strip(dobase, D, S, q0, lane, bdo);
-    load_strip(obase, D, S, q0, lane, bo);
-    float dsum = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dsum += (float)bdo[ks][e] * (float)bo[ks][e];
-    dsum = gsum(dsum);
-    if (g == 0) dq_s[q] = dsum * scale;      // stored pre-multiplied by `scale`; q < NKT*16 <= KP
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (dbg) tc1 = __builtin_readcyclecounter();
+  const float sl = scale * LOG2E;
 
-  // ---------------- phase A: this wave's 16-query strip -> dQ ------------------------------------------------------
-  {
-    const int q0 = wave * 16, q = q0 + (lane & 15);
-    bf16x8_t bq[2], bdo[2];                  // B operands: lane (j = q, g) holds X[q][ks*32 + g*8 ..]
-    bq[0] = frag_rm(Qs, wave, 0, lane); bq[1] = frag_rm(Qs, wave, 1, lane);
-    bdo[0] = frag_rm(dOs, wave, 0, lane); bdo[1] = frag_rm(dOs, wave, 1, lane);
-    const float sl = scale * LOG2E;
-    const float dss = dq_s[q], lq2 = lse_s[q];          // folded constants: p = exp2(s*sl - lq2), ds = p*(dp*scale - dss)
-    f32x4_t acc[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < NP; ++t) {
-      f32x4_t dsv[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int kt = 2 * t + u;
-        dsv[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (kt < NKT) {
-          f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s = mfma16(frag_rm(Ks, kt, 0, lane), bq[0], s);
-          s = mfma16(frag_rm(Ks, kt, 1, lane), bq[1], s);
-          dp = mfma16(frag_rm(Vs, kt, 0, lane), bdo[0], dp);
-          dp = mfma16(frag_rm(Vs, kt, 1, lane), bdo[1], dp);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dsv[u][r] = __builtin_amdgcn_exp2f(fmaf(s[r], sl, -lq2)) * fmaf(dp[r], scale, -dss);
-        }
-      }
-      bf16x8_t b = pack_pair(dsv[0], dsv[1]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(frag_tr_rm(Ks, dt, t, lane), b, acc[dt]);
-    }
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      if (q < S) {
-        u32x2_t w; w[0] = pack2bf(acc[dt][0], acc[dt][1]); w[1] = pack2bf(acc[dt][2], acc[dt][3]);
-        *(u32x2_t*)(dbase + (size_t)q * ld + dt * 16 + 4 * g) = w;
-      }
-      if (dbias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = lsum16((q < S) ? acc[dt][r] : 0.f);
-          if ((lane & 15) == 0) atomicAdd(&bias_s[dt * 16 + 4 * g + r], v);
-        }
-      }
-    }
+  if (dbias) for (int i = tid; i < H * 192; i += nthr) bias_s[i] = 0.f;
+  int item = blockIdx.x;
+  const int q0 = wave * 16, q = q0 + (lane & 15);
+  // this wave's own Q / dO / O strips and lse of the NEXT item are fetched (to registers) at the end of phase B of the current one
+  bf16x8_t nq[2], ndo[2], no[2];
+  float nlq = 0.f;
+  auto fetch_strips = [&](int it) __attribute__((always_inline)) {
+    const int fr = it / H, hd = it % H;
+    const size_t r0 = (size_t)fr * S;
+    load_strip(qkv + r0 * ld + hd * HD, ld, S, q0, lane, nq);
+    load_strip(dout + r0 * D + hd * HD, D, S, q0, lane, ndo);
+    load_strip(out + r0 * D + hd * HD, D, S, q0, lane, no);
+    nlq = (q < S) ? lse[((size_t)fr * H + hd) * S + q] * LOG2E : 0.f;
+  };
+  if (item < items) {
+    const bf16_t* base = qkv + (size_t)(item / H) * S * ld + (item % H) * HD;
+    stage_head_dma(base + D, ld, S, Ks, KP, wv, NKT, lane);
+    stage_head_dma(base + 2 * D, ld, S, Vs, KP, wv, NKT, lane);
+    fetch_strips(item);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  if (dbg) tc2 = __builtin_readcyclecounter();
-  // ---------------- phase B: this wave's 16-key strip -> dK, dV (no barrier needed: LDS tiles are read-only) --------
-  {
-    const int key = wave * 16 + (lane & 15);
-    const float slb = scale * LOG2E;
-    bf16x8_t bk[2], bv[2];
-    bk[0] = frag_rm(Ks, wave, 0, lane); bk[1] = frag_rm(Ks, wave, 1, lane);
-    bv[0] = frag_rm(Vs, wave, 0, lane); bv[1] = frag_rm(Vs, wave, 1, lane);
-    f32x4_t adk[4], adv[4];
+  for (; item < items; item += gridDim.x) {
+    // per-lane offsets are cheap to recompute; hide the lane id from loop-invariant code motion so that they are not all
+    // kept in registers across the item loop (the kernel runs 13 waves = 128 VGPRs per lane)
+    int lane_i = lane;
+    asm volatile("" : "+v"(lane_i));
+#define lane lane_i
+    const int frame = item / H, head = item % H;
+    const size_t row0 = (size_t)frame * S;
+    const bf16_t* base = qkv + row0 * ld + head * HD;
+    const bf16_t* dobase = dout + row0 * D + head * HD;
+    bf16_t* dbase = dqkv + row0 * ld + head * HD;
+    const float* lse_g = lse + ((size_t)frame * H + head) * S;
+    float* bias_h = bias_s + head * 192;
+
+    // K, V of this item have landed once all but the youngest 15 vector-memory operations of this wave are done: after their
+    // LDS-DMA requests came the 7 strip loads and the 8 dK / dV stores of the previous item (nothing younger at the first item)
+    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    __syncthreads();                                       // barrier 1
+    stage_head_dma(base, ld, S, Qs, KP, wv, NKT, lane);
+    stage_head_dma(dobase, D, S, dOs, KP, wv, NKT, lane);
+    for (int i = tid; i < KP; i += nthr) lse_s[i] = (i < S) ? lse_g[i] * LOG2E : 0.f;
+    bf16x8_t bq[2], bdo[2];                  // B operands: lane (j = q, g) holds X[q][ks*32 + g*8 ..]
+    float dss, lq2;
+    {
+      bq[0] = nq[0]; bq[1] = nq[1]; bdo[0] = ndo[0]; bdo[1] = ndo[1];
+      lq2 = nlq;
+      float dsum = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-    for (int t = 0; t < NP; ++t) {
-      f32x4_t pv2[2], ds2[2];
+        for (int e = 0; e < 8; ++e) dsum += (float)bdo[ks][e] * (float)no[ks][e];
+      dss = gsum(dsum) * scale;
+      if (g == 0) dq_s[q] = dss;             // q < NKT*16 <= KP
+    }
+    if (dbg) { long long t = __builtin_readcyclecounter(); tcs += t - tc0; tc0 = t; }
+
+    // ---------------- phase A: this wave's 16-query strip -> dQ ------------------------------------------------------
+    {
+      f32x4_t acc[4];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int qt = 2 * t + u;
-        pv2[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        ds2[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (qt < NKT) {
-          f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s = mfma16(frag_rm(Qs, qt, 0, lane), bk[0], s);
-          s = mfma16(frag_rm(Qs, qt, 1, lane), bk[1], s);
-          dp = mfma16(frag_rm(dOs, qt, 0, lane), bv[0], dp);
-          dp = mfma16(frag_rm(dOs, qt, 1, lane), bv[1], dp);
-          const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g);      // pre-scaled by log2(e)
-          const f32x4_t d4 = *(const f32x4_t*)(dq_s + qt * 16 + 4 * g);       // pre-scaled by `scale`
+      for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        f32x4_t dsv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int kt = 2 * t + u;
+          dsv[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          if (kt < NKT) {
+            f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            s = mfma16(frag_rm(Ks, kt, 0, lane), bq[0], s);
+            s = mfma16(frag_rm(Ks, kt, 1, lane), bq[1], s);
+            dp = mfma16(frag_rm(Vs, kt, 0, lane), bdo[0], dp);
+            dp = mfma16(frag_rm(Vs, kt, 1, lane), bdo[1], dp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dsv[u][r] = __builtin_amdgcn_exp2f(fmaf(s[r], sl, -lq2)) * fmaf(dp[r], scale, -dss);
+          }
+        }
+        bf16x8_t b = pack_pair(dsv[0], dsv[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(frag_tr_rm(Ks, dt, t, lane), b, acc[dt]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        if (q < S) {
+          u32x2_t w; w[0] = pack2bf(acc[dt][0], acc[dt][1]); w[1] = pack2bf(acc[dt][2], acc[dt][3]);
+          *(u32x2_t*)(dbase + (size_t)q * ld + dt * 16 + 4 * g) = w;
+        }
+        if (dbias) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float p = __builtin_amdgcn_exp2f(fmaf(s[r], slb, -l4[r]));
-            pv2[u][r] = p;
-            ds2[u][r] = p * fmaf(dp[r], scale, -d4[r]);
+            float v = lsum16((q < S) ? acc[dt][r] : 0.f);
+            if ((lane & 15) == 0) atomicAdd(&bias_h[dt * 16 + 4 * g + r], v);
           }
         }
       }
-      bf16x8_t bp = pack_pair(pv2[0], pv2[1]);
-      bf16x8_t bd = pack_pair(ds2[0], ds2[1]);
+    }
+    // own K / V strips for phase B, taken before the tiles are handed to the next item's prefetch
+    bf16x8_t bk[2], bv[2];
+    bk[0] = frag_rm(Ks, wave, 0, lane); bk[1] = frag_rm(Ks, wave, 1, lane);
+    bv[0] = frag_rm(Vs, wave, 0, lane); bv[1] = frag_rm(Vs, wave, 1, lane);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // Q, dO landed (this wave's share); strips are in registers
+    __syncthreads();                                                // barrier 2
+    if (item + gridDim.x < items) {
+      const int nitem = item + gridDim.x;
+      const bf16_t* nbase = qkv + (size_t)(nitem / H) * S * ld + (nitem % H) * HD;
+      stage_head_dma(nbase + D, ld, S, Ks, KP, wv, NKT, lane);
+      stage_head_dma(nbase + 2 * D, ld, S, Vs, KP, wv, NKT, lane);
+    }
+    if (dbg) { long long t = __builtin_readcyclecounter(); tca += t - tc0; tc0 = t; }
+    // ---------------- phase B: this wave's 16-key strip -> dK, dV ----------------------------------------------------
+    {
+      const int key = wave * 16 + (lane & 15);
+      f32x4_t adk[4], adv[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        f32x4_t pv2[2], ds2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int qt = 2 * t + u;
+          pv2[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          ds2[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+          if (qt < NKT) {
+            f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            s = mfma16(frag_rm(Qs, qt, 0, lane), bk[0], s);
+            s = mfma16(frag_rm(Qs, qt, 1, lane), bk[1], s);
+            dp = mfma16(frag_rm(dOs, qt, 0, lane), bv[0], dp);
+            dp = mfma16(frag_rm(dOs, qt, 1, lane), bv[1], dp);
+            const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g);      // pre-scaled by log2(e)
+            const f32x4_t d4 = *(const f32x4_t*)(dq_s + qt * 16 + 4 * g);       // pre-scaled by `scale`
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl, -l4[r]));
+              pv2[u][r] = p;
+              ds2[u][r] = p * fmaf(dp[r], scale, -d4[r]);
+            }
+          }
+        }
+        bf16x8_t bp = pack_pair(pv2[0], pv2[1]);
+        bf16x8_t bd = pack_pair(ds2[0], ds2[1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          adv[dt] = mfma16(frag_tr_rm(dOs, dt, t, lane), bp, adv[dt]);
+          adk[dt] = mfma16(frag_tr_rm(Qs, dt, t, lane), bd, adk[dt]);
+        }
+      }
+      // next item's strips: requested here, after the register-hungry loop, and hidden behind the stores and barrier 1
+      fetch_strips(item + gridDim.x < items ? item + gridDim.x : item);     // unconditional (re-fetches this item at the end): keeps the strips' live ranges short
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        adv[dt] = mfma16(frag_tr_rm(dOs, dt, t, lane), bp, adv[dt]);
-        adk[dt] = mfma16(frag_tr_rm(Qs, dt, t, lane), bd, adk[dt]);
-      }
-    }
+        if (key < S) {
+          u32x2_t w; w[0] = pack2bf(adk[dt][0], adk[dt][1]); w[1] = pack2bf(adk[dt][2], adk[dt][3]);
+          *(u32x2_t*)(dbase + (size_t)key * ld + D + dt * 16 + 4 * g) = w;
+          u32x2_t x; x[0] = pack2bf(adv[dt][0], adv[dt][1]); x[1] = pack2bf(adv[dt][2], adv[dt][3]);
+          *(u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g) = x;
+        }
+        if (dbias) {
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      if (key < S) {
-        u32x2_t w; w[0] = pack2bf(adk[dt][0], adk[dt][1]); w[1] = pack2bf(adk[dt][2], adk[dt][3]);
-        *(u32x2_t*)(dbase + (size_t)key * ld + D + dt * 16 + 4 * g) = w;
-        u32x2_t x; x[0] = pack2bf(adv[dt][0], adv[dt][1]); x[1] = pack2bf(adv[dt][2], adv[dt][3]);
-        *(u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g) = x;
-      }
-      if (dbias) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float vk = lsum16((key < S) ? adk[dt][r] : 0.f);
-          float vv = lsum16((key < S) ? adv[dt][r] : 0.f);
-          if ((lane & 15) == 0) { atomicAdd(&bias_s[64 + dt * 16 + 4 * g + r], vk); atomicAdd(&bias_s[128 + dt * 16 + 4 * g + r], vv); }
+          for (int r = 0; r < 4; ++r) {
+            float vk = lsum16((key < S) ? adk[dt][r] : 0.f);
+            float vv = lsum16((key < S) ? adv[dt][r] : 0.f);
+            if ((lane & 15) == 0) { atomicAdd(&bias_h[64 + dt * 16 + 4 * g + r], vk); atomicAdd(&bias_h[128 + dt * 16 + 4 * g + r], vv); }
+          }
         }
       }
     }
+    if (dbg) { long long t = __builtin_readcyclecounter(); tcb += t - tc0; tc0 = t; }
+#undef lane
   }
   if (dbias) {
     __syncthreads();
-    for (int i = tid; i < 192; i += nthr) unsafeAtomicAdd(&dbias[(i >> 6) * D + head * HD + (i & 63)], bias_s[i]);
+    for (int i = tid; i < H * 192; i += nthr) {
+      const int hh = i / 192, c = i % 192;
+      const float v = bias_s[i];
+      if (v != 0.f) unsafeAtomicAdd(&dbias[(c >> 6) * D + hh * HD + (c & 63)], v);
+    }
   }
   if (dbg && lane == 0) {
     long long* d = dbg + ((size_t)blockIdx.x * 16 + wave) * 4;
-    d[0] = tc1 - tc0; d[1] = tc2 - tc1; d[2] = __builtin_readcyclecounter() - tc2;
+    d[0] = tcs; d[1] = tca; d[2] = tcb; d[3] = (items - blockIdx.x + gridDim.x - 1) / gridDim.x;
   }
 }
 
 int pick_nkt(int S) { int n = (S + 15) / 16; if (n <= 1) return 1; if (n <= 2) return 2; if (n <= 4) return 4; if (n <= 8) return 8; return 13; }
 
 template <int NKT> size_t fwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)2 * NP * 32 * 128; }
-template <int NKT> size_t bwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128 + (2 * NP * 32 + 192) * 4; }
+template <int NKT> size_t bwd_smem(int H) { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128 + (size_t)(2 * NP * 32 + H * 192) * 4; }
 
 template <int NKT>
 int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, int H, float scale, hipStream_t s) {
@@ -380,12 +427,17 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, in
 template <int NKT>
 int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, float* dbias,
                int frames, int S, int H, float scale, hipStream_t s) {
-  size_t sm = bwd_smem<NKT>();
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
+  size_t sm = bwd_smem<NKT>(H);
+  if (sm > 160 * 1024) { avt_set_error("avt_vit_attn_bwd: H = %d needs more LDS than a CU has", H); return -1; }
+  (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   static const char* e = getenv("AVT_ATTN_DBG_PTR");
   long long* dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr;
-  hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT>), dim3(frames * H), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, S, H, scale, dbg);
+  const int items = frames * H;
+  // persistent: one workgroup per CU when the tiles of a head need most of the LDS, more for short sequences
+  const int per_cu = (int)((160 * 1024) / sm) < 1 ? 1 : (int)((160 * 1024) / sm);
+  int grid = 256 * (per_cu > 8 ? 8 : per_cu);
+  if (grid > items) grid = items;
+  hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT>), dim3(grid), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, S, H, items, scale, dbg);
   return 0;
 }
 
@@ -417,13 +469,15 @@ extern "C" int avt_vit_attn_bwd(const void* qkv, const void* out, const void* do
   AVT_CHECK(frames > 0 && H > 0 && aligned16(qkv) && aligned16(out) && aligned16(dout) && aligned16(dqkv), "avt_vit_attn_bwd: bad shape or alignment");
   hipStream_t s = (hipStream_t)stream;
   const bf16_t* q = (const bf16_t*)qkv; const bf16_t* o = (const bf16_t*)out; const bf16_t* d = (const bf16_t*)dout; bf16_t* dq = (bf16_t*)dqkv;
+  int rc = 0;
   switch (pick_nkt(S)) {
-    case 1: launch_bwd<1>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
-    case 2: launch_bwd<2>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
-    case 4: launch_bwd<4>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
-    case 8: launch_bwd<8>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
-    default: launch_bwd<13>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
+    case 1: rc = launch_bwd<1>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
+    case 2: rc = launch_bwd<2>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
+    case 4: rc = launch_bwd<4>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
+    case 8: rc = launch_bwd<8>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
+    default: rc = launch_bwd<13>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
   }
+  if (rc) return rc;
   AVT_LAUNCH_CHECK();
   return 0;
 }

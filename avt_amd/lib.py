@@ -8,7 +8,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libavt_hip.so')
+LIB_PATH = os.environ.get('AVT_HIP_LIB') or os.path.join(_HERE, 'libavt_hip.so')      # AVT_HIP_LIB: A/B a differently built library (lab use)
 ABI_VERSION = 1
 
 _P, _I, _F, _L, _U64 = c_void_p, c_int, c_float, c_long, c_uint64

@@ -9,6 +9,7 @@ qkv = (torch.rand((frames * S, 3 * H * 64), device='cuda') * 2 - 1).to(torch.bfl
 o, lse = ops.vit_attn_fwd(qkv, frames, S, H)
 for _ in range(2):
     ops.vit_attn_bwd(qkv, o, o, lse, frames, S, H); torch.cuda.synchronize()
-d = dbg.view(frames * H, 16, 4)[:, :13].double()
-print('per wave avg cycles: staging+D %.0f  phaseA %.0f  phaseB+store %.0f' % (d[..., 0].mean(), d[..., 1].mean(), d[..., 2].mean()))
-print('per block max over waves: staging %.0f  A %.0f  B %.0f' % (d[..., 0].max(1).values.mean(), d[..., 1].max(1).values.mean(), d[..., 2].max(1).values.mean()))
+nb = min(frames * H, 256)
+d = dbg.view(frames * H, 16, 4)[:nb, :13].double()
+n = d[..., 3].clamp(min=1)
+print('per item, per wave avg cycles: barrier1+strips %.0f  phaseA+barrier2 %.0f  phaseB+stores %.0f' % ((d[..., 0] / n).mean(), (d[..., 1] / n).mean(), (d[..., 2] / n).mean()))
