@@ -48,7 +48,9 @@ struct GemmParams {
 constexpr int BK64 = 64;
 
 // XCD-aware bijective remap of the linear block id: XCD x (= id % 8 by dispatch order) owns a contiguous
-// range of logical tiles, so tiles sharing an A row-panel sit behind the same L2.
+// range of logical blocks, ordered (split, tile row, tile column), so tiles sharing an A row-panel sit behind the same L2
+// and -- for split-K weight gradients -- an XCD works on one or two K ranges only, instead of pulling every K range of
+// the shared B operand through each of the eight L2s (fc1 wgrad: 2.65 GB fetched for 0.97 GB of operands before).
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   int q = nblk >> 3, r = nblk & 7;
   int xcd = bid & 7, idx = bid >> 3;
@@ -676,8 +678,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
 
   const int ntile = p.tiles_m * p.tiles_n;
   const int bid = blockIdx.x;
-  const int split = bid / ntile;
-  const int t = xcd_remap(bid - split * ntile, ntile);
+  const int lb = xcd_remap(bid, ntile * p.splitk);          // an XCD owns a contiguous range of (split, tile): see xcd_remap
+  const int split = lb / ntile;
+  const int t = lb - split * ntile;
   const int tm0 = (t / p.tiles_n) * BM;
   const int tn0 = (t % p.tiles_n) * BN;
 
@@ -948,8 +951,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
 
   const int ntile = p.tiles_m * p.tiles_n;
   const int bid = blockIdx.x;
-  const int split = bid / ntile;
-  const int t = xcd_remap(bid - split * ntile, ntile);
+  const int lb = xcd_remap(bid, ntile * p.splitk);          // an XCD owns a contiguous range of (split, tile): see xcd_remap
+  const int split = lb / ntile;
+  const int t = lb - split * ntile;
   const int tm0 = (t / p.tiles_n) * BM;
   const int tn0 = (t % p.tiles_n) * BN;
   const int nk_total = (p.K + BK - 1) / BK;
@@ -1139,8 +1143,9 @@ __global__ __launch_bounds__(512) void gemm_deepa_kernel(GemmParams p) {
 
   const int ntile = p.tiles_m * p.tiles_n;
   const int bid = blockIdx.x;
-  const int split = bid / ntile;
-  const int t = xcd_remap(bid - split * ntile, ntile);
+  const int lb = xcd_remap(bid, ntile * p.splitk);          // an XCD owns a contiguous range of (split, tile): see xcd_remap
+  const int split = lb / ntile;
+  const int t = lb - split * ntile;
   const int tm0 = (t / p.tiles_n) * BM;
   const int tn0 = (t % p.tiles_n) * BN;
   const int nk_total = (p.K + BK - 1) / BK;
@@ -1281,8 +1286,9 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
 
   const int ntile = p.tiles_m * p.tiles_n;
   const int bid = blockIdx.x;
-  const int split = bid / ntile;
-  const int t_ = xcd_remap(bid - split * ntile, ntile);
+  const int lb = xcd_remap(bid, ntile * p.splitk);          // an XCD owns a contiguous range of (split, tile): see xcd_remap
+  const int split = lb / ntile;
+  const int t_ = lb - split * ntile;
   const int tm0 = (t_ / p.tiles_n) * BM;
   const int tn0 = (t_ % p.tiles_n) * BN;
   const int nk_total = (p.K + BK - 1) / BK;

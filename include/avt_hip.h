@@ -44,7 +44,7 @@ int avt_abi_version(void);
  *     v = acc + bias[n];  act 3: v *= aux[m,n] (backward of an activation whose derivative was saved);
  *     act 1|2: C2[m,n] = gelu_erf'|gelu_tanh'(v) (optional, saved for backward), v = gelu_erf|gelu_tanh(v);
  *     act 0 with C2: C2[m,n] = v;  dropout(drop_p, drop_seed, element index m*N+n);
- *     v += res[(res_period ? m % res_period : m), n];  colsum[n] += v (fp32 atomics);  C[m,n] = v
+ *     v += res[(res_period ? m % res_period : m), n];  colsum[n] += v (fp32 atomics; over the bf16-rounded values when C is bf16);  C[m,n] = v
  * out_mode 2: C (fp32) += acc with atomics, no epilogue; splitk > 1 splits the reduction over workgroups
  *             (splitk <= 0 picks a factor that fills the chip).  Used for weight gradients.
  * tile: 0 = choose; 64 | 128 | 256 | 808 (256x256 tile, 8-phase schedule) force a kernel.  Requirements: 16-B aligned pointers, lda/ldb % 8 == 0,
