@@ -104,22 +104,46 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       for (int e = 0; e < 8; ++e) gam[i][e] = 0.f;
     }
   }
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    const float mean = mean_in[row], rstd = rstd_in[row];
+  // software pipeline over this wave's rows: the 16-byte loads of row r+1 (x, dy, residual gradient, statistics) are in flight
+  // while row r is reduced and written, so every wave keeps two rows of requests outstanding
+  const int rstep = gridDim.x * 4;
+  u32x4_t nx[V], nd[V], nr[V];
+  float nmean = 0.f, nrstd = 0.f;
+  auto fetch = [&](int row) __attribute__((always_inline)) {
+    const bool ok = row < rows;
     const bf16_t* xr = x + (size_t)row * ldx;
     const bf16_t* dyr = dy + (size_t)row * lddy;
+    const bf16_t* rr = dres + (size_t)row * lddres;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane + i * 64;
+      nx[i] = (u32x4_t){0u, 0u, 0u, 0u}; nd[i] = nx[i]; nr[i] = nx[i];
+      if (ok && c < nchunk) {
+        nx[i] = *(const u32x4_t*)(xr + c * 8);
+        nd[i] = *(const u32x4_t*)(dyr + c * 8);
+        if (dres) nr[i] = *(const u32x4_t*)(rr + c * 8);
+      }
+    }
+    nmean = ok ? mean_in[row] : 0.f; nrstd = ok ? rstd_in[row] : 0.f;
+  };
+  int row = blockIdx.x * 4 + wave;
+  fetch(row);
+  for (; row < rows; row += rstep) {
+    u32x4_t cx[V], cd[V], cr[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) { cx[i] = nx[i]; cd[i] = nd[i]; cr[i] = nr[i]; }
+    const float mean = nmean, rstd = nrstd;
+    fetch(row + rstep);
     float xh[V][8], g[V][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       int c = lane + i * 64;
       if (c < nchunk) {
-        u32x4_t wx = *(const u32x4_t*)(xr + c * 8);
-        u32x4_t wd = *(const u32x4_t*)(dyr + c * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float x0 = (bflo(wx[e]) - mean) * rstd, x1 = (bfhi(wx[e]) - mean) * rstd;
-          float d0 = bflo(wd[e]), d1 = bfhi(wd[e]);
+          float x0 = (bflo(cx[i][e]) - mean) * rstd, x1 = (bfhi(cx[i][e]) - mean) * rstd;
+          float d0 = bflo(cd[i][e]), d1 = bfhi(cd[i][e]);
           xh[i][2 * e] = x0; xh[i][2 * e + 1] = x1;
           ag[i][2 * e] += d0 * x0; ag[i][2 * e + 1] += d1 * x1;
           ab[i][2 * e] += d0; ab[i][2 * e + 1] += d1;
@@ -139,9 +163,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = rstd * (g[i][e] - m1 - xh[i][e] * m2);
         if (dres) {
-          u32x4_t wr = *(const u32x4_t*)(dres + (size_t)row * lddres + c * 8);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { o[2 * e] += bflo(wr[e]); o[2 * e + 1] += bfhi(wr[e]); }
+          for (int e = 0; e < 4; ++e) { o[2 * e] += bflo(cr[i][e]); o[2 * e + 1] += bfhi(cr[i][e]); }
         }
         u32x4_t w;
 #pragma unroll
@@ -149,7 +172,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         *(u32x4_t*)(dxr + c * 8) = w;
         if (colsum) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) ac[i][e] += bf2f(f2bf(o[e]));   // sum what the consumer GEMM will see
+          for (int e = 0; e < 4; ++e) { ac[i][2 * e] += bflo(w[e]); ac[i][2 * e + 1] += bfhi(w[e]); }   // sum what the consumer GEMM will see
         }
       }
     }
@@ -214,7 +237,7 @@ extern "C" int avt_layernorm_bwd(const void* dy, int lddy, const void* x, int ld
   AVT_CHECK(rows > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * MAXV, "avt_layernorm_bwd: D must be a multiple of 8 and <= 4096 (D=%d)", D);
   AVT_CHECK(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && (!dres || lddres % 8 == 0), "avt_layernorm_bwd: leading dims must be multiples of 8");
   AVT_CHECK(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (!dres || aligned16(dres)), "avt_layernorm_bwd: 16-byte alignment required");
-  int grid = (rows + 3) / 4; if (grid > 512) grid = 512;
+  int grid = (rows + 3) / 4; if (grid > 512) grid = 512;          // 2 blocks of 4 waves per CU (register-limited), persistent over rows
   hipStream_t s = (hipStream_t)stream;
 #define LN_BWD(V) hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, dgamma, dbeta, colsum, rows, D)
   switch (pick_v(D)) {

@@ -49,7 +49,7 @@ def test_gemm_plain(ops, M, N, K, layout):
         out = ops.gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=False, out_mode=ops.OUT_F32)
     torch.cuda.synchronize()
     assert relerr(out, ref) < 2e-3, relerr(out, ref)
-    for tile in (64, 128, 256, 512, 258, 2568, 808):
+    for tile in (64, 643, 128, 256, 512, 258, 2568, 808):
         o2 = ops.gemm(a, b, M, N, K, a_kmajor=True, b_kmajor=(layout == 'NT'), out_mode=ops.OUT_BF16, tile=tile)
         torch.cuda.synchronize()
         assert relerr(o2, ref) < 1e-2, (tile, relerr(o2, ref))

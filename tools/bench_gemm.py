@@ -33,7 +33,7 @@ for name, N, K in [('c_attn', 6144, 2048), ('c_proj', 2048, 2048), ('c_fc', 8192
     x, w, dy = r((Mh, K)), r((K, N)), r((Mh, N))
     dw = torch.zeros((K, N), device='cuda')
     by = (K * N * 2.0)
-    for tile in (64, 128):
+    for tile in (64, 643, 128):
         t = bench(lambda: ops.conv1d_fwd(x, w, tile=tile)); print(f'{name:8s} fwd   tile={tile} {t*1e6:8.1f} us  {by/t/1e12:5.2f} TB/s(weights)')
         t = bench(lambda: ops.conv1d_dgrad(dy, w, tile=tile)); print(f'{name:8s} dgrad tile={tile} {t*1e6:8.1f} us  {by/t/1e12:5.2f} TB/s')
     t = bench(lambda: ops.conv1d_wgrad(x, dy, dw)); print(f'{name:8s} wgrad {t*1e6:8.1f} us  {2*by/t/1e12:5.2f} TB/s(fp32 out)')
