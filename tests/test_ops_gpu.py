@@ -127,6 +127,36 @@ def test_gemm_epilogue_mul_aux(ops):
     assert relerr(out, ref) < 1e-2
 
 
+@pytest.mark.parametrize('N', [128, 200, 100])
+def test_gemm_epilogue_mul_aux_colsum_tails(ops, N):
+    """act 3 + bias + column sums, with N a multiple of 64 / of 8 only / of 4 only (register-layout path vs general path)."""
+    M, K = 421, 192
+    a, b = rnd((M, K), 0.5, 21), rnd((N, K), 0.5, 22)
+    d = rnd((M, N), 1.0, 23)
+    bias = rnd((N,), 0.5, 24, torch.float32)
+    ref = (a.float() @ b.float().t() + bias) * d.float()
+    for tile in (0, 64, 128, 808):
+        cs = torch.zeros(N, device='cuda', dtype=torch.float32)
+        out = ops.gemm(a, b, M, N, K, bias=bias, act=ops.ACT_MUL_AUX, aux=d, colsum=cs, tile=tile)
+        torch.cuda.synchronize()
+        assert relerr(out, ref) < 1e-2
+        assert relerr(cs, ref.sum(0)) < 1e-2
+
+
+def test_gemm_epilogue_dropout_residual_bf16(ops):
+    """bf16 output: dropout then residual in the register-layout path; the mask must be the one the fp32 path draws."""
+    M, N, K = 300, 256, 128
+    a, b = rnd((M, K), 0.5, 25), rnd((N, K), 0.5, 26)
+    res = rnd((M, N), 1.0, 27)
+    f32 = ops.gemm(a, b, M, N, K, drop_p=0.25, seed=99, out_mode=ops.OUT_F32)
+    for tile in (0, 64, 808):
+        out = ops.gemm(a, b, M, N, K, drop_p=0.25, seed=99, res=res, tile=tile)
+        torch.cuda.synchronize()
+        assert relerr(out, f32 + res.float()) < 1e-2
+        kept = (out.float() - res.float()).abs() > 1e-2          # dropped elements equal the residual exactly
+        assert float(((f32 != 0) ^ kept).float().mean()) < 0.02
+
+
 def test_gemm_epilogue_dropout(ops):
     M, N, K = 256, 256, 64
     a, b = rnd((M, K), 0.5, 15), rnd((N, K), 0.5, 16)
