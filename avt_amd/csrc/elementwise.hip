@@ -95,26 +95,29 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const bf16_t* __rest
   }
 }
 
-// dx0 bf16 [N,S,D] -> dpos[S,D] += sum_n ; dcls[D] += row s=0 ; dbias[D] += sum_{s>=1}
+// dx0 bf16 [N,S,D] -> dpos[S,D] += sum_n ; dcls[D] += row s=0 ; dbias[D] += sum_{s>=1}.  blockIdx.y splits the frames so that
+// the 19 k (s, chunk) columns of a ViT-B still give a few thousand workgroups of work in flight (fp32 atomics merge the parts)
 __global__ __launch_bounds__(256) void patch_bwd_reduce_kernel(const bf16_t* __restrict__ dx, float* __restrict__ dpos,
                                                                float* __restrict__ dcls, float* __restrict__ dbias,
-                                                               int N, int S, int D) {
+                                                               int N, int S, int D, int frames_per_block) {
   const int nch = D / 8;
-  long total = (long)S * nch;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    int c = (int)(idx % nch), s = (int)(idx / nch);
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int n = 0; n < N; ++n) {
-      u32x4_t w = *(const u32x4_t*)(dx + ((size_t)n * S + s) * D + c * 8);
+  const long total = (long)S * nch;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int n0 = blockIdx.y * frames_per_block;
+  int n1 = n0 + frames_per_block; if (n1 > N) n1 = N;
+  const int c = (int)(idx % nch), s = (int)(idx / nch);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int n = n0; n < n1; ++n) {
+    u32x4_t w = *(const u32x4_t*)(dx + ((size_t)n * S + s) * D + c * 8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { acc[2 * e] += bflo(w[e]); acc[2 * e + 1] += bfhi(w[e]); }
-    }
+    for (int e = 0; e < 4; ++e) { acc[2 * e] += bflo(w[e]); acc[2 * e + 1] += bfhi(w[e]); }
+  }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      dpos[(size_t)s * D + c * 8 + e] += acc[e];
-      if (s == 0) dcls[c * 8 + e] += acc[e];
-      else unsafeAtomicAdd(&dbias[c * 8 + e], acc[e]);
-    }
+  for (int e = 0; e < 8; ++e) {
+    unsafeAtomicAdd(&dpos[(size_t)s * D + c * 8 + e], acc[e]);
+    if (s == 0) unsafeAtomicAdd(&dcls[c * 8 + e], acc[e]);
+    else unsafeAtomicAdd(&dbias[c * 8 + e], acc[e]);
   }
 }
 
@@ -206,7 +209,10 @@ extern "C" int avt_patch_embed_bwd_reduce(const void* dx, float* dpos, float* dc
   AVT_CHECK(dx && dpos && dcls && dbias && N > 0 && S > 0 && D > 0 && D % 8 == 0, "avt_patch_embed_bwd_reduce: bad argument");
   AVT_CHECK(aligned16(dx), "avt_patch_embed_bwd_reduce: 16-byte alignment required");
   long total = (long)S * (D / 8);
-  hipLaunchKernelGGL(patch_bwd_reduce_kernel, dim3(GRID_FOR(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, dpos, dcls, dbias, N, S, D);
+  int gx = (int)((total + 255) / 256);
+  int gy = 4096 / gx; if (gy < 1) gy = 1; if (gy > (N + 7) / 8) gy = (N + 7) / 8;
+  int fpb = (N + gy - 1) / gy; gy = (N + fpb - 1) / fpb;
+  hipLaunchKernelGGL(patch_bwd_reduce_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, dpos, dcls, dbias, N, S, D, fpb);
   AVT_LAUNCH_CHECK();
   return 0;
 }

@@ -117,76 +117,101 @@ __device__ __forceinline__ float lsum16(float v) {
   return v;
 }
 
-template <int NKT>
+// Forward: persistent workgroups walking over (frame, head) items with the K / V tiles double-buffered in LDS: the tiles of
+// item n+1 are requested (LDS-DMA) when item n starts computing, and this wave's Q strip of item n+1 right after, so the
+// only exposed global latency is the very first item's.
+template <int NKT, bool ALL_LIVE>
 __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                float* __restrict__ lse, int S, int H, float scale) {
+                                                                float* __restrict__ lse, int S, int H, int items, float scale) {
   constexpr int NP = (NKT + 1) / 2;          // key-tile pairs
   constexpr int KP = NP * 32;                // padded key count
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Klds = smem;                         // [KP][64] swizzled row-major
-  char* Vlds = smem + KP * 128;              // [KP][64] swizzled row-major (consumed through transposing reads)
+  constexpr int RM = KP * 128;               // one [KP][64] swizzled row-major tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K | V] (V is consumed through transposing reads)
   const int D = H * HD, ld = 3 * D;
-  const int frame = blockIdx.x / H, head = blockIdx.x % H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bf16_t* base = qkv + (size_t)frame * S * ld + head * HD;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  stage_head_dma(base + D, ld, S, Klds, KP, wv, NKT, lane);
-  stage_head_dma(base + 2 * D, ld, S, Vlds, KP, wv, NKT, lane);
   const int q0 = wave * 16, g = lane >> 4;
-  bf16x8_t bq[2];
-  load_strip(base, ld, S, q0, lane, bq);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  f32x4_t st[2 * NP];
-#pragma unroll
-  for (int kt = 0; kt < 2 * NP; ++kt) st[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  float mx = -3.0e38f;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-    a = mfma16(frag_rm(Klds, kt, 0, lane), bq[0], a);
-    a = mfma16(frag_rm(Klds, kt, 1, lane), bq[1], a);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int key = kt * 16 + 4 * g + r;
-      a[r] = (key < S) ? a[r] : -3.0e38f;
-      mx = fmaxf(mx, a[r]);
-    }
-    st[kt] = a;
+  int item = blockIdx.x;
+  bf16x8_t nq[2];
+  if (item < items) {
+    const bf16_t* base = qkv + (size_t)(item / H) * S * ld + (item % H) * HD;
+    stage_head_dma(base + D, ld, S, smem, KP, wv, NKT, lane);
+    stage_head_dma(base + 2 * D, ld, S, smem + RM, KP, wv, NKT, lane);
+    load_strip(base, ld, S, q0, lane, nq);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  mx = gmax(mx);
-  const float sl = scale * LOG2E;
-  const float mxs = mx * sl;
-  float sum = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int key = kt * 16 + 4 * g + r;
-      float pv = (key < S) ? __builtin_amdgcn_exp2f(fmaf(st[kt][r], sl, -mxs)) : 0.f;
-      st[kt][r] = pv;
-      sum += pv;
+  int buf = 0;
+  for (; item < items; item += gridDim.x, buf ^= 1) {
+    const int frame = item / H, head = item % H;
+    const char* Kb = smem + buf * 2 * RM;
+    const char* Vb = Kb + RM;
+    // K, V of this item were requested one item ago; younger than them are only the 2 Q-strip loads and the 5 stores of the
+    // previous item (nothing at the first item)
+    // (ALL_LIVE: every wave's strip has at least one row inside the sequence, so every guarded load / store is issued; else
+    // a wave may have skipped them and the count would be wrong -> wait for everything)
+    if (ALL_LIVE) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                          // also: everyone is done with the other buffer (item n-1)
+    bf16x8_t bq[2];
+    bq[0] = nq[0]; bq[1] = nq[1];
+    {
+      const int nitem = item + gridDim.x < items ? item + gridDim.x : item;     // the last item re-requests itself (keeps the counts)
+      const bf16_t* nbase = qkv + (size_t)(nitem / H) * S * ld + (nitem % H) * HD;
+      char* nb = smem + (buf ^ 1) * 2 * RM;
+      stage_head_dma(nbase + D, ld, S, nb, KP, wv, NKT, lane);
+      stage_head_dma(nbase + 2 * D, ld, S, nb + RM, KP, wv, NKT, lane);
+      load_strip(nbase, ld, S, q0, lane, nq);
     }
-  sum = gsum(sum);
-  f32x4_t o[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int t = 0; t < NP; ++t) {
-    bf16x8_t pb = pack_pair(st[2 * t], st[2 * t + 1]);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(frag_tr_rm(Vlds, dt, t, lane), pb, o[dt]);
-  }
-  const int q = q0 + (lane & 15);
-  if (q < S) {
-    const float inv = 1.0f / sum;
-    bf16_t* orow = out + ((size_t)frame * S + q) * D + head * HD;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      u32x2_t w; w[0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv); w[1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
-      *(u32x2_t*)(orow + dt * 16 + 4 * g) = w;
+    f32x4_t st[2 * NP];
+  #pragma unroll
+    for (int kt = 0; kt < 2 * NP; ++kt) st[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float mx = -3.0e38f;
+  #pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+      a = mfma16(frag_rm(Kb, kt, 0, lane), bq[0], a);
+      a = mfma16(frag_rm(Kb, kt, 1, lane), bq[1], a);
+  #pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = kt * 16 + 4 * g + r;
+        a[r] = (key < S) ? a[r] : -3.0e38f;
+        mx = fmaxf(mx, a[r]);
+      }
+      st[kt] = a;
     }
-    if (g == 0) lse[((size_t)frame * H + head) * S + q] = mx * scale + __logf(sum);
+    mx = gmax(mx);
+    const float sl = scale * LOG2E;
+    const float mxs = mx * sl;
+    float sum = 0.f;
+  #pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+  #pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = kt * 16 + 4 * g + r;
+        float pv = (key < S) ? __builtin_amdgcn_exp2f(fmaf(st[kt][r], sl, -mxs)) : 0.f;
+        st[kt][r] = pv;
+        sum += pv;
+      }
+    sum = gsum(sum);
+    f32x4_t o[4];
+  #pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      bf16x8_t pb = pack_pair(st[2 * t], st[2 * t + 1]);
+  #pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(frag_tr_rm(Vb, dt, t, lane), pb, o[dt]);
+    }
+    const int q = q0 + (lane & 15);
+    if (q < S) {
+      const float inv = 1.0f / sum;
+      bf16_t* orow = out + ((size_t)frame * S + q) * D + head * HD;
+  #pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        u32x2_t w; w[0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv); w[1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
+        *(u32x2_t*)(orow + dt * 16 + 4 * g) = w;
+      }
+      if (g == 0) lse[((size_t)frame * H + head) * S + q] = mx * scale + __logf(sum);
+    }
   }
 }
 
@@ -199,7 +224,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
 //     phase B: dK, dV of this wave's 16 keys (needs the Q, dO tiles + own K / V strips, taken before barrier 2)
 // so the global -> LDS latency of every tile hides behind the other phase.  Column sums of dq|dk|dv (the qkv bias gradient)
 // are kept in LDS per head for the whole kernel and flushed once.
-template <int NKT>
+template <int NKT, bool ALL_LIVE>
 __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                 const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                 bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
@@ -262,7 +287,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
 
     // K, V of this item have landed once all but the youngest 15 vector-memory operations of this wave are done: after their
     // LDS-DMA requests came the 7 strip loads and the 8 dK / dV stores of the previous item (nothing younger at the first item)
-    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    // (ALL_LIVE: every wave's strip has at least one row inside the sequence, so every guarded load / store is issued; else
+    // a wave may have skipped them and the count would be wrong -> wait for everything)
+    if (ALL_LIVE) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // barrier 1
     stage_head_dma(base, ld, S, Qs, KP, wv, NKT, lane);
     stage_head_dma(dobase, D, S, dOs, KP, wv, NKT, lane);
@@ -413,15 +440,21 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
 
 int pick_nkt(int S) { int n = (S + 15) / 16; if (n <= 1) return 1; if (n <= 2) return 2; if (n <= 4) return 4; if (n <= 8) return 8; return 13; }
 
-template <int NKT> size_t fwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)2 * NP * 32 * 128; }
+template <int NKT> size_t fwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128; }     // K, V x 2 buffers
 template <int NKT> size_t bwd_smem(int H) { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128 + (size_t)(2 * NP * 32 + H * 192) * 4; }
 
 template <int NKT>
 int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, int H, float scale, hipStream_t s) {
   size_t sm = fwd_smem<NKT>();
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)vit_attn_fwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
-  hipLaunchKernelGGL((vit_attn_fwd_kernel<NKT>), dim3(frames * H), dim3(64 * NKT), sm, s, qkv, out, lse, S, H, scale);
+  (void)hipFuncSetAttribute((const void*)vit_attn_fwd_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  (void)hipFuncSetAttribute((const void*)vit_attn_fwd_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  const int items = frames * H;
+  const bool all_live = S > (NKT - 1) * 16;
+  const int per_cu = (int)((160 * 1024) / sm) < 1 ? 1 : (int)((160 * 1024) / sm);
+  int grid = 256 * (per_cu > 8 ? 8 : per_cu);
+  if (grid > items) grid = items;
+  if (all_live) hipLaunchKernelGGL((vit_attn_fwd_kernel<NKT, true>), dim3(grid), dim3(64 * NKT), sm, s, qkv, out, lse, S, H, items, scale);
+  else hipLaunchKernelGGL((vit_attn_fwd_kernel<NKT, false>), dim3(grid), dim3(64 * NKT), sm, s, qkv, out, lse, S, H, items, scale);
   return 0;
 }
 template <int NKT>
@@ -429,7 +462,9 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
                int frames, int S, int H, float scale, hipStream_t s) {
   size_t sm = bwd_smem<NKT>(H);
   if (sm > 160 * 1024) { avt_set_error("avt_vit_attn_bwd: H = %d needs more LDS than a CU has", H); return -1; }
-  (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  const bool all_live = S > (NKT - 1) * 16;
   static const char* e = getenv("AVT_ATTN_DBG_PTR");
   long long* dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr;
   const int items = frames * H;
@@ -437,7 +472,8 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
   const int per_cu = (int)((160 * 1024) / sm) < 1 ? 1 : (int)((160 * 1024) / sm);
   int grid = 256 * (per_cu > 8 ? 8 : per_cu);
   if (grid > items) grid = items;
-  hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT>), dim3(grid), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, S, H, items, scale, dbg);
+  if (all_live) hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT, true>), dim3(grid), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, S, H, items, scale, dbg);
+  else hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT, false>), dim3(grid), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, S, H, items, scale, dbg);
   return 0;
 }
 

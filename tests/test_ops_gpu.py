@@ -214,7 +214,7 @@ def test_layernorm_strided_rows(ops):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('frames,S,H', [(3, 197, 12), (2, 5, 4), (2, 17, 2), (1, 50, 3), (2, 100, 2), (1, 208, 1)])
+@pytest.mark.parametrize('frames,S,H', [(3, 197, 12), (2, 5, 4), (2, 17, 2), (1, 50, 3), (2, 100, 2), (1, 208, 1), (49, 197, 12), (70, 180, 4)])   # the last two: more (frame, head) items than persistent workgroups
 def test_vit_attention(ops, frames, S, H):
     D = H * 64
     qkv = rnd((frames * S, 3 * D), 1.0, 30)
