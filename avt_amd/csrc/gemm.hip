@@ -1529,6 +1529,9 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
               "avt_gemm_bf16: N and ldc/ldc2/ldres/ldaux must be multiples of 4 for the activation epilogue");
     p.wide_ok = (ldc % 8 == 0) && (!C2 || ldc2 % 8 == 0) && (!res || ldres % 8 == 0) && (!aux || ldaux % 8 == 0);
     AVT_CHECK(splitk <= 1, "avt_gemm_bf16: split-K needs out_mode 2");
+    // the second operand of the epilogue is fetched through a buffer descriptor with 32-bit byte offsets
+    AVT_CHECK(!aux || (size_t)M * (size_t)ldaux * 2 < 0xFFFFFFF0ull, "avt_gemm_bf16: aux larger than 4 GiB");
+    AVT_CHECK(!res || (size_t)(res_period ? res_period : M) * (size_t)ldres * 2 < 0xFFFFFFF0ull, "avt_gemm_bf16: res larger than 4 GiB");
   } else {
     AVT_CHECK(!bias && !act && !C2 && !res && !colsum && drop_p == 0.f, "avt_gemm_bf16: accumulate mode has no fused epilogue");
   }

@@ -14,6 +14,7 @@ OUT_BF16, OUT_F32, OUT_ACCUM_F32 = 0, 1, 2
 
 # When set to a list, every gemm() appends (variant, flops, start_event, end_event): bench.py's live roofline probe.
 GEMM_TRACE = None
+FORCE_TILE = 0          # tests: route every auto-selected (tile=0) GEMM to one kernel, e.g. 808, to validate it inside the whole model
 
 
 def _stream():
@@ -67,6 +68,8 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
          aux=None, c2=None, res=None, res_period=0, drop_p=0.0, seed=0, colsum=None, splitk=0, tile=0):
     """C[M,N] = epilogue(sum_k opA[m,k] opB[n,k]); see avt_gemm_bf16 in include/avt_hip.h."""
     _chk(A, BF16, 'A'); _chk(B, BF16, 'B')
+    if tile == 0 and FORCE_TILE:
+        tile = FORCE_TILE
     if out is None:
         assert out_mode != OUT_ACCUM_F32, 'accumulate mode needs an output buffer'
         out = torch.empty((M, N), device=A.device, dtype=BF16 if out_mode == OUT_BF16 else torch.float32)

@@ -122,9 +122,21 @@ def test_g3b_vitb_cls_features_vs_hf_golden(golden_dir):
 
 
 @pytest.mark.parametrize('cfg', [dict(vit=(128, 2, 2, 32), T=4, B=3, Dh=64, L=2, H=4, C=17, std=0.5),
-                                 dict(vit=(192, 3, 3, 48), T=5, B=2, Dh=128, L=2, H=4, C=50, std=0.4)])
+                                 dict(vit=(192, 3, 3, 48), T=5, B=2, Dh=128, L=2, H=4, C=50, std=0.4),
+                                 dict(vit=(256, 2, 4, 32), T=3, B=2, Dh=128, L=1, H=4, C=24, std=0.4, tile=808),
+                                 dict(vit=(128, 2, 2, 32), T=4, B=3, Dh=64, L=2, H=4, C=17, std=0.5, tile=256)])
 def test_random_weights_vs_oracle(cfg):
-    """Random-normal weights large enough that attention is far from uniform (exercises q/k/softmax gradients)."""
+    """Random-normal weights large enough that attention is far from uniform (exercises q/k/softmax gradients).
+    The `tile` cases push every GEMM of the model through one big-tile kernel (the one a full-size batch selects)."""
+    from avt_amd import ops as _ops
+    _ops.FORCE_TILE = cfg.get('tile', 0)
+    try:
+        _random_weights_vs_oracle(cfg)
+    finally:
+        _ops.FORCE_TILE = 0
+
+
+def _random_weights_vs_oracle(cfg):
     dim, depth, heads, img = cfg['vit']
     torch.manual_seed(0)
     orc = build_oracle_model('vit', dim, cfg['Dh'], cfg['L'], cfg['H'], cfg['C'], vit=cfg['vit'])
