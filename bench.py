@@ -169,7 +169,7 @@ def main():
                     'avg_launch_gflop': round(fl / n_launch / 1e9, 3),
                     'share_of_step_time': round(tm / elapsed, 3),
                     'per_variant_tflops': {k: round(v[0] / v[1] / 1e12, 1) for k, v in per_variant.items() if v[1] > 0}}
-        out = {'metric': 'training clips/sec (ViT-B/16+AVT-h, 10x224^2 frames)' if args.model.startswith('vit_base') else f'training clips/sec ({args.model}+AVT-h)',
+        out = {'metric': f'training clips/sec (ViT-B/16+AVT-h, {args.frames}x224^2 frames)' if args.model.startswith('vit_base') else f'training clips/sec ({args.model}+AVT-h, {args.frames}x224^2 frames)',
                'value': round(clips, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
