@@ -1299,7 +1299,11 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
 
-  // per-lane source offsets (bytes) of this wave's two DMA instructions per half-tile, K tile 0
+  // per-lane source offsets (bytes) of this wave's two DMA instructions per half-tile, K tile 0.  Rows / columns past the
+  // matrix edge need no zero fill (they only feed output rows / columns that are never stored): a k-major row past the end is
+  // out of the descriptor's range anyway, a column of a k-strided operand is clamped to the last valid 8-column chunk.
+  // Only the K tail must read as zero: tiles >= nk use a descriptor with num_records = 0, so the in-loop address work is
+  // one scalar select of the descriptor and one vector add per instruction (no per-lane masks, no branches).
   uint32_t offA[2][2], offB[2][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -1314,7 +1318,8 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
         int r = j * 32 + wave * 4 + (lane >> 4);                         // k row
         int cl = ((lane & 15) ^ kstrided_swz<128>(r)) * 8;               // LDS column of the half-tile
         int col = tm0 + (cl >> 6) * 128 + (cl & 63) + h * 64;
-        offA[h][j] = (col < p.M) ? (uint32_t)(((size_t)(kt_begin * BK + r) * (size_t)p.lda + (size_t)col) * 2) : 0xFFFFFFF0u;
+        if (col > p.M - 8) col = (p.M - 8) & ~7;
+        offA[h][j] = (uint32_t)(((size_t)(kt_begin * BK + r) * (size_t)p.lda + (size_t)col) * 2);
       }
       if (B_KMAJOR) {
         int r = j * 64 + wave * 8 + (lane >> 3);
@@ -1325,7 +1330,8 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
         int r = j * 32 + wave * 4 + (lane >> 4);
         int cl = ((lane & 15) ^ kstrided_swz<128>(r)) * 8;
         int col = tn0 + (cl >> 5) * 64 + (cl & 31) + h * 32;
-        offB[h][j] = (col < p.N) ? (uint32_t)(((size_t)(kt_begin * BK + r) * (size_t)p.ldb + (size_t)col) * 2) : 0xFFFFFFF0u;
+        if (col > p.N - 8) col = (p.N - 8) & ~7;
+        offB[h][j] = (uint32_t)(((size_t)(kt_begin * BK + r) * (size_t)p.ldb + (size_t)col) * 2);
       }
     }
   const uint32_t kstepA = A_KMAJOR ? (uint32_t)(BK * 2) : (uint32_t)((size_t)BK * p.lda * 2);
@@ -1333,27 +1339,25 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
   char* const dstA = lds + (A_KMAJOR ? wave * 8 * (BK * 2) : wave * 4 * 256);
   char* const dstB = lds + (B_KMAJOR ? wave * 8 * (BK * 2) : wave * 4 * 256);
   constexpr int JSTEP = 8192;                              // second DMA instruction lands 64 rows x 128 B (or 32 k rows x 256 B) further
+  __amdgpu_buffer_rsrc_t ra_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0, 0x00020000);
 
   // slot index = kind * 2 + (tile & 1); kinds 0 = A0h, 1 = B0h, 2 = B1h, 3 = A1h
   auto stage_a = [&](int h, int tile) __attribute__((always_inline)) {
-    const bool valid = tile < nk;
+    const __amdgpu_buffer_rsrc_t r = (tile < nk) ? ra : ra_null;
     char* d = dstA + ((h ? 3 : 0) * 2 + (tile & 1)) * HALF;
+    const uint32_t adv = (uint32_t)tile * kstepA;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      uint32_t off = offA[h][j] + (uint32_t)tile * kstepA;
-      if (!valid || offA[h][j] == 0xFFFFFFF0u) off = 0xFFFFFFF0u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, AVT_LDS_PTR(d + j * JSTEP), 16, off, 0, 0, 0);
-    }
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offA[h][j] + adv, 0, 0, 0);
   };
   auto stage_b = [&](int h, int tile) __attribute__((always_inline)) {
-    const bool valid = tile < nk;
+    const __amdgpu_buffer_rsrc_t r = (tile < nk) ? rb : rb_null;
     char* d = dstB + ((h ? 2 : 1) * 2 + (tile & 1)) * HALF;
+    const uint32_t adv = (uint32_t)tile * kstepB;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      uint32_t off = offB[h][j] + (uint32_t)tile * kstepB;
-      if (!valid || offB[h][j] == 0xFFFFFFF0u) off = 0xFFFFFFF0u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, AVT_LDS_PTR(d + j * JSTEP), 16, off, 0, 0, 0);
-    }
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offB[h][j] + adv, 0, 0, 0);
   };
 
   bf16x8_t fa[2][4], fb0[4], fb1[4];
@@ -1381,6 +1385,8 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #define P8_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+// fragment reads first, LDS-DMA second: an LDS-DMA blocks the issuing wave for ~100 cycles, the reads only queue
+#define P8_PIN() __builtin_amdgcn_sched_barrier(0)
 #define P8_MFMA(FA, FB, I0, J)                                                                          \
   do {                                                                                                   \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
@@ -1405,42 +1411,42 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
     read_b(fb0, 0, 0);
     for (int t = 0; t < nk; t += 2) {
       // ---- even tile t (slot parity 0): B0 in fb0, next tile's B0 -> fb0n ----
-      read_a(fa, 0, 0); stage_b(1, t + 1); wait_vmcnt<8>(); P8_BARRIER();
+      read_a(fa, 0, 0); P8_PIN(); stage_b(1, t + 1); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb0, 0, 0); P8_BARRIER();
-      read_b(fb1, 1, 0); stage_a(1, t + 1); wait_vmcnt<8>(); P8_BARRIER();
+      read_b(fb1, 1, 0); P8_PIN(); stage_a(1, t + 1); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb1, 0, 1); P8_BARRIER();
-      read_a(fa, 1, 0); stage_a(0, t + 2); wait_vmcnt<6>(); P8_BARRIER();
+      read_a(fa, 1, 0); P8_PIN(); stage_a(0, t + 2); wait_vmcnt<6>(); P8_BARRIER();
       P8_MFMA(fa, fb1, 2, 1); P8_BARRIER();
-      read_b(fb0n, 0, 1); stage_b(0, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+      read_b(fb0n, 0, 1); P8_PIN(); stage_b(0, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb0, 2, 0); P8_BARRIER();
       // ---- odd tile t+1 (slot parity 1): B0 in fb0n, next tile's B0 -> fb0; when nk is odd this runs once on zero-filled
       //      slots (no mid-loop exit: it would split the accumulators' live ranges and cost a copy of all of them per trip) ----
-      read_a(fa, 0, 1); stage_b(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+      read_a(fa, 0, 1); P8_PIN(); stage_b(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb0n, 0, 0); P8_BARRIER();
-      read_b(fb1, 1, 1); stage_a(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+      read_b(fb1, 1, 1); P8_PIN(); stage_a(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb1, 0, 1); P8_BARRIER();
-      read_a(fa, 1, 1); stage_a(0, t + 3); wait_vmcnt<6>(); P8_BARRIER();
+      read_a(fa, 1, 1); P8_PIN(); stage_a(0, t + 3); wait_vmcnt<6>(); P8_BARRIER();
       P8_MFMA(fa, fb1, 2, 1); P8_BARRIER();
-      read_b(fb0, 0, 0); stage_b(0, t + 3); wait_vmcnt<8>(); P8_BARRIER();
+      read_b(fb0, 0, 0); P8_PIN(); stage_b(0, t + 3); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb0n, 2, 0); P8_BARRIER();
     }
   } else {
     for (int t = 0; t < nk; t += 2) {
       // ---- even tile t (slot parity 0) ----
-      read_a(fa, 0, 0); read_b(fb0, 0, 0); stage_b(1, t + 1); wait_vmcnt<8>(); P8_BARRIER();
+      read_a(fa, 0, 0); read_b(fb0, 0, 0); P8_PIN(); stage_b(1, t + 1); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb0, 0, 0); P8_BARRIER();
-      read_b(fb1, 1, 0); stage_a(1, t + 1); wait_vmcnt<8>(); P8_BARRIER();
+      read_b(fb1, 1, 0); P8_PIN(); stage_a(1, t + 1); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb1, 0, 1); P8_BARRIER();
-      read_a(fa, 1, 0); stage_a(0, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+      read_a(fa, 1, 0); P8_PIN(); stage_a(0, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb1, 2, 1); P8_BARRIER();
       stage_b(0, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb0, 2, 0); P8_BARRIER();
       // ---- odd tile t+1 (slot parity 1) ----
-      read_a(fa, 0, 1); read_b(fb0, 0, 1); stage_b(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+      read_a(fa, 0, 1); read_b(fb0, 0, 1); P8_PIN(); stage_b(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb0, 0, 0); P8_BARRIER();
-      read_b(fb1, 1, 1); stage_a(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+      read_b(fb1, 1, 1); P8_PIN(); stage_a(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb1, 0, 1); P8_BARRIER();
-      read_a(fa, 1, 1); stage_a(0, t + 3); wait_vmcnt<8>(); P8_BARRIER();
+      read_a(fa, 1, 1); P8_PIN(); stage_a(0, t + 3); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb1, 2, 1); P8_BARRIER();
       stage_b(0, t + 3); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb0, 2, 0); P8_BARRIER();
@@ -1453,6 +1459,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
   int lane_e = lane, m0_e = tm0 + grp * WM, n0_e = tn0 + wn * WN;
   asm volatile("" : "+v"(lane_e), "+s"(m0_e), "+s"(n0_e));   // keep the epilogue's address arithmetic out of the K loop's register budget
   gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane_e, m0_e, n0_e);
+#undef P8_PIN
 #undef P8_MFMA
 #undef P8_BARRIER
 }
