@@ -108,8 +108,20 @@ __global__ __launch_bounds__(256) void patch_bwd_reduce_kernel(const bf16_t* __r
   int n1 = n0 + frames_per_block; if (n1 > N) n1 = N;
   const int c = (int)(idx % nch), s = (int)(idx / nch);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int n = n0; n < n1; ++n) {
-    u32x4_t w = *(const u32x4_t*)(dx + ((size_t)n * S + s) * D + c * 8);
+  const bf16_t* src = dx + (size_t)s * D + c * 8;
+  const size_t fstride = (size_t)S * D;
+  int n = n0;
+  for (; n + 4 <= n1; n += 4) {                       // four independent 16-byte loads in flight per thread
+    u32x4_t w0 = *(const u32x4_t*)(src + (size_t)n * fstride), w1 = *(const u32x4_t*)(src + (size_t)(n + 1) * fstride);
+    u32x4_t w2 = *(const u32x4_t*)(src + (size_t)(n + 2) * fstride), w3 = *(const u32x4_t*)(src + (size_t)(n + 3) * fstride);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      acc[2 * e] += (bflo(w0[e]) + bflo(w1[e])) + (bflo(w2[e]) + bflo(w3[e]));
+      acc[2 * e + 1] += (bfhi(w0[e]) + bfhi(w1[e])) + (bfhi(w2[e]) + bfhi(w3[e]));
+    }
+  }
+  for (; n < n1; ++n) {
+    u32x4_t w = *(const u32x4_t*)(src + (size_t)n * fstride);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { acc[2 * e] += bflo(w[e]); acc[2 * e + 1] += bfhi(w[e]); }
   }
@@ -210,7 +222,7 @@ extern "C" int avt_patch_embed_bwd_reduce(const void* dx, float* dpos, float* dc
   AVT_CHECK(aligned16(dx), "avt_patch_embed_bwd_reduce: 16-byte alignment required");
   long total = (long)S * (D / 8);
   int gx = (int)((total + 255) / 256);
-  int gy = 4096 / gx; if (gy < 1) gy = 1; if (gy > (N + 7) / 8) gy = (N + 7) / 8;
+  int gy = 1024 / gx; if (gy < 1) gy = 1; if (gy > 16) gy = 16; if (gy > (N + 7) / 8) gy = (N + 7) / 8;   // few frame groups: the fp32 atomics of the groups collide
   int fpb = (N + gy - 1) / gy; gy = (N + fpb - 1) / fpb;
   hipLaunchKernelGGL(patch_bwd_reduce_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, dpos, dcls, dbias, N, S, D, fpb);
   AVT_LAUNCH_CHECK();
