@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
         int r = j * 32 + wave * 4 + (lane >> 4);                         // k row
         int cl = ((lane & 15) ^ kstrided_swz<128>(r)) * 8;               // LDS column of the half-tile
         int col = tm0 + (cl >> 6) * 128 + (cl & 63) + h * 64;
-        if (col > p.M - 8) col = (p.M - 8) & ~7;
+        if (col > p.M - 8) col = p.M >= 8 ? ((p.M - 8) & ~7) : 0;
         offA[h][j] = (uint32_t)(((size_t)(kt_begin * BK + r) * (size_t)p.lda + (size_t)col) * 2);
       }
       if (B_KMAJOR) {
@@ -1330,7 +1330,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
         int r = j * 32 + wave * 4 + (lane >> 4);
         int cl = ((lane & 15) ^ kstrided_swz<128>(r)) * 8;
         int col = tn0 + (cl >> 5) * 64 + (cl & 31) + h * 32;
-        if (col > p.N - 8) col = (p.N - 8) & ~7;
+        if (col > p.N - 8) col = p.N >= 8 ? ((p.N - 8) & ~7) : 0;
         offB[h][j] = (uint32_t)(((size_t)(kt_begin * BK + r) * (size_t)p.ldb + (size_t)col) * 2);
       }
     }
