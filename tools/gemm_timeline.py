@@ -7,12 +7,16 @@ os.environ['AVT_GEMM_DBG_PTR'] = hex(dbg.data_ptr())
 from avt_amd import ops
 M = 63040
 r = lambda s: (torch.rand(s, device='cuda') * 2 - 1).to(torch.bfloat16)
-for name, N, K, kw in [('proj', 768, 768, {}), ('proj+bias+res', 768, 768, 'res'), ('fc1+bias+gelu+c2', 3072, 768, 'gelu'), ('fc1 plain', 3072, 768, {}), ('fc2dgrad aux', 3072, 768, 'aux'), ('fc2dgrad aux+colsum', 3072, 768, 'auxcs'), ('fc2', 768, 3072, {})]:
+for name, N, K, kw in [('proj', 768, 768, {}), ('proj+bias+res', 768, 768, 'res'), ('fc1+bias+gelu+c2', 3072, 768, 'gelu'), ('fc1+bias+gelu', 3072, 768, 'gelu1'), ('fc1+bias+c2', 3072, 768, 'c2only'), ('fc1 plain', 3072, 768, {}), ('fc2dgrad aux', 3072, 768, 'aux'), ('fc2dgrad aux+colsum', 3072, 768, 'auxcs'), ('fc2', 768, 3072, {})]:
     x, w = r((M, K)), r((N, K))
     for tile in (256,):
         kws = {}
         if kw == 'gelu':
             kws = dict(bias=torch.zeros(N, device='cuda'), act=1, c2=torch.empty((M, N), device='cuda', dtype=torch.bfloat16))
+        if kw == 'gelu1':
+            kws = dict(bias=torch.zeros(N, device='cuda'), act=1)
+        if kw == 'c2only':
+            kws = dict(bias=torch.zeros(N, device='cuda'), c2=torch.empty((M, N), device='cuda', dtype=torch.bfloat16))
         if kw == 'res':
             kws = dict(bias=torch.zeros(N, device='cuda'), res=r((M, N)))
         if kw in ('aux', 'auxcs'):
