@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int key = kt * 16 + 4 * g + r;
-        a[r] = (key < S) ? a[r] : -3.0e38f;
+        if (!ALL_LIVE || kt == NKT - 1) a[r] = (key < S) ? a[r] : -3.0e38f;     // ALL_LIVE: only the last key tile can hold keys >= S
         mx = fmaxf(mx, a[r]);
       }
       st[kt] = a;
@@ -187,7 +187,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int key = kt * 16 + 4 * g + r;
-        float pv = (key < S) ? __builtin_amdgcn_exp2f(fmaf(st[kt][r], sl, -mxs)) : 0.f;
+        float pv = __builtin_amdgcn_exp2f(fmaf(st[kt][r], sl, -mxs));
+        if (!ALL_LIVE || kt == NKT - 1) pv = (key < S) ? pv : 0.f;
         st[kt][r] = pv;
         sum += pv;
       }
