@@ -111,9 +111,13 @@ __device__ __forceinline__ bf16x8_t pack_pair(f32x4_t a, f32x4_t b) {
 // sum / max over the 4 lane groups g (lanes sharing l&15)
 __device__ __forceinline__ float gsum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
 __device__ __forceinline__ float gmax(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64)); return v; }
-// sum over the 16 lanes of a group (l&15)
+// sum over the 16 lanes of a group (l&15) = one DPP row: four rotate-and-add steps on the VALU (v_add_f32 with a row_ror
+// modifier) instead of four ds_bpermute round trips through the LDS crossbar -- the backward takes 48 such sums per item
 __device__ __forceinline__ float lsum16(float v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
   return v;
 }
 
