@@ -332,8 +332,13 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
             s = mfma16(frag_rm(Ks, kt, 1, lane), bq[1], s);
             dp = mfma16(frag_rm(Vs, kt, 0, lane), bdo[0], dp);
             dp = mfma16(frag_rm(Vs, kt, 1, lane), bdo[1], dp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dsv[u][r] = __builtin_amdgcn_exp2f(fmaf(s[r], sl, -lq2)) * fmaf(dp[r], scale, -dss);
+            // packed fp32 arithmetic (v_pk_fma / v_pk_mul): two elements per VALU instruction around the four exponentials
+            const f32x2_t s01 = (f32x2_t){s[0], s[1]} * sl - lq2, s23 = (f32x2_t){s[2], s[3]} * sl - lq2;
+            const f32x2_t e01 = (f32x2_t){dp[0], dp[1]} * scale - dss, e23 = (f32x2_t){dp[2], dp[3]} * scale - dss;
+            const f32x2_t p01 = (f32x2_t){__builtin_amdgcn_exp2f(s01[0]), __builtin_amdgcn_exp2f(s01[1])};
+            const f32x2_t p23 = (f32x2_t){__builtin_amdgcn_exp2f(s23[0]), __builtin_amdgcn_exp2f(s23[1])};
+            const f32x2_t d01 = p01 * e01, d23 = p23 * e23;
+            dsv[u] = (f32x4_t){d01[0], d01[1], d23[0], d23[1]};
           }
         }
         bf16x8_t b = pack_pair(dsv[0], dsv[1]);
@@ -390,12 +395,13 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
             dp = mfma16(frag_rm(dOs, qt, 1, lane), bv[1], dp);
             const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g);      // pre-scaled by log2(e)
             const f32x4_t d4 = *(const f32x4_t*)(dq_s + qt * 16 + 4 * g);       // pre-scaled by `scale`
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float p = __builtin_amdgcn_exp2f(fmaf(s[r], sl, -l4[r]));
-              pv2[u][r] = p;
-              ds2[u][r] = p * fmaf(dp[r], scale, -d4[r]);
-            }
+            const f32x2_t s01 = (f32x2_t){s[0], s[1]} * sl - (f32x2_t){l4[0], l4[1]}, s23 = (f32x2_t){s[2], s[3]} * sl - (f32x2_t){l4[2], l4[3]};
+            const f32x2_t e01 = (f32x2_t){dp[0], dp[1]} * scale - (f32x2_t){d4[0], d4[1]}, e23 = (f32x2_t){dp[2], dp[3]} * scale - (f32x2_t){d4[2], d4[3]};
+            const f32x2_t p01 = (f32x2_t){__builtin_amdgcn_exp2f(s01[0]), __builtin_amdgcn_exp2f(s01[1])};
+            const f32x2_t p23 = (f32x2_t){__builtin_amdgcn_exp2f(s23[0]), __builtin_amdgcn_exp2f(s23[1])};
+            const f32x2_t d01 = p01 * e01, d23 = p23 * e23;
+            pv2[u] = (f32x4_t){p01[0], p01[1], p23[0], p23[1]};
+            ds2[u] = (f32x4_t){d01[0], d01[1], d23[0], d23[1]};
           }
         }
         bf16x8_t bp = pack_pair(pv2[0], pv2[1]);
