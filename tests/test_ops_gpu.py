@@ -157,6 +157,27 @@ def test_gemm_epilogue_dropout_residual_bf16(ops):
         assert float(((f32 != 0) ^ kept).float().mean()) < 0.02
 
 
+def test_big_tile_gemm_and_attention_bit_reproducible(ops):
+    """Race screen: the 8-phase GEMM synchronises with counted vmcnt waits and two wave groups half a phase apart, the
+    attention kernels prefetch across (frame, head) items -- a too-early read of a staged buffer would make calls differ."""
+    M, N, K = 20000, 768, 768
+    a, b = rnd((M, K), 0.5, 31), rnd((N, K), 0.5, 32)
+    res = rnd((M, N), 1.0, 33)
+    ref = ops.gemm(a, b, M, N, K, res=res, tile=808).clone()
+    assert relerr(ref, a.float() @ b.float().t() + res.float()) < 1e-2
+    for _ in range(25):
+        assert torch.equal(ops.gemm(a, b, M, N, K, res=res, tile=808), ref)
+    frames, S, H = 60, 197, 12            # 720 items on 256 persistent workgroups
+    qkv = rnd((frames * S, 3 * H * 64), 1.0, 34)
+    o0, l0 = ops.vit_attn_fwd(qkv, frames, S, H)
+    o0, l0 = o0.clone(), l0.clone()
+    d0 = ops.vit_attn_bwd(qkv, o0, o0, l0, frames, S, H).clone()
+    for _ in range(8):
+        o, l = ops.vit_attn_fwd(qkv, frames, S, H)
+        assert torch.equal(o, o0) and torch.equal(l, l0)
+        assert torch.equal(ops.vit_attn_bwd(qkv, o0, o0, l0, frames, S, H), d0)
+
+
 def test_gemm_epilogue_dropout(ops):
     M, N, K = 256, 256, 64
     a, b = rnd((M, K), 0.5, 15), rnd((N, K), 0.5, 16)
