@@ -107,8 +107,21 @@ class ParamArena:
     def mark_shadow_current(self):
         self._version = self._current_version()
 
-    def attach_grads(self):
-        """Re-attach ``.grad`` views dropped by ``zero_grad(set_to_none=True)``; zero the buffer when that happened."""
+    def grads_attached(self):
+        """Cheap check (first / last parameter): ``zero_grad(set_to_none=True)`` drops every ``.grad`` or none."""
+        for n in (self.names[0], self.names[-1]):
+            p = self.params[n]
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self.offsets[n]:
+                return False
+        return True
+
+    def attach_grads(self, zero=True):
+        """Re-attach ``.grad`` views dropped by ``zero_grad(set_to_none=True)``; zero the buffer when that happened
+        (``zero=False``: only re-attach -- the buffer already holds this step's gradients).  Called at the start of every
+        fused forward AND backward node, so the reference's order forward -> optimizer.zero_grad() -> backward -> step
+        (func/train.py:221-233) works with any torch optimizer."""
+        if self.grads_attached():
+            return
         dropped = False
         for n in self.names:
             p = self.params[n]
@@ -116,7 +129,7 @@ class ParamArena:
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 dropped = True
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
-        if dropped:
+        if dropped and zero:
             self.grad.zero_()
 
     def zero_grad(self):

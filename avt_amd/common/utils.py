@@ -19,6 +19,17 @@ def accuracy(output, target, topk=(1,)):
         return [correct[:k].flatten().sum(dtype=torch.float32) * (100.0 / batch_size) for k in topk]
 
 
+def accuracy_from_rank(rank, target, topk=(1,)):
+    """Same numbers as ``accuracy`` from the target-rank vector the fused cross-entropy kernel emits (rank = number of logits
+    strictly above the target's, -1 for ignored rows): a row is a top-k hit iff 0 <= rank < k.  Rows with ignored targets
+    count as misses and an all-ignored batch gives zeros, as in the reference (common/utils.py:17-44)."""
+    with torch.no_grad():
+        rank = rank.flatten()
+        batch_size = target.numel()
+        valid = rank >= 0
+        return [((rank < k) & valid).sum(dtype=torch.float32) * (100.0 / batch_size) for k in topk]
+
+
 def is_dist_avail_and_initialized():
     return dist.is_available() and dist.is_initialized()
 

@@ -150,14 +150,49 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   for (int e = 0; e < 8; ++e) unsafeAtomicAdd(&out[c * 8 + e], acc[e]);
 }
 
-// feat loss (models/future_prediction.py:207-215): loss[b,t,:] = (dec[b,t,:] - x[b,t+1,:])^2, t < T-1 (fp32 out)
-__global__ __launch_bounds__(256) void mse_shift_fwd_kernel(const bf16_t* __restrict__ dec, const bf16_t* __restrict__ x,
+// feat loss (models/future_prediction.py:207-215, torch.nn.MSELoss(reduction='none')): loss[b,t,:] = (dec[b,t,:] - x[b,t+1,:])^2, t < T-1
+__global__ __launch_bounds__(256) void mse_shift_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ x,
                                                             float* __restrict__ loss, int B, int T, int F) {
   long n = (long)B * (T - 1) * F;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     int f = (int)(i % F); long r = i / F; int t = (int)(r % (T - 1)); int b = (int)(r / (T - 1));
-    float d = bf2f(dec[((size_t)b * T + t) * F + f]) - bf2f(x[((size_t)b * T + t + 1) * F + f]);
+    float d = dec[((size_t)b * T + t) * F + f] - x[((size_t)b * T + t + 1) * F + f];
     loss[i] = d * d;
+  }
+}
+// its backward: ddec[b,t,:] = 2 (dec[b,t] - x[b,t+1]) g[b,t] for t < T-1 (row T-1: 0);  dx[b,t,:] = -ddec[b,t-1,:] for t >= 1 (row 0: 0)
+__global__ __launch_bounds__(256) void mse_shift_bwd_kernel(const float* __restrict__ dec, const float* __restrict__ x,
+                                                            const float* __restrict__ g, float* __restrict__ ddec,
+                                                            float* __restrict__ dx, int B, int T, int F) {
+  long n = (long)B * T * F;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    int f = (int)(i % F); long r = i / F; int t = (int)(r % T); int b = (int)(r / T);
+    float a = 0.f, c = 0.f;
+    if (t < T - 1) a = 2.f * (dec[i] - x[i + F]) * g[((size_t)b * (T - 1) + t) * F + f];
+    if (t >= 1) c = -2.f * (dec[i - F] - x[i]) * g[((size_t)b * (T - 1) + t - 1) * F + f];
+    ddec[i] = a; dx[i] = c;
+  }
+}
+// fp32 [rows, cols] (row stride lds) -> bf16 [rows, ldd] with columns >= cols zero (classifier gradient padding)
+__global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__ src, int lds, bf16_t* __restrict__ dst, int ldd,
+                                                       int rows, int cols) {
+  long n = (long)rows * ldd;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    int c = (int)(i % ldd); long r = i / ldd;
+    dst[i] = c < cols ? f2bf(src[(size_t)r * lds + c]) : (bf16_t)0;
+  }
+}
+// dst[r, :] += src[r, :] for strided bf16 rows (the CLS rows of a [frames*S, D] tensor: ldd = S*D)
+__global__ __launch_bounds__(256) void add_rows_kernel(bf16_t* __restrict__ dst, long ldd, const bf16_t* __restrict__ src, long lds,
+                                                       int rows, int D) {
+  const int nch = D / 8;
+  long n = (long)rows * nch;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    int c = (int)(i % nch); long r = i / nch;
+    u32x4_t a = *(const u32x4_t*)(dst + r * ldd + c * 8), b = *(const u32x4_t*)(src + r * lds + c * 8), o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2bf(bflo(a[e]) + bflo(b[e]), bfhi(a[e]) + bfhi(b[e]));
+    *(u32x4_t*)(dst + r * ldd + c * 8) = o;
   }
 }
 }  // namespace
@@ -238,10 +273,33 @@ extern "C" int avt_colsum_bf16(const void* x, int ld, float* out, int M, int N, 
   AVT_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int avt_mse_shift_fwd(const void* dec, const void* x, float* loss, int B, int T, int F, void* stream) {
+extern "C" int avt_mse_shift_fwd(const float* dec, const float* x, float* loss, int B, int T, int F, void* stream) {
   AVT_CHECK(dec && x && loss && B > 0 && T > 1 && F > 0, "avt_mse_shift_fwd: bad argument");
   long n = (long)B * (T - 1) * F;
-  hipLaunchKernelGGL(mse_shift_fwd_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dec, (const bf16_t*)x, loss, B, T, F);
+  hipLaunchKernelGGL(mse_shift_fwd_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, (hipStream_t)stream, dec, x, loss, B, T, F);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_mse_shift_bwd(const float* dec, const float* x, const float* gloss, float* ddec, float* dx, int B, int T, int F,
+                                 void* stream) {
+  AVT_CHECK(dec && x && gloss && ddec && dx && B > 0 && T > 1 && F > 0, "avt_mse_shift_bwd: bad argument");
+  long n = (long)B * T * F;
+  hipLaunchKernelGGL(mse_shift_bwd_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, (hipStream_t)stream, dec, x, gloss, ddec, dx, B, T, F);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_pad_cast_f32_to_bf16(const float* src, int lds, void* dst, int ldd, int rows, int cols, void* stream) {
+  AVT_CHECK(src && dst && rows > 0 && cols > 0 && ldd >= cols && lds >= cols, "avt_pad_cast_f32_to_bf16: bad argument");
+  long n = (long)rows * ldd;
+  hipLaunchKernelGGL(pad_cast_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, (hipStream_t)stream, src, lds, (bf16_t*)dst, ldd, rows, cols);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_add_rows_bf16(void* dst, long ldd, const void* src, long lds, int rows, int D, void* stream) {
+  AVT_CHECK(dst && src && rows > 0 && D > 0, "avt_add_rows_bf16: bad argument");
+  AVT_CHECK(D % 8 == 0 && ldd % 8 == 0 && lds % 8 == 0 && aligned16(dst) && aligned16(src), "avt_add_rows_bf16: D and strides must be multiples of 8, pointers 16-byte aligned");
+  long n = (long)rows * (D / 8);
+  hipLaunchKernelGGL(add_rows_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst, ldd, (const bf16_t*)src, lds, rows, D);
   AVT_LAUNCH_CHECK();
   return 0;
 }

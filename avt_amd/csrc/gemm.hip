@@ -40,10 +40,23 @@ struct GemmParams {
   int tiles_m, tiles_n;
   uint32_t a_bytes, b_bytes;     // buffer-descriptor bounds
   uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
-  int stagger;                   // cycles over which the first wave of workgroups spreads its start (0 = off)
+#ifdef AVT_LAB
+  int stagger;                   // lab only: cycles over which the first wave of workgroups spreads its start (0 = off)
+#endif
   int wide_ok;                   // all epilogue leading dims are multiples of 8 -> 16-byte accesses allowed
-  long long* dbg;                // lab only: per-block phase timestamps (s_memtime), NULL in production
+#ifdef AVT_LAB
+  long long* dbg;                // lab only: per-block phase timestamps (s_memtime)
+#endif
 };
+// Instrumentation and experiment switches exist only in the lab build (make lab -> libavt_hip_lab.so, used by tools/):
+// the product library reads no environment variable and takes no pointer from anywhere but its arguments.
+#ifdef AVT_LAB
+#define AVT_DBG(p) ((p).dbg)
+#define AVT_STAGGER(p) ((p).stagger)
+#else
+#define AVT_DBG(p) ((long long*)nullptr)
+#define AVT_STAGGER(p) 0
+#endif
 
 constexpr int BK64 = 64;
 
@@ -688,7 +701,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
   const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
   const int nk = kt_end - kt_begin;
-  stagger_start(p.stagger, bid);
+  stagger_start(AVT_STAGGER(p), bid);
 
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
@@ -712,7 +725,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   };
 
   long long t_start = 0, t_loop = 0;
-  if (p.dbg) t_start = __builtin_readcyclecounter();
+  if (AVT_DBG(p)) t_start = __builtin_readcyclecounter();
   // NSTAGE-deep LDS ring, one barrier per K tile: iteration `it` waits (counted vmcnt) until its own tile has
   // landed while up to NSTAGE-2 younger tiles stay in flight across the barrier, then refills the slot that was
   // consumed in iteration it-1 with tile it+NSTAGE-1, then computes.
@@ -857,13 +870,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
     if (++slot == NSTAGE) slot = 0;
   }
   asm volatile("s_barrier" ::: "memory");   // every wave is done reading the ring before the epilogue reuses it
-  if (p.dbg) t_loop = __builtin_readcyclecounter();
+  if (AVT_DBG(p)) t_loop = __builtin_readcyclecounter();
 
   gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
-  if (p.dbg && tid == 0) {
+  if (AVT_DBG(p) && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     long long t_end = __builtin_readcyclecounter();
-    p.dbg[bid * 4 + 0] = t_start; p.dbg[bid * 4 + 1] = t_loop; p.dbg[bid * 4 + 2] = t_end; p.dbg[bid * 4 + 3] = nk;
+    long long* d_ = AVT_DBG(p);
+    d_[bid * 4 + 0] = t_start; d_[bid * 4 + 1] = t_loop; d_[bid * 4 + 2] = t_end; d_[bid * 4 + 3] = nk;
   }
 }
 
@@ -929,6 +943,7 @@ int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk,
              : dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 0, SPREAD, PR, MINW, NWL>(p, a_kmajor, b_kmajor, s);
 }
 
+#ifdef AVT_LAB   // ---- lab-only kernel variants (negative results kept for A/B in tools/): not part of libavt_hip.so ----
 // ---- ping-pong kernel: 256x256 tile, 8 waves = two groups of four, half-K-tile ring ---------------------------
 // Group g owns the 128-row half g of the tile (wave tile 128x64).  Waves w and w+4 share a SIMD; the groups run the
 // same program one phase apart, so on every SIMD one wave issues its 16 MFMAs from registers (compute phase) while
@@ -1256,6 +1271,8 @@ int dispatch_deepa(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int split
   return launch_deepa<false, true, 1>(p, s);
 }
 
+#endif  // AVT_LAB
+
 // ---- 8-phase kernel: 256x256x64 tile, two wave groups half a phase apart, half-tile ring 1.5 K tiles deep ---------
 // The K tile is consumed in four phases, one 64x32 quadrant of the 128x64 wave tile each; every phase is
 //     L: ds_read the operand sub-tiles the quadrant still needs, issue 2 LDS-DMA instructions (1/8 of one 16-KB
@@ -1523,8 +1540,10 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldres = ldres; p.ldaux = ldaux;
   p.res_period = res_period; p.act = act; p.out_f32 = (out_mode == 1);
   p.drop_thresh = drop_threshold(drop_p); p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed;
+#ifdef AVT_LAB
   { static const char* e2 = getenv("AVT_GEMM_STAGGER"); p.stagger = e2 ? atoi(e2) : 0; }
   { static const char* e = getenv("AVT_GEMM_DBG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
   size_t a_rows = a_kmajor ? (size_t)M : (size_t)K, b_rows = b_kmajor ? (size_t)N : (size_t)K;
   size_t ab = a_rows * (size_t)lda * 2, bb = b_rows * (size_t)ldb * 2;
   AVT_CHECK(ab < 0xFFFFFFF0ull && bb < 0xFFFFFFF0ull, "avt_gemm_bf16: operand larger than 4 GiB");
@@ -1565,10 +1584,12 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
     case 808:                                                                                     // 8-phase schedule (needs K % 64 == 0 for k-major operands)
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_8p(p, epi, a_kmajor, b_kmajor, splitk, s);
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
+#ifdef AVT_LAB
     case 258: return dispatch_deepa(p, epi, a_kmajor, b_kmajor, splitk, s);                          // A ring 3 deep, B ring 2 deep
     case 512: return dispatch_pp(p, epi, a_kmajor, b_kmajor, splitk, s);                            // ping-pong 256x256
+#endif
     default: break;
   }
-  avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 64, 128, 256 (one barrier per K tile), 808 (8-phase), 258 (deep-A ring) or 512 (ping-pong) (got %d)", tile);
+  avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 64, 128, 643, 256 / 2568 (one barrier per K tile) or 808 (8-phase) (got %d)", tile);
   return -1;
 }

@@ -476,8 +476,12 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
   (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   const bool all_live = S > (NKT - 1) * 16;
+#ifdef AVT_LAB            // per-phase cycle stamps for tools/: the product library takes no pointer from the environment
   static const char* e = getenv("AVT_ATTN_DBG_PTR");
   long long* dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr;
+#else
+  long long* dbg = nullptr;
+#endif
   const int items = frames * H;
   // persistent: one workgroup per CU when the tiles of a head need most of the LDS, more for short sequences
   const int per_cu = (int)((160 * 1024) / sm) < 1 ? 1 : (int)((160 * 1024) / sm);

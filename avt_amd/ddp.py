@@ -28,9 +28,10 @@ class GradReducer:
         self._lo = self.arena.total         # everything in [_lo, total) has been produced
         self._sent = self.arena.total       # everything in [_sent, total) has been handed to the collective
         self._handles = []
-        for m in model.modules():
-            if hasattr(m, 'grad_ready_hook'):
-                m.grad_ready_hook = self._segment_ready
+        self._hooked = [m for m in model.modules() if hasattr(m, 'grad_ready_hook')]
+        self._seen = {}
+        for m in self._hooked:
+            m.grad_ready_hook = (lambda first, last, _m=m: self._segment_ready(_m, first, last))
 
     @staticmethod
     def broadcast_parameters(model, src=0):
@@ -42,9 +43,19 @@ class GradReducer:
     def start_step(self):
         self._lo = self._sent = self.arena.total
         self._handles = []
+        self._seen = {}
+        for m in self._hooked:
+            m._fwd_calls = 0
 
-    def _segment_ready(self, first_param, last_param):
+    def _segment_ready(self, module, first_param, last_param):
+        """A fused node finished writing the gradients of [first_param, last_param].  A module that ran forward k times
+        this step (multi-crop clips: one node per crop, models/base_model.py:251-273) accumulates into the same range k
+        times: the range only counts as finished after the k-th backward."""
         a = self.arena
+        key = id(first_param)
+        self._seen[key] = self._seen.get(key, 0) + 1
+        if self._seen[key] < max(getattr(module, '_fwd_calls', 1), 1):
+            return
         start = a.offsets[a.name_of[id(first_param)]]
         self._lo = min(self._lo, start)
         if self.world > 1 and self.overlap:

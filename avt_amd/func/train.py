@@ -25,9 +25,11 @@ def build_model(cfg, num_classes: Dict[str, int], class_mappings=None, device='c
     return model.to(device)
 
 
-def _param_groups(model, lr_wd, world_size, bias_bn_wd_scale=1.0):
+def _param_groups(model, lr_wd, world_size, bias_bn_wd_scale=1.0, lr_mult=1.0):
     """func/train.py:696-742: per ``opt.lr_wd`` entry two groups (names ending in 'bias' or containing '.bn' get the
-    weight decay scaled), LR multiplied by the number of replicas, zero-LR groups dropped."""
+    weight decay scaled), LR multiplied by the number of replicas (and by the batch size with ``opt.scale_lr_by_bs``),
+    zero-LR groups dropped and their parameters frozen (``requires_grad = False``, func/train.py:735-742) -- a frozen
+    backbone then skips its backward and its gradient range is never touched."""
     groups = []
     for modules, lr, wd in lr_wd:
         if not isinstance(modules, (list, tuple)):
@@ -38,8 +40,10 @@ def _param_groups(model, lr_wd, world_size, bias_bn_wd_scale=1.0):
             named.extend((mod_name + '.' + n, p) for n, p in mod.named_parameters() if p.requires_grad)
         decay = [p for n, p in named if not (n.endswith('bias') or '.bn' in n)]
         no_decay = [p for n, p in named if (n.endswith('bias') or '.bn' in n)]
-        this_lr = lr * world_size
+        this_lr = lr * world_size * lr_mult
         if this_lr == 0:
+            for p in decay + no_decay:
+                p.requires_grad = False
             continue
         groups.append({'params': decay, 'lr': this_lr, 'weight_decay': wd})
         groups.append({'params': no_decay, 'lr': this_lr, 'weight_decay': wd * bias_bn_wd_scale})
@@ -56,7 +60,10 @@ def _get_submodule(model, dotted):
 def build_optimizer(cfg, model, world_size=1):
     """func/train.py:744 ``hydra.utils.instantiate(cfg.opt.optimizer, params)``; ``_target_: torch.optim.SGD`` maps to the
     fused arena optimizer (same hyper-parameters, same update rule)."""
-    groups = _param_groups(model, cfg.opt.lr_wd, world_size, cfg.opt.get('bias_bn_wd_scale', 1.0))
+    if cfg.opt.get('classifier_only', False):                    # func/train.py:692-695 (the BN freeze there is a no-op: ViT / GPT-2 have no BN)
+        assert len(cfg.opt.lr_wd) == 1 and cfg.opt.lr_wd[0][0] == 'classifier'
+    lr_mult = cfg.train.batch_size if cfg.opt.get('scale_lr_by_bs', False) else 1.0      # func/train.py:718-720
+    groups = _param_groups(model, cfg.opt.lr_wd, world_size, cfg.opt.get('bias_bn_wd_scale', 1.0), lr_mult)
     oc = dict(cfg.opt.optimizer)
     target = oc.pop('_target_', 'torch.optim.SGD')
     if target == 'torch.optim.SGD':
@@ -86,15 +93,17 @@ class Trainer:
     all-reduce), step -> lr_scheduler.step().  The NaN check / ``loss.item()`` host syncs of the reference are made
     optional (``sync_loss``) because they stall the launch queue."""
     def __init__(self, model, train_eval_op, optimizer, lr_scheduler=None, loss_wts=None, distributed=False,
-                 bucket_bytes=256 << 20):
+                 bucket_bytes=64 << 20, grad_clip=None):
         self.model, self.op, self.optimizer, self.lr_scheduler = model, train_eval_op, optimizer, lr_scheduler
         self.loss_wts = dict(loss_wts or {})
+        self.fused = isinstance(optimizer, FusedSGD)
+        gc = dict(grad_clip or {})
+        self.max_norm = gc.get('max_norm', None)                 # conf/config.yaml train_one_epoch_fn.grad_clip_params
+        self.norm_type = float(gc.get('norm_type', 2.0))
         self.world = utils.get_world_size() if distributed else 1
         self.reducer = GradReducer(model, bucket_bytes=bucket_bytes) if self.world > 1 else None
         if self.reducer is not None:
             GradReducer.broadcast_parameters(model)
-            if hasattr(optimizer, 'grad_scale'):
-                optimizer.grad_scale = 1.0 / self.world
         self.last_losses = {}
 
     def total_loss(self, losses):
@@ -106,15 +115,33 @@ class Trainer:
                 final = term if final is None else final + term
         return final
 
+    def _clip_coef(self, pre_scale):
+        """torch.nn.utils.clip_grad_norm_ over the parameters being optimised, as one reduction over their arena ranges."""
+        a = self.model.arena
+        norms = []
+        for g in self.optimizer.param_groups:
+            for p in g['params']:
+                n = a.name_of[id(p)]
+                norms.append(torch.linalg.vector_norm(a.grad[a.offsets[n]:a.offsets[n] + a.sizes[n]], self.norm_type))
+        total = torch.linalg.vector_norm(torch.stack(norms), self.norm_type) * pre_scale
+        return float(torch.clamp(self.max_norm / (total + 1e-6), max=1.0))
+
     def step(self, data, sync_loss=False):
         if self.reducer is not None:
             self.reducer.start_step()
         data, outputs, losses, accuracies = self.op(data, train_mode=True)
         loss = self.total_loss(losses)
-        self.optimizer.zero_grad()
-        loss.backward()
+        self.optimizer.zero_grad()          # FusedSGD: no-op (its step re-zeroes); torch optimizers drop / zero the .grad views
+        loss.backward()                     # fused nodes re-attach the views and write the flat gradient buffer
         if self.reducer is not None:
             self.reducer.finish()
+        scale = 1.0 / self.world
+        if self.max_norm is not None:       # func/train.py:224-231 (norm of the averaged gradients)
+            scale *= self._clip_coef(scale)
+        if self.fused:
+            self.optimizer.grad_scale = scale
+        elif scale != 1.0:
+            self.model.arena.grad.mul_(scale)
         self.optimizer.step()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()
@@ -139,7 +166,8 @@ def main(cfg, steps=10, batch_size=None, log_every=1):
     iters_per_epoch = cfg.get('synthetic', Cfg()).get('iters_per_epoch', 100)
     lr_sched = build_schedulers(cfg, optimizer, iters_per_epoch, world)
     op = instantiate(cfg.train_eval_op, model, device, None, _recursive_=False)
-    trainer = Trainer(model, op, optimizer, lr_sched, cfg.train.train_one_epoch_fn.loss_wts, distributed=dist_on)
+    trainer = Trainer(model, op, optimizer, lr_sched, cfg.train.train_one_epoch_fn.loss_wts, distributed=dist_on,
+                      grad_clip=cfg.train.train_one_epoch_fn.get('grad_clip_params', None))
     feat_shape = tuple(cfg.get('synthetic', Cfg()).get('feat_shape', (3, 1, 224, 224)))
     data = synthetic_batch(B, T, C, device, seed=cfg.get('seed', 42) + rank, feat_shape=feat_shape)
     for it in range(steps):

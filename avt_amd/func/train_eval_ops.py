@@ -32,8 +32,8 @@ class BasicLossAccuracy(nn.Module):
         for tgt_type, tgt_val in target.items():
             logits = outputs[f'logits/{tgt_type}']
             assert logits.ndim == tgt_val.ndim + 1
-            losses[f'cls_{tgt_type}'] = self.cls_criterion(logits, tgt_val)
-            acc1, acc5 = utils.accuracy(logits, tgt_val, topk=(1, min(5, logits.size(-1))))
+            losses[f'cls_{tgt_type}'], rank = self.cls_criterion.forward_with_rank(logits, tgt_val)
+            acc1, acc5 = utils.accuracy_from_rank(rank, tgt_val, topk=(1, min(5, logits.size(-1))))
             accuracies[f'acc1/{tgt_type}'] = acc1
             accuracies[f'acc5/{tgt_type}'] = acc5
             past_key = f'{PAST_LOGITS_PREFIX}logits/{tgt_type}'

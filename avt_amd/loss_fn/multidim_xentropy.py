@@ -39,11 +39,16 @@ class MultiDimCrossEntropy(nn.Module):
             raise NotImplementedError('class-weighted cross entropy is outside the accelerated path')
         self.ignore_index, self.reduction = ignore_index, reduction
 
-    def forward(self, inp, tgt):
+    def forward_with_rank(self, inp, tgt):
+        """(loss, rank): rank[...] = number of logits strictly above the target's (-1 where the target is ignored) -- what
+        top-k accuracy needs, from the same pass over the logits (common/utils.py:17-44 would run a second top-k)."""
         assert inp.ndim == tgt.ndim + 1
         assert inp.shape[:-1] == tgt.shape
-        loss, _ = cross_entropy_with_rank(inp.reshape(-1, inp.size(-1)), tgt.reshape(-1), self.ignore_index)
+        loss, rank = cross_entropy_with_rank(inp.reshape(-1, inp.size(-1)), tgt.reshape(-1), self.ignore_index)
         if self.reduction == 'none':
-            return loss.reshape(tgt.shape)
+            return loss.reshape(tgt.shape), rank.reshape(tgt.shape)
         valid = (tgt.reshape(-1) != self.ignore_index).sum().clamp(min=1)
-        return loss.sum() / valid if self.reduction == 'mean' else loss.sum()
+        return (loss.sum() / valid if self.reduction == 'mean' else loss.sum()), rank.reshape(tgt.shape)
+
+    def forward(self, inp, tgt):
+        return self.forward_with_rank(inp, tgt)[0]

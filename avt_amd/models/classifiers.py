@@ -48,13 +48,13 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        ctx.arena.attach_grads()          # .grad views dropped between forward and backward (optimizer.zero_grad())
         m, arena, xb = ctx.m, ctx.arena, ctx.xb
         R = xb.size(0)
-        d = torch.zeros((R, m.out_padded), device=dout.device, dtype=torch.bfloat16)
-        d[:, :m.out_features] = dout.reshape(R, m.out_features)
+        d = ops.pad_cast_to_bf16(dout.reshape(R, m.out_features).float().contiguous(), m.out_padded)   # zero padding columns
         w = arena.sh(m.weight, rows=m.out_padded)
         ops.linear_wgrad(d, xb, arena.gr(m.weight, rows=m.out_padded), rows=m.out_features)
         if m.bias is not None:
-            arena.gr(m.bias).add_(d[:, :m.out_features].float().sum(0))
+            ops.colsum(d, arena.gr(m.bias, rows=m.out_padded))
         dx = ops.linear_dgrad(d, w, out_mode=ops.OUT_F32)
         return None, None, dx.reshape(ctx.lead + (m.in_features,)), None

@@ -3,8 +3,9 @@
 Same constructor arguments, ``forward(feats, target_shape) -> (past, future, losses, endpoints)`` contract and
 state_dict layout as the reference (``encoder.weight (Dh,in)``, ``decoder.weight (in,Dh)``, ``gpt_model.wpe.weight``,
 ``gpt_model.h.{i}.{ln_1,ln_2}``, ``attn.{c_attn,c_proj}``, ``mlp.{c_fc,c_proj}`` with HF Conv1D (in,out) weights,
-``gpt_model.ln_f``).  Scope: the non-quantised path with ``output_len == 1`` -- the configuration of
-every AVT experiment; the KV-cache roll-out and the k-means variants raise NotImplementedError.
+``gpt_model.ln_f``).  Scope: the non-quantised path.  Training uses ``output_len == 1`` (the configuration of every AVT
+experiment); ``output_len > 1`` is the forward-only roll-out with a KV cache (reference :168-202, eval / no_grad only);
+the k-means variants raise NotImplementedError.
 
 encoder -> +wpe, embd-dropout -> n_layer x {LN, c_attn, causal attention (+attn dropout), c_proj (+resid dropout)
 + residual, LN, c_fc + gelu_new, c_proj (+dropout) + residual} -> ln_f -> decoder is ONE autograd node; the
@@ -129,8 +130,15 @@ class AVTh(nn.Module):
         if torch.is_grad_enabled():
             arena.attach_grads()
         keep = torch.is_grad_enabled()
+        if keep:
+            self._fwd_calls = getattr(self, '_fwd_calls', 0) + 1
         seed = (next(AVTh._seed_counter) * 1000003) if self.training else 0
         return _HeadFn.apply(self, arena, keep, self.training, seed, feats, self.encoder.weight)
+
+    def _rollout(self, feats, output_len):
+        arena = get_arena(self)
+        arena.refresh_shadow()
+        return _head_rollout(self, arena, feats.float(), output_len)
 
     def forward(self, feats, target_shape):
         addl_endpoints = {}
@@ -142,14 +150,22 @@ class AVTh(nn.Module):
             output_len = self.output_len
         else:
             output_len = self.output_len_eval
-        if output_len != 1:
-            raise NotImplementedError('roll-out with output_len != 1 (KV cache) is outside the accelerated path (SURVEY 8f)')
         orig_len = feats.size(1)
-        all_outputs = self._decode_all(feats)                                    # reference :163-203
+        if output_len == 1:
+            all_outputs = self._decode_all(feats)                                # reference :163-203, one GPT-2 call
+        elif output_len > 1:
+            if torch.is_grad_enabled():
+                raise NotImplementedError('roll-out with output_len > 1 is implemented forward-only (eval, torch.no_grad)')
+            all_outputs = self._rollout(feats, output_len)                       # reference :168-202 with the KV cache
+        else:
+            raise NotImplementedError('output_len <= 0 (no GPT-2 call) is not a configuration of the AVT experiments')
         losses = {}
         if self.future_pred_loss is not None:                                    # reference :205-215
             n = min(feats.size(1), all_outputs.size(1))
-            losses = {'feat': self.future_pred_loss(all_outputs[:, :n - 1], feats[:, 1:n])}
+            if isinstance(self.future_pred_loss, nn.MSELoss) and feats.is_cuda:
+                losses = {'feat': _MseShiftFn.apply(all_outputs[:, :n].contiguous(), feats[:, :n].float().contiguous())}
+            else:
+                losses = {'feat': self.future_pred_loss(all_outputs[:, :n - 1], feats[:, 1:n])}
         prev = feats
         if self.return_past_too:                                                 # reference :232-240
             final = torch.cat((prev, all_outputs[:, orig_len - 1:, :]), dim=1)
@@ -161,6 +177,68 @@ class AVTh(nn.Module):
             final = torch.mean(final[:, -self.avg_last_n:, :], dim=1)
         updated_past = torch.cat([prev[:, :1, :], all_outputs[:, :(orig_len - 1)]], dim=1)   # reference :249-250
         return updated_past, final, losses, addl_endpoints
+
+
+class _MseShiftFn(torch.autograd.Function):
+    """``MSELoss(reduction='none')(decoded[:, :T-1], feats[:, 1:T])`` (reference :207-215) as one kernel each way."""
+    @staticmethod
+    def forward(ctx, dec, x):
+        ctx.save_for_backward(dec, x)
+        return ops.mse_shift_fwd(dec, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        dec, x = ctx.saved_tensors
+        return ops.mse_shift_bwd(dec, x, g.float().contiguous())
+
+
+@torch.no_grad()
+def _head_rollout(m: AVTh, arena, x, output_len):
+    """Forward-only roll-out (reference :168-202): the first GPT-2 call sees the T observed frames; every further call feeds
+    the last hidden state (ln_f output) of the newest token back as the next input embedding at position T + step - 1 and
+    attends over the cached keys / values of all earlier tokens.  Returns decoder(all hidden states) (B, T+output_len-1, C)."""
+    B, T, C = x.shape
+    E, H = m.inter_dim, m.n_head
+    hd = E // H
+    sh = arena.sh
+    g = m.gpt_model
+    tmax = T + output_len - 1
+    assert tmax <= g.wpe.weight.size(0), 'roll-out longer than n_positions'
+    xb = x.reshape(B * T, C).to(torch.bfloat16).contiguous()
+    enc = ops.linear_fwd(xb, sh(m.encoder.weight))
+    h = ops.embed_pos_fwd(enc, g.wpe.weight, B, T, E, 0.0, 0)
+    caches = []
+    for blk in g.h:
+        l1, _, _ = ops.layernorm_fwd(h, blk.ln_1.weight, blk.ln_1.bias, m.ln_eps, save_stats=False)
+        qkv = ops.conv1d_fwd(l1, sh(blk.attn.c_attn.weight), bias=blk.attn.c_attn.bias)
+        kc = torch.zeros((B, tmax, E), device=x.device, dtype=torch.bfloat16)
+        vc = torch.zeros((B, tmax, E), device=x.device, dtype=torch.bfloat16)
+        q3 = qkv.view(B, T, 3 * E)
+        kc[:, :T].copy_(q3[:, :, E:2 * E])
+        vc[:, :T].copy_(q3[:, :, 2 * E:])
+        caches.append((kc, vc))
+        att, _ = ops.causal_attn_fwd(qkv, B, T, H, hd, 0.0, 0)
+        h1 = ops.conv1d_fwd(att, sh(blk.attn.c_proj.weight), bias=blk.attn.c_proj.bias, res=h)
+        l2, _, _ = ops.layernorm_fwd(h1, blk.ln_2.weight, blk.ln_2.bias, m.ln_eps, save_stats=False)
+        a = ops.conv1d_fwd(l2, sh(blk.mlp.c_fc.weight), bias=blk.mlp.c_fc.bias, act=ops.ACT_GELU_TANH)
+        h = ops.conv1d_fwd(a, sh(blk.mlp.c_proj.weight), bias=blk.mlp.c_proj.bias, res=h1)
+    lf, _, _ = ops.layernorm_fwd(h, g.ln_f.weight, g.ln_f.bias, m.ln_eps, save_stats=False)
+    outs = [ops.linear_fwd(lf, sh(m.decoder.weight), out_mode=ops.OUT_F32).view(B, T, C)]
+    feats = lf.view(B, T, E)[:, -1].contiguous()                     # last hidden state of the newest token
+    for step in range(1, output_len):
+        pos = T + step - 1
+        h = ops.embed_pos_fwd(feats, g.wpe.weight[pos:pos + 1], B, 1, E, 0.0, 0)
+        for blk, (kc, vc) in zip(g.h, caches):
+            l1, _, _ = ops.layernorm_fwd(h, blk.ln_1.weight, blk.ln_1.bias, m.ln_eps, save_stats=False)
+            qkv = ops.conv1d_fwd(l1, sh(blk.attn.c_attn.weight), bias=blk.attn.c_attn.bias)
+            att = ops.causal_attn_decode(qkv, kc, vc, B, H, hd, pos)
+            h1 = ops.conv1d_fwd(att, sh(blk.attn.c_proj.weight), bias=blk.attn.c_proj.bias, res=h)
+            l2, _, _ = ops.layernorm_fwd(h1, blk.ln_2.weight, blk.ln_2.bias, m.ln_eps, save_stats=False)
+            a = ops.conv1d_fwd(l2, sh(blk.mlp.c_fc.weight), bias=blk.mlp.c_fc.bias, act=ops.ACT_GELU_TANH)
+            h = ops.conv1d_fwd(a, sh(blk.mlp.c_proj.weight), bias=blk.mlp.c_proj.bias, res=h1)
+        feats, _, _ = ops.layernorm_fwd(h, g.ln_f.weight, g.ln_f.bias, m.ln_eps, save_stats=False)
+        outs.append(ops.linear_fwd(feats, sh(m.decoder.weight), out_mode=ops.OUT_F32).view(B, 1, C))
+    return torch.cat(outs, dim=1)
 
 
 def _head_forward(m: AVTh, arena, x, keep, training, seed):
@@ -246,6 +324,7 @@ class _HeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ddec):
+        ctx.arena.attach_grads()          # .grad views dropped between forward and backward (optimizer.zero_grad())
         dx = _head_backward(ctx.module, ctx.arena, ctx.saved, ddec)
         ctx.saved = None
         return None, None, None, None, None, dx, None

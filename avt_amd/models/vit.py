@@ -54,6 +54,11 @@ class _PatchEmbed(nn.Module):
 
 class HipViT(nn.Module):
     EPS = 1e-6
+    # timm's forward_features returns x[:, 0] after the final norm, so in the LAST block only token 0 of the attention /
+    # proj / MLP outputs is ever consumed, in both directions: that block runs its k|v projection on all
+    # tokens and everything else on the CLS rows only (10/12 of one block's GEMM work and its attention disappear; results
+    # are identical).  False = the generic all-token path for every block (kept for the parity tests).
+    cls_only_last_block = True
 
     def __init__(self, embed_dim=768, depth=12, num_heads=12, img_size=224):
         super().__init__()
@@ -72,11 +77,16 @@ class HipViT(nn.Module):
 
     def forward(self, frames):
         """frames fp32 (N, 3, H, W) -> CLS features fp32 (N, D)."""
+        if tuple(frames.shape[-2:]) != (self.img_size, self.img_size) or frames.size(1) != 3:
+            raise ValueError(f'HipViT was built for 3x{self.img_size}x{self.img_size} frames (pos_embed has {self.seq} '
+                             f'positions), got {tuple(frames.shape[1:])}')
         arena = get_arena(self)
         arena.refresh_shadow()
         if torch.is_grad_enabled():
             arena.attach_grads()
         keep = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if keep:
+            self._fwd_calls = getattr(self, '_fwd_calls', 0) + 1
         return _ViTFn.apply(self, arena, keep, frames, self.cls_token)   # one parameter stands in for all of them
 
 
@@ -88,8 +98,9 @@ def _vit_forward(m: HipViT, arena, frames, keep):
     patches = ops.im2col_patch16(frames)
     R = ops.posres_prep(m.pos_embed, m.cls_token, m.patch_embed.proj.bias, S, D)
     x = ops.gemm(patches, sh(m.patch_embed.proj.weight).view(D, 768), M, D, 768, res=R, res_period=S)
-    saved = {'patches': patches if keep else None, 'blocks': []}
-    for blk in m.blocks:
+    saved = {'patches': patches if keep else None, 'blocks': [], 'cls_last': bool(m.cls_only_last_block)}
+    full_blocks = m.blocks[:-1] if m.cls_only_last_block else m.blocks
+    for blk in full_blocks:
         ln1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, m.EPS)
         qkv = ops.linear_fwd(ln1, sh(blk.attn.qkv.weight), bias=blk.attn.qkv.bias)
         att, lse = ops.vit_attn_fwd(qkv, N, S, H)
@@ -101,9 +112,66 @@ def _vit_forward(m: HipViT, arena, frames, keep):
         if keep:
             saved['blocks'].append((x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act))
         x = x2
-    feat, meanf, rstdf = ops.layernorm_fwd(x, m.norm.weight, m.norm.bias, m.EPS, rows=N, ldx=S * D)
+    if m.cls_only_last_block:
+        x, last = _last_block_forward(m, arena, m.blocks[-1], x, N, keep)          # x: [N, D], the CLS rows only
+        if keep:
+            saved['blocks'].append(last)
+        feat, meanf, rstdf = ops.layernorm_fwd(x, m.norm.weight, m.norm.bias, m.EPS)
+    else:
+        feat, meanf, rstdf = ops.layernorm_fwd(x, m.norm.weight, m.norm.bias, m.EPS, rows=N, ldx=S * D)
     saved['final'] = (x, meanf, rstdf) if keep else None
     return feat, saved
+
+
+def _cls_rows(t, N, S, D):
+    """The CLS rows of a [N*S, D] token tensor as a strided [N, D] view (row stride S*D)."""
+    return t.view(N, S * D)[:, :D]
+
+
+def _last_block_forward(m: HipViT, arena, blk, x, N, keep):
+    """Last block, CLS-only: k|v for every token, q / attention / proj / MLP for token 0 of each frame."""
+    D, H, S = m.embed_dim, m.num_heads, m.seq
+    sh = arena.sh
+    ln1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, m.EPS)
+    wqkv, bqkv = sh(blk.attn.qkv.weight), blk.attn.qkv.bias.detach()
+    kv = ops.linear_fwd(ln1, wqkv[D:], bias=bqkv[D:])                                   # [N*S, 2D]
+    q = ops.linear_fwd(_cls_rows(ln1, N, S, D), wqkv[:D], bias=bqkv[:D])               # [N, D]
+    att, probs = ops.cls_attn_fwd(q, kv, N, S, H)
+    x1 = ops.linear_fwd(att, sh(blk.attn.proj.weight), bias=blk.attn.proj.bias, res=_cls_rows(x, N, S, D))
+    ln2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, m.EPS)
+    pre = torch.empty((N, 4 * D), device=x.device, dtype=torch.bfloat16) if keep else None
+    act = ops.linear_fwd(ln2, sh(blk.mlp.fc1.weight), bias=blk.mlp.fc1.bias, act=ops.ACT_GELU_ERF, c2=pre)
+    x2 = ops.linear_fwd(act, sh(blk.mlp.fc2.weight), bias=blk.mlp.fc2.bias, res=x1)
+    return x2, ((x, mean1, rstd1, ln1, kv, q, probs, att, x1, mean2, rstd2, ln2, pre, act) if keep else None)
+
+
+def _last_block_backward(m: HipViT, arena, blk, saved, dx2, N, prev_bias):
+    """dx2 [N, D] = gradient of the block's CLS-row output; returns the gradient of the block's (all-token) input."""
+    D, H, S = m.embed_dim, m.num_heads, m.seq
+    sh, gr = arena.sh, arena.gr
+    (x, mean1, rstd1, ln1, kv, q, probs, att, x1, mean2, rstd2, ln2, pre, act) = saved
+    ops.linear_wgrad(dx2, act, gr(blk.mlp.fc2.weight))
+    dh = ops.linear_dgrad(dx2, sh(blk.mlp.fc2.weight), act=ops.ACT_MUL_AUX, aux=pre, colsum=gr(blk.mlp.fc1.bias))
+    ops.linear_wgrad(dh, ln2, gr(blk.mlp.fc1.weight))
+    dln2 = ops.linear_dgrad(dh, sh(blk.mlp.fc1.weight))
+    dx1 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, blk.norm2.weight, gr(blk.norm2.weight), gr(blk.norm2.bias),
+                            dres=dx2, colsum=gr(blk.attn.proj.bias))
+    ops.linear_wgrad(dx1, att, gr(blk.attn.proj.weight))
+    datt = ops.linear_dgrad(dx1, sh(blk.attn.proj.weight))
+    dq, dkv = ops.cls_attn_bwd(q, kv, probs, datt, N, S, H)
+    gb, gw, wqkv = gr(blk.attn.qkv.bias), gr(blk.attn.qkv.weight), sh(blk.attn.qkv.weight)
+    ops.colsum(dq, gb[:D])                       # colsum(dk) == 0 and colsum(dv) == colsum(datt): see avt_cls_attn_bwd
+    ops.colsum(datt, gb[2 * D:])
+    ops.linear_wgrad(dq, _cls_rows(ln1, N, S, D), gw[:D])
+    ops.linear_wgrad(dkv, ln1, gw[D:])
+    dln1 = ops.linear_dgrad(dkv, wqkv[D:])                                              # [N*S, D]
+    dln1_cls = _cls_rows(dln1, N, S, D)
+    ops.linear_dgrad(dq, wqkv[:D], res=dln1_cls, out=dln1_cls)                          # CLS rows += dq @ Wq, in place
+    dx = ops.layernorm_bwd(dln1, x, mean1, rstd1, blk.norm1.weight, gr(blk.norm1.weight), gr(blk.norm1.bias), colsum=prev_bias)
+    ops.add_rows(_cls_rows(dx, N, S, D), dx1)                                           # residual path of the CLS rows
+    if prev_bias is not None:
+        ops.colsum(dx1, prev_bias)
+    return dx
 
 
 def _vit_backward(m: HipViT, arena, saved, dfeat):
@@ -113,13 +181,27 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
     sh, gr = arena.sh, arena.gr
     hook = m.grad_ready_hook
     x, meanf, rstdf = saved['final']
-    dx = torch.zeros((M, D), device=dfeat.device, dtype=torch.bfloat16)     # only the CLS rows receive gradient
     last = m.blocks[-1]
-    ops.layernorm_bwd(dfeat, x, meanf, rstdf, m.norm.weight, gr(m.norm.weight), gr(m.norm.bias),
-                      colsum=gr(last.mlp.fc2.bias), rows=N, ldx=S * D, dx=dx, lddx=S * D)
-    if hook:
-        hook(m.norm.weight, m.norm.bias)
-    for i in range(m.depth - 1, -1, -1):
+    first_full = m.depth - 1
+    if saved['cls_last']:
+        dx2 = ops.layernorm_bwd(dfeat, x, meanf, rstdf, m.norm.weight, gr(m.norm.weight), gr(m.norm.bias),
+                                colsum=gr(last.mlp.fc2.bias))
+        if hook:
+            hook(m.norm.weight, m.norm.bias)
+        prev_bias = gr(m.blocks[-2].mlp.fc2.bias) if m.depth > 1 else None
+        dx = _last_block_backward(m, arena, last, saved['blocks'][-1], dx2, N, prev_bias)
+        saved['blocks'][-1] = None
+        del dx2
+        if hook:
+            hook(last.norm1.weight, last.mlp.fc2.bias)
+        first_full = m.depth - 2
+    else:
+        dx = torch.zeros((M, D), device=dfeat.device, dtype=torch.bfloat16)     # only the CLS rows receive gradient
+        ops.layernorm_bwd(dfeat, x, meanf, rstdf, m.norm.weight, gr(m.norm.weight), gr(m.norm.bias),
+                          colsum=gr(last.mlp.fc2.bias), rows=N, ldx=S * D, dx=dx, lddx=S * D)
+        if hook:
+            hook(m.norm.weight, m.norm.bias)
+    for i in range(first_full, -1, -1):
         blk = m.blocks[i]
         (x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act) = saved['blocks'][i]
         saved['blocks'][i] = None
@@ -161,6 +243,7 @@ class _ViTFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dfeat):
+        ctx.arena.attach_grads()          # .grad views dropped between forward and backward (optimizer.zero_grad())
         _vit_backward(ctx.module, ctx.arena, ctx.saved, dfeat.to(torch.bfloat16).contiguous())
         ctx.saved = None
         return None, None, None, None, None

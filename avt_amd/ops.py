@@ -162,6 +162,34 @@ def vit_attn_bwd(qkv, out, dout, lse, frames, S, H, dbias=None):
     return dqkv
 
 
+def cls_attn_fwd(q, kv, frames, S, H):
+    """CLS-query attention of the last ViT block: q [frames, H*64], kv [frames*S, 2*H*64] -> (out [frames, H*64], probs)."""
+    _chk(q, BF16, 'q'); _chk(kv, BF16, 'kv')
+    D = H * 64
+    out = torch.empty((frames, D), device=q.device, dtype=BF16)
+    probs = torch.empty((frames, H, S), device=q.device, dtype=torch.float32)
+    _lib.call('avt_cls_attn_fwd', _p(q), _ld(q), _p(kv), _ld(kv), _p(out), D, _p(probs), frames, S, H, 64, 0.125, _stream())
+    return out, probs
+
+
+def cls_attn_bwd(q, kv, probs, dout, frames, S, H):
+    D = H * 64
+    dq = torch.empty((frames, D), device=q.device, dtype=BF16)
+    dkv = torch.empty((frames * S, 2 * D), device=q.device, dtype=BF16)
+    _lib.call('avt_cls_attn_bwd', _p(q), _ld(q), _p(kv), _ld(kv), _p(probs), _p(dout), _ld(dout), _p(dq), D, _p(dkv), 2 * D,
+              frames, S, H, 64, 0.125, _stream())
+    return dq, dkv
+
+
+def causal_attn_decode(qkv, kcache, vcache, B, H, hd, pos):
+    """KV-cache step of the AVT-h roll-out: appends the token's k / v at row ``pos`` and attends over rows 0..pos."""
+    _chk(qkv, BF16, 'qkv'); _chk(kcache, BF16, 'kcache'); _chk(vcache, BF16, 'vcache')
+    assert qkv.is_contiguous() and kcache.is_contiguous() and vcache.is_contiguous()
+    out = torch.empty((B, H * hd), device=qkv.device, dtype=BF16)
+    _lib.call('avt_causal_attn_decode', _p(qkv), _p(kcache), _p(vcache), _p(out), B, H, hd, pos, kcache.size(1), float(hd) ** -0.5, _stream())
+    return out
+
+
 def causal_attn_fwd(qkv, B, T, H, hd, drop_p=0.0, seed=0):
     _chk(qkv, BF16, 'qkv')
     out = torch.empty((B * T, H * hd), device=qkv.device, dtype=BF16)
@@ -238,10 +266,36 @@ def colsum(x, out):
     _lib.call('avt_colsum_bf16', _p(x), _ld(x), _p(out), x.size(0), x.size(1), _stream())
 
 
-def mse_shift_fwd(dec, x, B, T, F):
+def mse_shift_fwd(dec, x):
+    """loss[b,t,:] = (dec[b,t,:] - x[b,t+1,:])^2 for t < T-1; dec, x fp32 contiguous [B,T,F]."""
+    _chk(dec, torch.float32, 'dec'); _chk(x, torch.float32, 'x')
+    B, T, F = dec.shape
     loss = torch.empty((B, T - 1, F), device=dec.device, dtype=torch.float32)
     _lib.call('avt_mse_shift_fwd', _p(dec), _p(x), _p(loss), B, T, F, _stream())
     return loss
+
+
+def mse_shift_bwd(dec, x, gloss):
+    B, T, F = dec.shape
+    ddec, dx = torch.empty_like(dec), torch.empty_like(x)
+    _lib.call('avt_mse_shift_bwd', _p(dec), _p(x), _p(gloss), _p(ddec), _p(dx), B, T, F, _stream())
+    return ddec, dx
+
+
+def pad_cast_to_bf16(src, ldd):
+    """fp32 [rows, cols] (unit inner stride) -> bf16 [rows, ldd], columns >= cols zero."""
+    _chk(src, torch.float32, 'src')
+    rows, cols = src.shape
+    dst = torch.empty((rows, ldd), device=src.device, dtype=BF16)
+    _lib.call('avt_pad_cast_f32_to_bf16', _p(src), _ld(src), _p(dst), ldd, rows, cols, _stream())
+    return dst
+
+
+def add_rows(dst, src):
+    """dst[r, :] += src[r, :]; both 2-D bf16 views with unit inner stride (dst typically the CLS rows of a [frames*S, D] tensor)."""
+    _chk(dst, BF16, 'dst'); _chk(src, BF16, 'src')
+    assert dst.shape == src.shape
+    _lib.call('avt_add_rows_bf16', _p(dst), _ld(dst), _p(src), _ld(src), dst.size(0), dst.size(1), _stream())
 
 
 # ---- cross entropy ---------------------------------------------------------------------------------------------------------

@@ -35,6 +35,7 @@ class FusedSGD:
         self.steps = 0
         self.grad_scale = 1.0            # set to 1/world_size by the gradient reducer (sum all-reduce)
         self._ranges = None
+        self._uncovered = []
 
     def _build_ranges(self):
         """[(start, end, group_index)] covering each group's parameters as maximal contiguous arena ranges."""
@@ -58,9 +59,16 @@ class FusedSGD:
 
     @torch.no_grad()
     def step(self):
+        a = self.arena
         if self._ranges is None:
             self._ranges = self._build_ranges()
-        a = self.arena
+            self._uncovered, pos = [], 0
+            for s0, e0, _ in self._ranges:
+                if s0 > pos:
+                    self._uncovered.append((pos, s0))
+                pos = max(pos, e0)
+            if pos < a.total:
+                self._uncovered.append((pos, a.total))
         # launch per maximal run of adjacent ranges whose hyper-parameters agree
         i = 0
         R = self._ranges
@@ -80,15 +88,65 @@ class FusedSGD:
                          g['weight_decay'], grad_scale=self.grad_scale, nesterov=bool(g['nesterov']),
                          first_step=(self.steps == 0), zero_grad=True)
             i = j
+        for s0, e0 in self._uncovered:           # frozen parameters: nobody consumes their gradients, keep the range clean
+            a.grad[s0:e0].zero_()
         self.steps += 1
         a.mark_shadow_current()
 
+    # ---- checkpoint format: torch.optim.SGD's (func/train.py:52-74 stores optimizer.state_dict(), :760-769 resumes it) ------
+    def _flat_params(self):
+        return [p for g in self.param_groups for p in g['params']]
+
     def state_dict(self):
-        return {'momentum_buf': self.momentum_buf, 'steps': self.steps,
-                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+        """Same layout as ``torch.optim.SGD.state_dict()``: ``state[idx]['momentum_buffer']`` per parameter (a copy of
+        its slice of the flat momentum buffer) and ``param_groups`` with parameter indices, so a checkpoint written
+        here resumes under the reference's torch optimizer and vice versa."""
+        a = self.arena
+        state, groups, idx = {}, [], 0
+        for g in self.param_groups:
+            ids = []
+            for p in g['params']:
+                if self.steps > 0:
+                    n = a.name_of[id(p)]
+                    o = a.offsets[n]
+                    state[idx] = {'momentum_buffer': self.momentum_buf[o:o + p.numel()].view(p.shape).clone()}
+                ids.append(idx)
+                idx += 1
+            d = {k: v for k, v in g.items() if k != 'params'}
+            d.setdefault('dampening', 0)
+            d.setdefault('maximize', False)
+            d.setdefault('foreach', None)
+            d.setdefault('differentiable', False)
+            d.setdefault('fused', None)
+            d['params'] = ids
+            groups.append(d)
+        return {'state': state, 'param_groups': groups}
 
     def load_state_dict(self, sd):
-        self.momentum_buf.copy_(sd['momentum_buf'])
-        self.steps = sd['steps']
-        for g, s in zip(self.param_groups, sd['param_groups']):
-            g.update(s)
+        a = self.arena
+        if 'momentum_buf' in sd:                                   # round-1 private format
+            self.momentum_buf.copy_(sd['momentum_buf'])
+            self.steps = sd['steps']
+            for g, s in zip(self.param_groups, sd['param_groups']):
+                g.update(s)
+            return
+        params = self._flat_params()
+        saved_groups = sd['param_groups']
+        if len(saved_groups) != len(self.param_groups) or any(len(sg['params']) != len(g['params'])
+                                                              for sg, g in zip(saved_groups, self.param_groups)):
+            raise ValueError('loaded state dict has a different number of parameter groups / parameters')
+        order = [i for sg in saved_groups for i in sg['params']]
+        loaded = 0
+        with torch.no_grad():
+            for p, i in zip(params, order):
+                st = sd['state'].get(i, sd['state'].get(str(i)))
+                if st is None or st.get('momentum_buffer') is None:
+                    continue
+                n = a.name_of[id(p)]
+                o = a.offsets[n]
+                self.momentum_buf[o:o + p.numel()].copy_(st['momentum_buffer'].reshape(-1).to(self.momentum_buf.device, torch.float32))
+                loaded += 1
+        self.steps = 1 if loaded else 0          # torch initialises the buffer with the first gradient; after that it is live
+        for g, sg in zip(self.param_groups, saved_groups):
+            g.update({k: v for k, v in sg.items() if k != 'params'})
+        self._ranges = None

@@ -1,15 +1,23 @@
 #!/usr/bin/env python
 """Headline benchmark: training clips/sec of ViT-B/16 + AVT-h (10 x 224^2 frames, C = 3806) on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU over RCCL.  Either the caller launches the ranks (``python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N``: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* are read from the environment) or
+``python bench.py --gpus N`` spawns them itself (re-exec under torch.distributed.run on 127.0.0.1, the counterpart of the
+reference's one-process-per-GPU launch, train_net.py:43 / common/utils.py:106-150); it exits non-zero with a message when
+the node has fewer than N devices.
 
 A step = forward + losses + backward (+ overlapped RCCL gradient all-reduce for N > 1) + fused SGD-nesterov update on a
 synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line:
   value      whole-job clips/sec (N x per-GPU batch / max-over-ranks step time)
-  roofline   the dominant kernel (the 128x128-tile bf16 MFMA GEMM templates): algorithmic 2*M*N*K flops of every launch
-             in the timed region / their summed HIP-event durations, against the 2.5 PFLOP/s dense bf16 MFMA peak
+  roofline   bound = mfma.  ``frac`` is the WHOLE-STEP fraction north_star names: clips/s/GPU x algorithmic GFLOP/clip
+              / 2.5 PFLOP/s dense bf16.  ``dominant_kernel`` is the bf16 MFMA GEMM family measured live: 2*M*N*K
+             of every launch in the timed region / their summed HIP-event durations.  ``traffic`` = HBM bytes per step from
+             the committed rocprofv3 PMC pass over the same workload (profiles/pmc_step.json; null when none matches)
   cpu_baseline  the fp32 CPU oracle (a port of the reference's timm/HF path, oracle/avt_oracle.py) timed on this box's
-             host cores on a bounded sample (B = 1 clip, 1 warm-up + 2 timed steps of fwd+bwd+SGD)
+             host cores on a bounded sample (B = 1 clip, 1 warm-up + 3 timed steps of fwd+bwd+SGD; min/max reported)
 """
 import argparse
 import json
@@ -83,7 +91,7 @@ def cpu_baseline(args):
     sub = torch.randint(-1, NUM_CLASSES, (B, args.frames, 1), generator=g)
     wts = {'cls_action': 1.0, 'past_cls_action': 1.0, 'feat': 1.0}
     times = []
-    for it in range(3):
+    for it in range(4):
         t0 = time.time()
         out, aux = orc(video, target_shape=target.shape)
         losses, _ = O.basic_loss_accuracy(out, {'action': target}, {'action': sub})
@@ -93,13 +101,49 @@ def cpu_baseline(args):
         tot.backward()
         opt.step()
         times.append(time.time() - t0)
-    t = sum(times[1:]) / len(times[1:])
+    timed = times[1:]
+    t = sum(timed) / len(timed)
     return {'value': round(B / t, 4), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
-            'sample': f'B={B} clip x {args.frames} frames, 1 warm-up + 2 timed fwd+bwd+SGD steps of the fp32 oracle '
-                      f'({t:.2f} s/step, {flops_per_clip(D, L, args.frames) * B / t / 1e9:.0f} GFLOP/s)'}
+            'min': round(B / max(timed), 4), 'max': round(B / min(timed), 4),
+            'sample': f'B={B} clip x {args.frames} frames, 1 warm-up + {len(timed)} timed fwd+bwd+SGD steps of the fp32 oracle '
+                      f'(mean {t:.2f} s/step, range {min(timed):.2f}-{max(timed):.2f} s, '
+                      f'{flops_per_clip(D, L, args.frames) * B / t / 1e9:.0f} GFLOP/s)'}
 
 
-def main():
+def self_launch(args, argv):
+    """``python bench.py --gpus N`` without a launcher: spawn one rank per GPU under torch.distributed.run (127.0.0.1
+    rendezvous on a free port) and pass rank 0's JSON line through.  Fails loudly when the node has fewer devices."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: this node exposes {ndev} GPU(s); refusing to oversubscribe '
+                         f'(RCCL needs one device per rank)')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def pmc_traffic(args):
+    """HBM bytes per step from the committed PMC pass over the same workload (profiles/pmc_step.json), else None."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_step.json')
+    try:
+        with open(path) as f:
+            recs = json.load(f)
+    except (OSError, ValueError):
+        return None
+    for r in recs:
+        if (r.get('model'), r.get('batch'), r.get('frames')) == (args.model, args.batch, args.frames):
+            return r
+    return None
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -107,17 +151,21 @@ def main():
     ap.add_argument('--batch', type=int, default=128, help='clips per GPU (weak scaling: fixed per GPU)')
     ap.add_argument('--frames', type=int, default=10)
     ap.add_argument('--model', default='vit_base_patch16_224', choices=list(VIT))
-    ap.add_argument('--bucket-mb', type=int, default=256)
+    ap.add_argument('--bucket-mb', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-trace', action='store_true')
-    args = ap.parse_args()
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = ap.parse_args(argv)
+
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        raise SystemExit(self_launch(args, argv))
+    if args.gpus != world_env:
+        raise SystemExit(f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks')
 
     import torch.distributed as dist
     from avt_amd import ops
     from avt_amd.common import utils
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
     dist_on, rank, world, local = utils.init_distributed_mode('nccl')
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
@@ -137,10 +185,12 @@ def main():
     for _ in range(args.steps):
         loss, _, _, _ = trainer.step(data)
     sync()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
     ops.GEMM_TRACE = None
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    t = torch.tensor([elapsed_local], device=device, dtype=torch.float64)
+    per_rank = [t.clone() for _ in range(world)]
     if dist_on:
+        dist.all_gather(per_rank, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t)
     loss_val = float(loss)
@@ -160,16 +210,24 @@ def main():
         fl = sum(v[0] for v in dom.values())
         tm = sum(v[1] for v in dom.values())
         n_launch = sum(v[2] for v in dom.values())
-        roof = None
+        step_tf = clips / world * fclip / 1e12
+        pmc = pmc_traffic(args)
+        roof = {'bound': 'mfma', 'scope': 'whole training step (fwd + bwd + SGD) per GPU: clips/s/GPU x algorithmic GFLOP/clip (SURVEY 8d)',
+                'achieved': round(step_tf, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(step_tf / MFMA_PEAK_TFLOPS, 4),
+                'traffic': None if pmc is None else pmc['hbm_bytes_per_step'],
+                'traffic_source': None if pmc is None else pmc.get('source'),
+                'algorithmic_bytes_per_step': None if pmc is None else pmc.get('algorithmic_bytes_per_step')}
         if tm > 0:
             ach = fl / tm / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'gemm_8p_kernel<*> (256x256x64, 8-phase) + gemm_kernel<256|128,*> (bf16 MFMA GEMM, all layouts/epilogues)',
-                    'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4),
-                    'traffic': None, 'launches': n_launch, 'avg_launch_us': round(tm / n_launch * 1e6, 2),
-                    'avg_launch_gflop': round(fl / n_launch / 1e9, 3),
-                    'share_of_step_time': round(tm / elapsed, 3),
-                    'per_variant_tflops': {k: round(v[0] / v[1] / 1e12, 1) for k, v in per_variant.items() if v[1] > 0}}
-        out = {'metric': f'training clips/sec (ViT-B/16+AVT-h, {args.frames}x224^2 frames)' if args.model.startswith('vit_base') else f'training clips/sec ({args.model}+AVT-h, {args.frames}x224^2 frames)',
+            roof['dominant_kernel'] = {
+                'kernel': 'gemm_8p_kernel<*> (256x256x64, 8-phase) + gemm_kernel<256|128,*> (bf16 MFMA GEMM, all layouts/epilogues)',
+                'achieved': round(ach, 1), 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4),
+                'launches': n_launch, 'avg_launch_us': round(tm / n_launch * 1e6, 2),
+                'avg_launch_gflop': round(fl / n_launch / 1e9, 3), 'share_of_step_time': round(tm / elapsed, 3),
+                'per_variant_tflops': {k: round(v[0] / v[1] / 1e12, 1) for k, v in per_variant.items() if v[1] > 0}}
+        name = 'ViT-B/16' if args.model.startswith('vit_base') else args.model
+        out = {'metric': f'training clips/sec ({name}+AVT-h, {args.frames}x224^2 frames)',
                'value': round(clips, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
@@ -177,7 +235,7 @@ def main():
                                       f'{args.batch} clips/GPU, dropout 0.1/0.2 on, fp32 master weights / bf16 MFMA',
                           'clips_per_gpu': args.batch, 'global_batch': args.batch * world, 'frames': args.frames,
                           'parallelism': f'dp{world}', 'gflop_per_clip': round(fclip / 1e9, 2), 'final_loss': round(loss_val, 4)},
-               'step_mfma_frac': round(clips / world * fclip / (MFMA_PEAK_TFLOPS * 1e12), 4),
+               'per_rank_clips_per_s': [round(args.batch * args.steps / float(x), 2) for x in per_rank],
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)

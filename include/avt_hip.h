@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 1
+#define AVT_ABI_VERSION 2
 
 const char* avt_last_error(void);
 int avt_abi_version(void);
@@ -74,6 +74,23 @@ int avt_vit_attn_fwd(const void* qkv, void* out, float* lse, int frames, int S, 
 int avt_vit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
                      int frames, int S, int H, int head_dim, float scale, void* stream);
 
+/* ---- single-query attention ---------------------------------------------------------------------------------------
+ * avt_cls_attn_*: the LAST ViT block's attention for the CLS query only.  [timm] VisionTransformer.forward_features returns
+ * x[:, 0] after the final norm (reached through models/video_classification.py:224 -> models/base_model.py:157), so of the last
+ * block only token 0's attention / proj / MLP output is ever consumed, in forward and in backward.
+ *   q [frames, H*64] (row stride ldq), kv [frames*S, 2*H*64] columns [k | v] head-major, out [frames, H*64], probs fp32
+ *   [frames, H, S] (saved for backward).  bwd writes dq [frames, H*64] and ALL rows of dkv; bias gradients are left to the
+ *   caller (colsum(dk) == 0, colsum(dv) == colsum(dout), colsum(dq) over the compact tensor).  S <= 256, head_dim == 64.
+ * avt_causal_attn_decode: [hf] GPT2Attention with `past_key_values` (models/future_prediction.py:168-202, roll-out for
+ *   output_len > 1): the new token's qkv [B, 3*H*hd]; its k / v are appended to kcache / vcache [B, tmax, H*hd] at row
+ *   `pos`, then out [B, H*hd] = softmax(q k[0..pos]^T * scale) v[0..pos].  No dropout (eval path). */
+int avt_cls_attn_fwd(const void* q, int ldq, const void* kv, int ldkv, void* out, int ldo, float* probs,
+                     int frames, int S, int H, int head_dim, float scale, void* stream);
+int avt_cls_attn_bwd(const void* q, int ldq, const void* kv, int ldkv, const float* probs, const void* dout, int lddo,
+                     void* dq, int lddq, void* dkv, int lddkv, int frames, int S, int H, int head_dim, float scale, void* stream);
+int avt_causal_attn_decode(const void* qkv, void* kcache, void* vcache, void* out, int B, int H, int head_dim, int pos,
+                           int tmax, float scale, void* stream);
+
 /* ---- AVT-h causal attention core ---------------------------------------------------------------------------------
  * [hf] GPT2Attention._attn via models/future_prediction.py:178-181: softmax(causal(q k^T * scale)), attention dropout,
  * times v.  qkv [B*T, 3*H*hd]; probs fp32 [B,H,T,T] = pre-dropout probabilities saved for backward.  T <= 32. */
@@ -94,14 +111,21 @@ int avt_patch_embed_bwd_reduce(const void* dx, float* dpos, float* dcls, float* 
  * casts (bf16 shadow of fp32 parameters), dropout (nn.Dropout, models/base_model.py:81,204,215; also its own backward),
  * GPT-2 position embedding + embd dropout ([hf] GPT2Model.forward: inputs_embeds + wpe(position_ids), drop) and its
  * backward (denc = dh*mask, dwpe[t] += sum_b), column sums (bias gradients), shifted MSE
- * (models/future_prediction.py:207-215: (decoded[:, :T-1] - feats[:, 1:T])^2, fp32 [B,T-1,F]). */
+ * (models/future_prediction.py:207-215 with future_pred_loss = torch.nn.MSELoss(reduction='none'):
+ * loss = (decoded[:, :T-1] - feats[:, 1:T])^2, fp32 [B,T-1,F]; bwd writes ddec and dfeats, both fp32 [B,T,F], rows without a
+ * term zero), fp32 -> bf16 cast with zero column padding (classifier gradient, models/base_model.py:222-238), strided row add
+ * (residual gradient of the CLS rows, see avt_cls_attn_*). */
 int avt_cast_f32_to_bf16(const float* src, void* dst, long n, void* stream);
 int avt_cast_bf16_to_f32(const void* src, float* dst, long n, void* stream);
 int avt_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, void* stream);
 int avt_embed_pos_fwd(const void* enc, const float* wpe, void* h, int B, int T, int E, float p, uint64_t seed, void* stream);
 int avt_embed_pos_bwd(const void* dh, void* denc, float* dwpe, int B, int T, int E, float p, uint64_t seed, void* stream);
 int avt_colsum_bf16(const void* x, int ld, float* out, int M, int N, void* stream);
-int avt_mse_shift_fwd(const void* dec, const void* x, float* loss, int B, int T, int F, void* stream);
+int avt_mse_shift_fwd(const float* dec, const float* x, float* loss, int B, int T, int F, void* stream);
+int avt_mse_shift_bwd(const float* dec, const float* x, const float* gloss, float* ddec, float* dx, int B, int T, int F,
+                      void* stream);
+int avt_pad_cast_f32_to_bf16(const float* src, int lds, void* dst, int ldd, int rows, int cols, void* stream);
+int avt_add_rows_bf16(void* dst, long ldd, const void* src, long lds, int rows, int D, void* stream);
 
 /* ---- softmax cross-entropy -------------------------------------------------------------------------------------------
  * loss_fn/multidim_xentropy.py:11-25 (CrossEntropyLoss(ignore_index=-1, reduction='none')) + common/utils.py:17-44.

@@ -1,4 +1,5 @@
 #!/bin/bash
+export AVT_HIP_LIB=${AVT_HIP_LIB:-$(pwd)/avt_amd/libavt_hip_lab.so}   # lab build (make -C avt_amd/csrc lab): the product library has no ablation / stagger switches
 for a in 0 1 2 3 4; do echo "ABLATE=$a"; AVT_GEMM_ABLATE=$a python - <<'PY'
 import sys, os
 sys.path.insert(0, os.getcwd())

@@ -1,6 +1,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+os.environ.setdefault('AVT_HIP_LIB', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'avt_amd', 'libavt_hip_lab.so'))   # lab build: make -C avt_amd/csrc lab
 frames, S, H = 320, 197, 12
 dbg = torch.zeros(frames * H * 16 * 4, device='cuda', dtype=torch.int64)
 os.environ['AVT_ATTN_DBG_PTR'] = hex(dbg.data_ptr())
