@@ -42,10 +42,11 @@ def get_rank():
     return dist.get_rank() if is_dist_avail_and_initialized() else 0
 
 
-def init_distributed_mode(backend=None):
+def init_distributed_mode(backend=None, allow_single=False):
     """One process per GPU, rank/world from torchrun's env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
-    ``backend='nccl'`` is RCCL on ROCm (xGMI inside a node); ``gloo`` is used by the CPU tests."""
-    if 'RANK' not in os.environ or int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+    ``backend='nccl'`` is RCCL on ROCm (xGMI inside a node); ``gloo`` is used by the CPU tests.  A single process stays
+    un-initialised unless ``allow_single`` (used to exercise RCCL on a one-GPU box)."""
+    if 'RANK' not in os.environ or (int(os.environ.get('WORLD_SIZE', '1')) <= 1 and not allow_single):
         return False, 0, 1, 0
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     local = int(os.environ.get('LOCAL_RANK', rank))

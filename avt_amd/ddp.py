@@ -8,7 +8,8 @@ the reducer cuts the finished region into buckets and launches ``all_reduce(SUM)
 soon as the kernels producing it have been enqueued (event-ordered), so the 1.2 GB of AVT-h gradients -- produced
 first -- travel while the long ViT backward still runs.  ``finish()`` makes the compute stream wait for the tail.
 The 1/world averaging is folded into the fused optimizer (``grad_scale``), not into a separate pass.
-Ring all-reduce on xGMI is per-link bound, so buckets are large (default 256 MiB) to keep the link pipelines full.
+Ring all-reduce on xGMI is per-link bound, so buckets are large (default 64 MiB: big enough to keep the link pipelines full,
+small enough that only the last bucket -- the ViT's first block and the patch embedding -- is exposed after backward).
 """
 import torch
 import torch.distributed as dist
@@ -17,7 +18,7 @@ from .arena import ParamArena
 
 
 class GradReducer:
-    def __init__(self, model, bucket_bytes=256 << 20, process_group=None, overlap=True):
+    def __init__(self, model, bucket_bytes=64 << 20, process_group=None, overlap=True, always=False):
         self.model = model
         self.arena: ParamArena = model.arena
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -28,6 +29,8 @@ class GradReducer:
         self._lo = self.arena.total         # everything in [_lo, total) has been produced
         self._sent = self.arena.total       # everything in [_sent, total) has been handed to the collective
         self._handles = []
+        self.always = always                # run the collectives even for a world of one (exercises RCCL on a one-GPU box)
+        self.launched = 0                   # collectives launched in the current step
         self._hooked = [m for m in model.modules() if hasattr(m, 'grad_ready_hook')]
         self._seen = {}
         for m in self._hooked:
@@ -44,6 +47,7 @@ class GradReducer:
         self._lo = self._sent = self.arena.total
         self._handles = []
         self._seen = {}
+        self.launched = 0
         for m in self._hooked:
             m._fwd_calls = 0
 
@@ -58,7 +62,7 @@ class GradReducer:
             return
         start = a.offsets[a.name_of[id(first_param)]]
         self._lo = min(self._lo, start)
-        if self.world > 1 and self.overlap:
+        if (self.world > 1 or self.always) and self.overlap:
             while self._sent - self._lo >= self.bucket_elems:
                 self._launch(self._sent - self.bucket_elems, self._sent)
 
@@ -73,11 +77,12 @@ class GradReducer:
         else:
             h = dist.all_reduce(a.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._handles.append(h)
+        self.launched += 1
         self._sent = s
 
     def finish(self):
         """Reduce whatever is left (everything, if no hook fired) and order the compute stream after the collectives."""
-        if self.world <= 1:
+        if self.world <= 1 and not self.always:
             return
         if self._sent > 0:
             self._launch(0, self._sent)

@@ -16,13 +16,93 @@ from ..ddp import GradReducer
 from ..models.base_model import BaseModel
 from ..optim import FusedSGD
 
-__all__ = ['build_model', 'build_optimizer', 'build_schedulers', 'Trainer', 'synthetic_batch', 'main']
+__all__ = ['build_model', 'build_optimizer', 'build_schedulers', 'Trainer', 'synthetic_batch', 'main', 'init_model',
+           'init_from_model', 'store_checkpoint', 'load_checkpoint', 'CKPT_FNAME']
+CKPT_FNAME = 'checkpoint.pth'
 
 
 def build_model(cfg, num_classes: Dict[str, int], class_mappings=None, device='cuda'):
-    """func/train.py:660-664,690"""
+    """func/train.py:660-690: construct, initialise sub-modules from checkpoints (``train.init_from_model``), move to device."""
     model = BaseModel(cfg.model, num_classes=num_classes, class_mappings=class_mappings or {})
+    init_from_model(model, cfg.get('train', Cfg()).get('init_from_model', None))
     return model.to(device)
+
+
+def init_model(model, ckpt_path, modules_to_keep=None, logger=None):
+    """func/train.py:457-497: non-strict initialisation of ``model`` from a checkpoint file.  Accepts the containers the
+    reference accepts (``{'model': ...}``, ``{'state_dict': ...}``, VISSL's ``classy_state_dict``, or a bare state_dict --
+    e.g. timm's ``jx_vit_base_patch16_224_in21k`` weights for ``backbone.model``), keeps only keys that start with one of the
+    comma-separated prefixes in ``modules_to_keep`` (prefix stripped), drops shape-mismatched entries (e.g. a classifier of
+    another dataset), ignores unexpected ones (HF 4.2.2's ``attn.bias`` / ``attn.masked_bias`` mask buffers).
+    Returns (missing_keys, unexpected_keys)."""
+    logger = logger or logging.getLogger(__name__)
+    checkpoint = torch.load(ckpt_path, map_location='cpu', weights_only=False)
+    if 'model' in checkpoint:
+        state_dict = checkpoint['model']
+    elif 'state_dict' in checkpoint:
+        state_dict = checkpoint['state_dict']
+    elif 'classy_state_dict' in checkpoint:
+        state_dict = checkpoint['classy_state_dict']['base_model']['model']['trunk']
+    else:
+        state_dict = checkpoint
+    if modules_to_keep:
+        prefixes = modules_to_keep.split(',')
+        state_dict = {k[len(pre):]: v for k, v in state_dict.items() for pre in prefixes if k.startswith(pre)}
+    else:
+        state_dict = dict(state_dict)
+    own = dict(model.named_parameters())
+    own.update(dict(model.named_buffers()))
+    for name, t in own.items():
+        if name in state_dict and state_dict[name].shape != t.shape:
+            logger.warning('Ckpt shape mismatch for %s (%s vs %s). Ignoring.', name, tuple(state_dict[name].shape), tuple(t.shape))
+            del state_dict[name]
+    missing, unexpected = model.load_state_dict(state_dict, strict=False)
+    logger.warning('Could not init from %s: %s', ckpt_path, missing)
+    logger.warning('Unused keys in %s: %s', ckpt_path, unexpected)
+    return missing, unexpected
+
+
+def init_from_model(model, spec, logger=None):
+    """func/train.py:669-688: ``train.init_from_model`` = list of [path] | [module, path] | [module, prefixes, path]."""
+    for elts in (spec or []):
+        elts = list(elts)
+        if len(elts) == 1:
+            target, keep, path = model, None, elts[0]
+        elif len(elts) == 2:
+            target, keep, path = _get_submodule(model, elts[0]), None, elts[1]
+        elif len(elts) == 3:
+            target, keep, path = _get_submodule(model, elts[0]), elts[1], elts[2]
+        else:
+            raise ValueError(f'Incorrect formatting {elts}')
+        init_model(target, path, keep, logger)
+
+
+def store_checkpoint(fpaths, model, optimizer, lr_scheduler, epoch):
+    """func/train.py:52-74: ``{'model', 'optimizer', 'lr_scheduler', 'epoch'}`` written by rank 0.  The model's state_dict has
+    the reference's names, FusedSGD's has torch.optim.SGD's layout and the schedulers' the reference's
+    ``{'base_sched_dict', 'other_stuff'}`` one, so the file resumes under the reference's loop (:760-769) and vice versa."""
+    checkpoint = {'model': {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                  'optimizer': optimizer.state_dict(),
+                  'lr_scheduler': lr_scheduler.state_dict() if lr_scheduler is not None else {},
+                  'epoch': epoch}
+    if not isinstance(fpaths, (list, tuple)):
+        fpaths = [fpaths]
+    for fpath in fpaths:
+        logging.info('Storing ckpt at epoch %f to %s', epoch, fpath)
+        if utils.get_rank() == 0:
+            torch.save(checkpoint, fpath)
+
+
+def load_checkpoint(fpath, model, optimizer=None, lr_scheduler=None):
+    """func/train.py:760-769: strict model load, optimizer / scheduler state, returns the stored epoch."""
+    checkpoint = torch.load(fpath, map_location='cpu', weights_only=False)
+    sd = {k: v for k, v in checkpoint['model'].items() if not k.endswith(('.attn.bias', '.attn.masked_bias'))}   # HF 4.2.2 mask buffers
+    model.load_state_dict(sd)
+    if optimizer is not None and checkpoint.get('optimizer'):
+        optimizer.load_state_dict(checkpoint['optimizer'])
+    if lr_scheduler is not None and checkpoint.get('lr_scheduler'):
+        lr_scheduler.load_state_dict(checkpoint['lr_scheduler'])
+    return checkpoint.get('epoch', 0)
 
 
 def _param_groups(model, lr_wd, world_size, bias_bn_wd_scale=1.0, lr_mult=1.0):
@@ -93,7 +173,7 @@ class Trainer:
     all-reduce), step -> lr_scheduler.step().  The NaN check / ``loss.item()`` host syncs of the reference are made
     optional (``sync_loss``) because they stall the launch queue."""
     def __init__(self, model, train_eval_op, optimizer, lr_scheduler=None, loss_wts=None, distributed=False,
-                 bucket_bytes=64 << 20, grad_clip=None):
+                 bucket_bytes=64 << 20, grad_clip=None, force_reducer=False):
         self.model, self.op, self.optimizer, self.lr_scheduler = model, train_eval_op, optimizer, lr_scheduler
         self.loss_wts = dict(loss_wts or {})
         self.fused = isinstance(optimizer, FusedSGD)
@@ -101,7 +181,7 @@ class Trainer:
         self.max_norm = gc.get('max_norm', None)                 # conf/config.yaml train_one_epoch_fn.grad_clip_params
         self.norm_type = float(gc.get('norm_type', 2.0))
         self.world = utils.get_world_size() if distributed else 1
-        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes) if self.world > 1 else None
+        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, always=force_reducer) if (self.world > 1 or force_reducer) else None
         if self.reducer is not None:
             GradReducer.broadcast_parameters(model)
         self.last_losses = {}
@@ -153,8 +233,9 @@ class Trainer:
         return loss, outputs, losses, accuracies
 
 
-def main(cfg, steps=10, batch_size=None, log_every=1):
-    """Synthetic-data training loop driven by a composed config (see avt_amd/train_net.py)."""
+def main(cfg, steps=10, batch_size=None, log_every=1, ckpt=None):
+    """Synthetic-data training loop driven by a composed config (see train_net.py).  ``ckpt``: resume from this file when it
+    exists and store to it at the end (the reference does both with ``checkpoint.pth`` in the run directory)."""
     dist_on, rank, world, local = utils.init_distributed_mode(cfg.get('dist_backend', None))
     device = torch.device('cuda', local)
     torch.manual_seed(cfg.get('seed', 42) + rank)
@@ -170,6 +251,11 @@ def main(cfg, steps=10, batch_size=None, log_every=1):
                       grad_clip=cfg.train.train_one_epoch_fn.get('grad_clip_params', None))
     feat_shape = tuple(cfg.get('synthetic', Cfg()).get('feat_shape', (3, 1, 224, 224)))
     data = synthetic_batch(B, T, C, device, seed=cfg.get('seed', 42) + rank, feat_shape=feat_shape)
+    start = 0
+    import os
+    if ckpt and os.path.isfile(ckpt):
+        start = load_checkpoint(ckpt, model, optimizer, lr_sched)
+        logging.warning('Loaded model from %s (ep %f)', ckpt, start)
     for it in range(steps):
         t0 = time.time()
         loss, _, _, accs = trainer.step(data, sync_loss=True)
@@ -177,4 +263,6 @@ def main(cfg, steps=10, batch_size=None, log_every=1):
         if rank == 0 and it % log_every == 0:
             logging.info('iter %d loss %.4f clips/s %.1f lr %.3g', it, loss, B * world / dt, optimizer.param_groups[0]['lr'])
             print(f'iter {it} loss {loss:.4f} clips/s {B * world / dt:.1f} lr {optimizer.param_groups[0]["lr"]:.3g}', flush=True)
+    if ckpt:
+        store_checkpoint(ckpt, model, optimizer, lr_sched, start + steps / float(iters_per_epoch))
     return trainer

@@ -44,6 +44,22 @@ def flops_per_clip(D, L, T, Dh=2048, Lh=6, C=NUM_CLASSES, S=197):
     return 3 * (T * f_v + f_h) - T * patch
 
 
+def algorithmic_bytes_per_step(D, L, T, B, Dh=2048, Lh=6, S=197):
+    """HBM bytes per step per GPU of the implemented dataflow if every tensor crossed HBM exactly as often as the kernel
+    sequence consumes / produces it (DESIGN.md section 4 lists the per-kernel terms).  Unit u = one [tokens, D] bf16 tensor.
+    A full ViT block moves 30 u forward (LN1 2, qkv 4, attention 4, proj 3, LN2 2, fc1 9, fc2 6) and 52 u backward (fc2
+    w/dgrad 14, fc1 w/dgrad 10, LN2 4, proj w/dgrad 4, attention 8, qkv w/dgrad 8, LN1 4); the CLS-only last block 20 u;
+    patch embedding: fp32 frames once + 6 u; parameters: 38 B each (bf16 shadow read by forward and dgrad, fp32 gradient
+    read-modify-write, 26 B in the fused SGD); the temporal head's activations with u_h = [B*T, Dh] bf16."""
+    u = B * T * S * D * 2
+    vit = ((L - 1) * 82 + 20 + 6) * u + B * T * 3 * 224 * 224 * 4
+    n_vit = 768 * D + D + S * D + D + L * (12 * D * D + 13 * D) + 2 * D
+    n_head = 2 * D * Dh + 1024 * Dh + Lh * (12 * Dh * Dh + 13 * Dh) + 2 * Dh
+    n_cls = (D + 1) * NUM_CLASSES
+    head = Lh * 82 * (B * T * Dh * 2)
+    return vit + head + 38 * (n_vit + n_head + n_cls)
+
+
 def build(args, device, world):
     from avt_amd.config import Cfg
     from avt_amd.func.train import Trainer, synthetic_batch
@@ -217,7 +233,8 @@ def main(argv=None):
                 'frac': round(step_tf / MFMA_PEAK_TFLOPS, 4),
                 'traffic': None if pmc is None else pmc['hbm_bytes_per_step'],
                 'traffic_source': None if pmc is None else pmc.get('source'),
-                'algorithmic_bytes_per_step': None if pmc is None else pmc.get('algorithmic_bytes_per_step')}
+                'algorithmic_bytes_per_step': algorithmic_bytes_per_step(D, L, args.frames, args.batch),
+                'hbm_time_floor_ms_at_6p3TBs': round(algorithmic_bytes_per_step(D, L, args.frames, args.batch) / 6.3e12 * 1e3, 2)}
         if tm > 0:
             ach = fl / tm / 1e12
             roof['dominant_kernel'] = {

@@ -213,14 +213,14 @@ class OracleGPT2(nn.Module):
 
 
 # --------------------------------------------------------------------------------------------------
-# AVT-h (models/future_prediction.py:51-258, non-quantised path, output_len == 1)
+# AVT-h (models/future_prediction.py:51-258, non-quantised path; output_len > 1 = the roll-out of :168-202)
 # --------------------------------------------------------------------------------------------------
 class OracleAVTh(nn.Module):
     def __init__(self, in_features, output_len=1, avg_last_n=1, inter_dim=2048, future_pred_loss=True,
-                 return_past_too=True, n_head=4, n_layer=6, **gpt_kwargs):
+                 return_past_too=True, n_head=4, n_layer=6, output_len_eval=-1, **gpt_kwargs):
         super().__init__()
         gpt_kwargs.pop('future_pred_loss_wt', None)   # rides along in the HF config upstream (:21 of expt 01)
-        assert output_len == 1, 'roll-out (output_len > 1, KV cache) is outside the hot path (SURVEY 8f)'
+        self.output_len_eval = output_len_eval
         self.encoder = nn.Linear(in_features, inter_dim, bias=False)      # :80
         self.decoder = nn.Linear(inter_dim, in_features, bias=False)      # :81
         self.gpt_model = OracleGPT2(inter_dim, n_layer=n_layer, n_head=n_head, **gpt_kwargs)  # :89-93
@@ -233,17 +233,34 @@ class OracleAVTh(nn.Module):
         return self.in_features
 
     def forward(self, feats, target_shape=None):
-        del target_shape
         t = feats.size(1)
+        if target_shape is not None and len(target_shape) == 3:                   # :123-130
+            output_len = target_shape[1]
+        elif self.training or self.output_len_eval < 0:
+            output_len = self.output_len
+        else:
+            output_len = self.output_len_eval
+        inputs = self.encoder(feats)                                              # :163
         pos = torch.arange(0, t, dtype=torch.long, device=feats.device)          # :170-173
-        decoded = self.decoder(self.gpt_model(self.encoder(feats), pos))          # :163,178-190
+        hidden = self.gpt_model(inputs, pos)                                      # :178-181
+        for _ in range(1, output_len):
+            # :168-202: the newest token's last hidden state is the next input embedding, at the next position.  The
+            # reference keeps HF's past_key_values; re-running the whole (causal, dropout-free) sequence is the same maths.
+            assert not self.training, 'the oracle restates the roll-out for eval mode only'
+            inputs = torch.cat([inputs, hidden[:, -1:]], dim=1)
+            pos = torch.arange(0, inputs.size(1), dtype=torch.long, device=feats.device)
+            hidden = torch.cat([hidden, self.gpt_model(inputs, pos)[:, -1:]], dim=1)
+        decoded = self.decoder(hidden)                                            # :190
         losses = {}
         if self.use_feat_loss:                                                    # :207-215
-            losses['feat'] = (decoded[:, :t - 1] - feats[:, 1:t]) ** 2
+            n = min(t, decoded.size(1))
+            losses['feat'] = (decoded[:, :n - 1] - feats[:, 1:n]) ** 2
         if self.return_past_too:                                                  # :232-235
             final = torch.cat((feats, decoded[:, t - 1:]), dim=1)
+        elif output_len > 0:
+            final = decoded[:, -output_len:]
         else:
-            final = decoded[:, -self.output_len:]
+            final = decoded
         if self.avg_last_n > 0:                                                   # :241-242
             final = final[:, -self.avg_last_n:].mean(dim=1)
         past = torch.cat([feats[:, :1], decoded[:, :t - 1]], dim=1)               # :249-250

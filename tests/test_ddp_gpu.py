@@ -75,3 +75,56 @@ def test_two_rank_training_matches_single_process(tmp_path):
         e = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-12))
         worst = max(worst, e)
         assert e < 2e-2, (k, e)          # bf16 activations; batch split changes rounding, not the maths
+
+
+NCCL_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+root = sys.argv[1]; sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'tests'))
+from helpers import build_hip_model, LOSS_WTS
+from avt_amd.config import Cfg
+from avt_amd.common import utils
+from avt_amd.ddp import GradReducer
+from avt_amd.func.train import Trainer
+from avt_amd.func.train_eval_ops import Basic
+from avt_amd.optim import FusedSGD
+on, rank, world, local = utils.init_distributed_mode('nccl', allow_single=True)
+assert on and dist.get_backend() == 'nccl' and world == 1
+torch.manual_seed(0)
+model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
+opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, arena=model.arena)
+op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
+tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=True, bucket_bytes=64 << 10, force_reducer=True)
+assert tr.reducer is not None
+g = torch.Generator().manual_seed(9)
+data = {'video': (torch.rand((2, 4, 3, 1, 32, 32), generator=g) * 2 - 1).cuda(), 'target': {'action': torch.randint(0, 17, (2,), generator=g).cuda()},
+        'target_subclips': {'action': torch.randint(-1, 17, (2, 4, 1), generator=g).cuda()}}
+before = model.classifiers.action.weight.detach().clone()
+for _ in range(2):
+    loss, _, _, _ = tr.step(data)
+torch.cuda.synchronize()
+assert tr.reducer.launched > 2, tr.reducer.launched          # bucketed RCCL all-reduces really ran, on the side stream
+assert not torch.equal(before, model.classifiers.action.weight) and float(loss) == float(loss)
+dist.barrier(); dist.destroy_process_group()
+print('OK nccl', tr.reducer.launched)
+'''
+
+
+def test_rccl_executes_the_bucketed_allreduce_on_one_gpu(tmp_path):
+    """backend='nccl' (= RCCL) with world_size 1: init_process_group, rank-0 broadcast, the bucketed all_reduce launched from
+    the backward segment hooks on the side stream, finish() -- the same code path the 8-GPU run takes, on the box we have."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    script = tmp_path / 'nccl_worker.py'
+    script.write_text(NCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29561', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and 'OK nccl' in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` spawns its own ranks; with fewer devices than N it must fail loudly, not fall back."""
+    n = torch.cuda.device_count() + 1 if torch.cuda.is_available() else 2
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(max(n, 2)), '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and 'refusing to oversubscribe' in (p.stdout + p.stderr)

@@ -198,3 +198,342 @@ def test_full_size_step_vs_oracle():
               'backbone.model.pos_embed']:
         e = rel(dict(model.named_parameters())[n].grad, op[n].grad)
         assert e < 6e-2, (n, e)
+
+
+# ---- round 2: every BASELINE config at its own architecture ---------------------------------------------------------------
+def _grad_report(model, orc, names=None, min_abs=1e-7):
+    """Per-parameter gradient errors in three metrics: max-abs normalised, relative L2, cosine."""
+    from helpers import cosine, rel_l2
+    op = dict(orc.named_parameters())
+    rows = []
+    for n, p in model.named_parameters():
+        if names is not None and n not in names:
+            continue
+        ref = op[n].grad
+        if ref is None or float(ref.abs().max()) < min_abs:
+            continue
+        rows.append((n, rel(p.grad, ref), rel_l2(p.grad, ref), cosine(p.grad, ref)))
+    return rows
+
+
+def test_g2b_full_head_T15_vs_reference_golden(golden_dir):
+    """BASELINE config 4's head (expts/07_ek100_avt_longer: 15 frames): in=768, Dh=2048, 6 layers, 4 heads (hd 512), T=15."""
+    g = load_golden(os.path.join(golden_dir, 'g2b_full_head_T15.npz'))
+    from oracle.make_golden import synth_batch
+    model = build_hip_model('feat', 768, 2048, 6, 4, 3806)
+    _fill(model)
+    video, target, sub = synth_batch(2, 15, 3806, (768, 1, 1, 1), seed=12)
+    out, losses, accs, tot = hip_step(model, video.cuda(), target.cuda(), sub.cuda())
+    assert rel(out['logits/action'], g['out/logits/action']) < TOL_OUT
+    assert rel(out['past_logits/action'][:, :, ::16], g['out/past_logits/action_sub']) < TOL_OUT
+    assert rel(out['future'], g['out/future']) < TOL_OUT and rel(out['past'], g['out/past']) < TOL_OUT
+    assert abs(float(tot) - float(g['total_loss'])) / abs(float(g['total_loss'])) < 3e-2
+    params = dict(model.named_parameters())
+    for name, p in params.items():
+        gn, ref = float(p.grad.float().norm()), float(g[f'gradnorm/{name}'])
+        assert abs(gn - ref) / (ref + 1e-12) < 6e-2, (name, gn, ref)
+    wpe = params['future_predictor.gpt_model.wpe.weight'].grad
+    assert rel(wpe[:16, ::8], g['grad/future_predictor.gpt_model.wpe.weight_rows0_16']) < TOL_GRAD
+    assert float(wpe[15:].abs().max()) == 0.0
+    assert rel(params['future_predictor.encoder.weight'].grad[::64, ::32], g['grad/future_predictor.encoder.weight_sub']) < TOL_GRAD
+
+
+def _full_arch_vs_oracle(vitc, T, B, seed, std=0.03):
+    torch.manual_seed(seed)
+    D = vitc[0]
+    orc = build_oracle_model('vit', D, 2048, 6, 4, 3806, vit=vitc)
+    for n, p in orc.backbone.named_parameters():
+        with torch.no_grad():
+            if p.ndim >= 2:
+                p.normal_(0, std)
+    model = build_hip_model('vit', D, 2048, 6, 4, 3806, vit=vitc)
+    model.load_state_dict(orc.state_dict())
+    g = torch.Generator().manual_seed(seed + 10)
+    C = 3806
+    video = torch.rand((B, T, 3, 1, 224, 224), generator=g) * 2 - 1
+    target = torch.randint(0, C, (B,), generator=g)
+    sub = torch.randint(-1, C, (B, T, 1), generator=g)
+    o_out, o_losses, _, o_tot = oracle_step(orc, video, target, sub)
+    out, losses, _, tot = hip_step(model, video.cuda(), target.cuda(), sub.cuda())
+    assert rel(out['logits/action'], o_out['logits/action']) < 3e-2
+    assert rel(out['past_logits/action'], o_out['past_logits/action']) < 3e-2
+    assert rel(out['backbone_mean'], o_out['backbone_mean']) < 3e-2
+    for k in ['cls_action', 'past_cls_action', 'feat']:
+        assert rel(losses[k], o_losses[k]) < 3e-2, k
+    assert abs(float(tot) - float(o_tot)) / abs(float(o_tot)) < 3e-2
+    return model, orc
+
+
+def test_config2_full_arch_T10_every_gradient_vs_oracle():
+    """BASELINE config 2 at its full architecture and T = 10 (ViT-B/16 + AVT-h 2048x6x4, C = 3806), B = 1: outputs, the three
+    losses, and EVERY parameter gradient in three metrics.  Stated tolerance (bf16 activations / weights in the GEMMs, fp32
+    accumulate, vs the fp32 oracle): max-abs <= 4e-2 of the gradient's max-abs, relative L2 <= 3e-2, cosine >= 0.999 (measured worst:
+    2.7e-2 / 1.9e-2 / 0.99984)."""
+    model, orc = _full_arch_vs_oracle((768, 12, 12, 224), T=10, B=1, seed=21)
+    rows = _grad_report(model, orc)
+    assert len(rows) > 200
+    worst = (max(rows, key=lambda r: r[1]), max(rows, key=lambda r: r[2]), min(rows, key=lambda r: r[3]))
+    print('worst max-abs %s\nworst rel-L2 %s\nworst cosine %s' % worst)
+    bad = [r for r in rows if r[1] > 4e-2 or r[2] > 3e-2 or r[3] < 0.999]
+    assert not bad, bad[:10]
+
+
+def test_config4_full_arch_T15_vs_oracle():
+    """BASELINE config 4 (expts/07: 15 frames per clip) at full architecture, B = 1."""
+    model, orc = _full_arch_vs_oracle((768, 12, 12, 224), T=15, B=1, seed=22)
+    names = {'classifiers.action.weight', 'future_predictor.decoder.weight', 'future_predictor.gpt_model.wpe.weight',
+             'future_predictor.gpt_model.h.3.attn.c_attn.weight', 'backbone.model.blocks.11.attn.qkv.weight',
+             'backbone.model.blocks.11.attn.qkv.bias', 'backbone.model.blocks.10.mlp.fc2.bias', 'backbone.model.blocks.5.mlp.fc1.weight',
+             'backbone.model.blocks.0.norm1.weight', 'backbone.model.patch_embed.proj.weight', 'backbone.model.cls_token'}
+    rows = _grad_report(model, orc, names)
+    assert len(rows) == len(names)
+    bad = [r for r in rows if r[1] > 6e-2 or r[2] > 6e-2 or r[3] < 0.998]
+    assert not bad, bad
+
+
+def test_config5_vitl_full_depth_cls_features_vs_hf_golden(golden_dir):
+    """BASELINE config 5's backbone at full size (ViT-L/16: D = 1024, 24 layers, 16 heads) vs HF ViTModel."""
+    g = load_golden(os.path.join(golden_dir, 'g7_vitl_cls.npz'))
+    from avt_amd.models.vit import HipViT
+    from oracle.avt_oracle import closed_form_fill_
+    vit = HipViT(1024, 24, 16).cuda()
+    closed_form_fill_(list(vit.named_parameters()))
+    assert sum(p.numel() for p in vit.parameters()) == 303301632
+    gen = torch.Generator().manual_seed(15)
+    frames = torch.rand((1, 3, 224, 224), generator=gen) * 2 - 1
+    with torch.no_grad():
+        f = vit(frames.cuda())
+    torch.cuda.synchronize()
+    assert rel(f, g['cls_hf']) < 4e-2, rel(f, g['cls_hf'])        # 24 layers deep: twice the roundings of ViT-B
+
+
+def test_config5_vitl_arch_step_vs_oracle():
+    """ViT-L/16 block shapes (D = 1024, H = 16, MLP 4096) x 3 layers + the full-size head, one training step, B = 1, T = 3."""
+    model, orc = _full_arch_vs_oracle((1024, 3, 16, 224), T=3, B=1, seed=23)
+    rows = _grad_report(model, orc)
+    bad = [r for r in rows if r[1] > 6e-2 or r[2] > 6e-2 or r[3] < 0.998]
+    assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize('tag,shape', [('h2_l8', (32, 64, 8, 2, 13)), ('h8_l8', (32, 128, 8, 8, 13))])
+def test_g8_other_head_shapes_vs_reference_golden(golden_dir, tag, shape):
+    """n_head = 2 / 8, n_layer = 8 heads (expts/13_50s_avt.txt:16-17) on the same kernels."""
+    g = load_golden(os.path.join(golden_dir, f'g8_head_{tag}.npz'))
+    IN, DH, L, H, C = shape
+    model = build_hip_model('feat', IN, DH, L, H, C)
+    _fill(model)
+    out, losses, accs, tot = hip_step(model, g['in/video'].cuda(), g['in/target'].cuda(), g['in/sub'].cuda())
+    assert rel(out['logits/action'], g['out/logits/action']) < TOL_OUT
+    assert rel(out['past_logits/action'], g['out/past_logits/action']) < TOL_OUT
+    assert abs(float(tot) - float(g['total_loss'])) / abs(float(g['total_loss'])) < 3e-2
+    params = dict(model.named_parameters())
+    for k in [k for k in g if k.startswith('grad/')]:
+        assert rel(params[k[5:]].grad, g[k]) < TOL_GRAD, (k, rel(params[k[5:]].grad, g[k]))
+
+
+# ---- round 2: eval path (SURVEY 8f-1) ----------------------------------------------------------------------------------------
+def test_g6a_multicrop_rollout_tiny_vit_vs_reference_golden(golden_dir):
+    """7-D multi-crop video (3 crops averaged, models/base_model.py:251-273) + KV-cache roll-out (output_len_eval = 3,
+    models/future_prediction.py:168-202), eval mode, against the reference's BaseModel / AVTh."""
+    g = load_golden(os.path.join(golden_dir, 'g6a_rollout_multicrop_tiny.npz'))
+    model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32), output_len_eval=3)
+    _fill(model)
+    model.eval()
+    video, target = g['in/video'].cuda(), g['in/target'].cuda()
+    with torch.no_grad():
+        out, aux = model(video, target_shape=target.shape)
+        model.future_predictor.output_len_eval = -1
+        single, _ = model(video[:, :, 0], target_shape=target.shape)
+    torch.cuda.synchronize()
+    for k in ['logits/action', 'past_logits/action', 'future', 'past', 'future_agg', 'backbone_mean']:
+        assert out[k].shape == g[f'out/{k}'].shape, k
+        assert rel(out[k], g[f'out/{k}']) < TOL_OUT, (k, rel(out[k], g[f'out/{k}']))
+    assert rel(aux['feat'], g['loss/feat']) < TOL_OUT
+    assert rel(single['logits/action'], g['out_single_crop_no_rollout/logits/action']) < TOL_OUT
+    assert rel(out['logits/action'], g['out_single_crop_no_rollout/logits/action']) > 5e-2       # both switches matter
+
+
+def test_g6b_rollout_full_size_head_vs_reference_golden(golden_dir):
+    g = load_golden(os.path.join(golden_dir, 'g6b_rollout_full_head.npz'))
+    model = build_hip_model('feat', 768, 2048, 6, 4, 3806, output_len_eval=4)
+    _fill(model)
+    model.eval()
+    gen = torch.Generator().manual_seed(14)
+    video = (torch.rand((2, 10, 2, 768, 1, 1, 1), generator=gen) * 2 - 1).cuda()
+    with torch.no_grad():
+        out, aux = model(video, target_shape=(2,))
+    torch.cuda.synchronize()
+    assert rel(out['logits/action'], g['out/logits/action']) < TOL_OUT
+    assert rel(out['future'], g['out/future']) < TOL_OUT and rel(out['past'], g['out/past']) < TOL_OUT
+    assert rel(out['past_logits/action'][:, :, ::16], g['out/past_logits/action_sub']) < TOL_OUT
+    assert rel(aux['feat'][:, :, ::8], g['loss/feat_sub']) < TOL_OUT
+    model.train()                                    # roll-out with gradients is not implemented: must fail loudly
+    model.future_predictor.output_len = 2
+    with pytest.raises(NotImplementedError):
+        model(video[:, :, 0], target_shape=(2,))
+
+
+# ---- round 2: structure checks -------------------------------------------------------------------------------------------------
+def test_cls_only_last_block_equals_all_token_path():
+    """The last ViT block computed for the CLS rows only gives the same features and gradients as the all-token path."""
+    from avt_amd.models.vit import HipViT
+    torch.manual_seed(3)
+    res = {}
+    frames = (torch.rand((6, 3, 48, 48)) * 2 - 1).cuda()
+    dfeat = torch.randn((6, 192)).cuda()
+    for flag in (True, False):
+        torch.manual_seed(5)
+        vit = HipViT(192, 3, 3, img_size=48).cuda()
+        with torch.no_grad():
+            for n, p in vit.named_parameters():
+                if p.ndim >= 2:
+                    p.normal_(0, 0.08)
+                elif 'bias' in n:
+                    p.normal_(0, 0.1)
+        vit.cls_only_last_block = flag
+        vit.zero_grad()
+        f = vit(frames)
+        f.backward(dfeat)
+        torch.cuda.synchronize()
+        res[flag] = (f.detach().clone(), {n: p.grad.detach().clone() for n, p in vit.named_parameters()})
+    assert rel(res[True][0], res[False][0]) < 1e-2
+    for n in res[True][1]:
+        a, b = res[True][1][n], res[False][1][n]
+        if float(b.abs().max()) < 1e-6:               # qkv bias, k part: exactly zero in the CLS path, rounding noise in the other
+            assert float(a.abs().max()) < 1e-3, n
+            continue
+        assert rel(a, b) < 2.5e-2, (n, rel(a, b))
+
+
+def test_reference_loop_order_with_a_torch_optimizer_trains():
+    """forward -> optimizer.zero_grad() (set_to_none=True) -> backward -> step, the reference's order (func/train.py:221-233),
+    with torch.optim.SGD on the HIP model: the fused backward re-attaches the gradient views, so the parameters move exactly
+    as they do under the fused optimizer."""
+    from avt_amd.config import Cfg
+    from avt_amd.func.train import Trainer
+    from avt_amd.func.train_eval_ops import Basic
+    from avt_amd.optim import FusedSGD
+    g = torch.Generator().manual_seed(9)
+    video = torch.rand((2, 4, 3, 1, 32, 32), generator=g) * 2 - 1
+    data = {'video': video.cuda(), 'target': {'action': torch.randint(0, 17, (2,), generator=g).cuda()},
+            'target_subclips': {'action': torch.randint(-1, 17, (2, 4, 1), generator=g).cuda()}}
+    states = {}
+    for kind in ('torch', 'fused'):
+        torch.manual_seed(0)
+        model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.ndim >= 2:
+                    p.normal_(0, 0.1)
+        before = {n: p.detach().clone() for n, p in model.named_parameters()}
+        kw = dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-4)
+        opt = torch.optim.SGD(model.parameters(), **kw) if kind == 'torch' else FusedSGD(model.parameters(), arena=model.arena, **kw)
+        op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
+        tr = Trainer(model, op, opt, None, LOSS_WTS)
+        for _ in range(3):
+            tr.step(data)
+        torch.cuda.synchronize()
+        states[kind] = {n: p.detach().clone() for n, p in model.named_parameters()}
+        moved = [n for n in before if not torch.equal(before[n], states[kind][n])]
+        assert len(moved) > 0.9 * len(before), (kind, len(moved), len(before))
+    for n in states['torch']:
+        assert rel(states['torch'][n], states['fused'][n]) < 1e-3, n
+
+
+def test_grad_clip_and_frozen_groups():
+    """opt.grad_clip.max_norm (func/train.py:224-231) and zero-LR groups (func/train.py:735-742) are honoured."""
+    from avt_amd.config import Cfg
+    from avt_amd.func.train import Trainer, build_optimizer
+    from avt_amd.func.train_eval_ops import Basic
+    torch.manual_seed(0)
+    model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
+    cfg = Cfg(opt=Cfg(lr_wd=[['backbone', 0.0, 0.0], ['future_predictor', 0.05, 1e-4], ['classifiers', 0.05, 1e-4]],
+                      optimizer=Cfg(_target_='torch.optim.SGD', momentum=0.9, nesterov=True), bias_bn_wd_scale=1.0,
+                      scale_lr_by_bs=False, classifier_only=False), train=Cfg(batch_size=2))
+    opt = build_optimizer(cfg, model, 1)
+    assert all(not p.requires_grad for p in model.backbone.parameters())
+    op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
+    tr = Trainer(model, op, opt, None, LOSS_WTS, grad_clip={'max_norm': 1e-3, 'norm_type': 2})
+    g = torch.Generator().manual_seed(9)
+    data = {'video': (torch.rand((2, 4, 3, 1, 32, 32), generator=g) * 2 - 1).cuda(),
+            'target': {'action': torch.randint(0, 17, (2,), generator=g).cuda()},
+            'target_subclips': {'action': torch.randint(-1, 17, (2, 4, 1), generator=g).cuda()}}
+    bb = {n: p.detach().clone() for n, p in model.backbone.named_parameters()}
+    hd = model.future_predictor.encoder.weight.detach().clone()
+    tr.step(data)
+    torch.cuda.synchronize()
+    for n, p in model.backbone.named_parameters():
+        assert torch.equal(p, bb[n]), n
+    step = (model.future_predictor.encoder.weight - hd).abs().max()
+    assert 0 < float(step) < 0.05 * 1e-3 * 1.01 + 1e-4 * 0.05 * float(hd.abs().max()) + 1e-7      # |dp| <= lr * (clipped |g| + wd |p|)
+    assert float(model.arena.grad.abs().max()) == 0.0            # consumed ranges re-zeroed, frozen ranges kept clean
+
+
+def test_train_net_entry_runs_the_composed_experiment(tmp_path):
+    """train_net.py composes conf/ + expts/01_ek100_avt.txt (the reference's Hydra surface) and trains on the GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'train_net.py'), '-c', os.path.join(root, 'expts', '01_ek100_avt.txt'),
+                        '--steps', '3', '--batch', '2'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('iter ')]
+    assert len(lines) == 3, r.stdout[-2000:]
+    losses = [float(l.split('loss ')[1].split()[0]) for l in lines]
+    assert all(l == l and 0 < l < 100 for l in losses), losses
+
+
+def test_checkpoint_round_trip_with_the_reference_format(tmp_path):
+    """a checkpoint in the reference's format ({'model', 'optimizer' (torch.optim.SGD), 'lr_scheduler', 'epoch'},
+    reference parameter names) resumes on the HIP model + fused optimizer; after one step each side the HIP checkpoint loads
+    back into the fp32 oracle + torch.optim.SGD with equal parameters and momentum buffers (bf16-GEMM tolerance)."""
+    from avt_amd.common.scheduler import CosineLR, Warmup
+    from avt_amd.func.train import load_checkpoint, store_checkpoint
+    from avt_amd.optim import FusedSGD
+    torch.manual_seed(0)
+    orc = build_oracle_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
+    with torch.no_grad():
+        for n, p in orc.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.1)
+    kw = dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    o_opt = torch.optim.SGD(orc.parameters(), **kw)
+    g = torch.Generator().manual_seed(5)
+    video = torch.rand((2, 4, 3, 1, 32, 32), generator=g) * 2 - 1
+    target, sub = torch.randint(0, 17, (2,), generator=g), torch.randint(-1, 17, (2, 4, 1), generator=g)
+    oracle_step(orc, video, target, sub)
+    o_opt.step()                                                         # momentum buffers now exist
+    ck = tmp_path / 'checkpoint.pth'
+    torch.save({'model': orc.state_dict(), 'optimizer': o_opt.state_dict(), 'lr_scheduler': {}, 'epoch': 1.5}, ck)   # reference layout
+    # ---- resume on the HIP side ----
+    model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
+    opt = FusedSGD(model.parameters(), arena=model.arena, **kw)
+    sched = Warmup(opt, CosineLR(opt, num_epochs=3, iters_per_epoch=4, world_size=1), num_epochs=1, iters_per_epoch=4, world_size=1)
+    assert load_checkpoint(str(ck), model, opt, sched) == 1.5
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach().cpu(), dict(orc.named_parameters())[n].detach()), n
+    for pg in opt.param_groups:
+        pg['lr'] = 0.05
+    # ---- one more step on both sides ----
+    oracle_step(orc, video, target, sub)
+    o_opt.step()
+    hip_step(model, video.cuda(), target.cuda(), sub.cuda())
+    opt.step()
+    torch.cuda.synchronize()
+    ck2 = tmp_path / 'checkpoint_hip.pth'
+    store_checkpoint(str(ck2), model, opt, sched, 1.75)
+    # ---- the HIP checkpoint loads into the torch side (reference resume code path, func/train.py:760-769) ----
+    torch.manual_seed(9)
+    orc2 = build_oracle_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
+    o_opt2 = torch.optim.SGD(orc2.parameters(), **kw)
+    c = torch.load(ck2, map_location='cpu', weights_only=False)
+    orc2.load_state_dict(c['model'])
+    o_opt2.load_state_dict(c['optimizer'])
+    assert c['epoch'] == 1.75 and set(c['lr_scheduler']) == {'base_sched_dict', 'other_stuff'}
+    for (n, a), b in zip(orc.named_parameters(), orc2.parameters()):
+        assert rel(b, a) < 1e-2, (n, rel(b, a))
+    s1, s2 = o_opt.state_dict()['state'], o_opt2.state_dict()['state']
+    assert set(s1) == set(s2)
+    for i in s1:
+        if float(s1[i]['momentum_buffer'].abs().max()) > 1e-6:
+            assert rel(s2[i]['momentum_buffer'], s1[i]['momentum_buffer']) < 5e-2, i

@@ -78,6 +78,87 @@ def test_g3b_vitb_cls(golden_dir):
     assert rel(f, g['cls_hf']) < 1e-4
 
 
+def test_g2b_full_head_T15(golden_dir):
+    """BASELINE config 4's head (expts/07: 15 frames) against the reference-generated golden."""
+    g = load_golden(os.path.join(golden_dir, 'g2b_full_head_T15.npz'))
+    from oracle.make_golden import synth_batch
+    orc = build_oracle_model('feat', 768, 2048, 6, 4, 3806)
+    O.closed_form_fill_(list(orc.named_parameters()))
+    video, target, sub = synth_batch(2, 15, 3806, (768, 1, 1, 1), seed=12)
+    out, losses, accs, tot = oracle_step(orc, video, target, sub)
+    assert rel(out['logits/action'], g['out/logits/action']) < 1e-4
+    assert rel(out['past'], g['out/past']) < 1e-4
+    assert abs(float(tot) - float(g['total_loss'])) / abs(float(g['total_loss'])) < 1e-5
+    for n, p in orc.named_parameters():
+        assert abs(float(p.grad.norm()) - float(g[f'gradnorm/{n}'])) / (float(g[f'gradnorm/{n}']) + 1e-12) < 1e-3, n
+    wpe = orc.future_predictor.gpt_model.wpe.weight.grad
+    assert rel(wpe[:16, ::8], g['grad/future_predictor.gpt_model.wpe.weight_rows0_16']) < 1e-4
+    assert float(wpe[15:].abs().max()) == 0.0                      # only positions 0..14 are touched at T = 15
+
+
+def test_g6_eval_rollout_and_multicrop(golden_dir):
+    """Eval path: multi-crop averaging + roll-out, oracle vs the reference's BaseModel / AVTh (HF KV cache)."""
+    g = load_golden(os.path.join(golden_dir, 'g6a_rollout_multicrop_tiny.npz'))
+    orc = build_oracle_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32), output_len_eval=3)
+    O.closed_form_fill_(list(orc.named_parameters()))
+    orc.eval()
+    with torch.no_grad():
+        out, aux = orc(g['in/video'], target_shape=g['in/target'].shape)
+        single, _ = build_and_run_single_crop(orc, g['in/video'])
+    for k in ['logits/action', 'past_logits/action', 'future', 'past', 'future_agg', 'backbone_mean']:
+        assert rel(out[k], g[f'out/{k}']) < 1e-4, k
+    assert rel(aux['feat'], g['loss/feat']) < 1e-4
+    assert rel(single['logits/action'], g['out_single_crop_no_rollout/logits/action']) < 1e-4
+    assert rel(out['logits/action'], g['out_single_crop_no_rollout/logits/action']) > 1e-2      # the switches matter
+    g = load_golden(os.path.join(golden_dir, 'g6b_rollout_full_head.npz'))
+    orc = build_oracle_model('feat', 768, 2048, 6, 4, 3806, output_len_eval=4)
+    O.closed_form_fill_(list(orc.named_parameters()))
+    orc.eval()
+    gen = torch.Generator().manual_seed(14)
+    video = torch.rand((2, 10, 2, 768, 1, 1, 1), generator=gen) * 2 - 1
+    with torch.no_grad():
+        out, aux = orc(video, target_shape=(2,))
+    assert rel(out['logits/action'], g['out/logits/action']) < 1e-4
+    assert rel(out['future'], g['out/future']) < 1e-4
+    assert rel(aux['feat'][:, :, ::8], g['loss/feat_sub']) < 1e-4
+
+
+def build_and_run_single_crop(orc, video7d):
+    keep = orc.future_predictor.output_len_eval
+    orc.future_predictor.output_len_eval = -1
+    try:
+        return orc(video7d[:, :, 0], target_shape=(video7d.size(0),))
+    finally:
+        orc.future_predictor.output_len_eval = keep
+
+
+def test_g7_vitl_cls(golden_dir):
+    """BASELINE config 5's backbone: full-depth ViT-L/16 vs HF ViTModel."""
+    g = load_golden(os.path.join(golden_dir, 'g7_vitl_cls.npz'))
+    vit = O.OracleViT(1024, 24, 16)
+    O.closed_form_fill_(list(vit.named_parameters()))
+    assert sum(p.numel() for p in vit.parameters()) == 303301632
+    gen = torch.Generator().manual_seed(15)
+    frames = torch.rand((1, 3, 224, 224), generator=gen) * 2 - 1
+    with torch.no_grad():
+        f = vit(frames)
+    assert rel(f, g['cls_hf']) < 1e-4
+
+
+@pytest.mark.parametrize('tag,shape', [('h2_l8', (32, 64, 8, 2, 13)), ('h8_l8', (32, 128, 8, 8, 13))])
+def test_g8_other_head_shapes(golden_dir, tag, shape):
+    g = load_golden(os.path.join(golden_dir, f'g8_head_{tag}.npz'))
+    IN, DH, L, H, C = shape
+    orc = build_oracle_model('feat', IN, DH, L, H, C)
+    O.closed_form_fill_(list(orc.named_parameters()))
+    out, losses, accs, tot = oracle_step(orc, g['in/video'], g['in/target'], g['in/sub'])
+    assert rel(out['logits/action'], g['out/logits/action']) < 1e-4
+    assert abs(float(tot) - float(g['total_loss'])) < 1e-4
+    params = dict(orc.named_parameters())
+    for k in [k for k in g if k.startswith('grad/')]:
+        assert rel(params[k[5:]].grad, g[k]) < 1e-4, k
+
+
 def test_g4_lr_schedules(golden_dir):
     z = np.load(os.path.join(golden_dir, 'g4_lr_schedules.npz'))
     for key in z.files:

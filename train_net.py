@@ -22,13 +22,14 @@ def main():
     ap.add_argument('-c', '--cfg', default=os.path.join(ROOT, 'expts', '01_ek100_avt.txt'))
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--batch', type=int, default=None)
+    ap.add_argument('--ckpt', default=None, help='resume from / store to this checkpoint.pth (reference format)')
     ap.add_argument('overrides', nargs='*')
     args = ap.parse_args()
     cfg = compose(os.path.join(ROOT, 'conf'), read_overrides(args.cfg) + list(args.overrides))
     random.seed(cfg.seed)
     torch.manual_seed(cfg.seed)
     mod = importlib.import_module(f'avt_amd.func.{cfg.train.fn}')
-    mod.main(cfg, steps=args.steps, batch_size=args.batch)
+    mod.main(cfg, steps=args.steps, batch_size=args.batch, ckpt=args.ckpt)
 
 
 if __name__ == '__main__':
