@@ -9,6 +9,7 @@
 //           dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy ; optional colsum(dx_out) (the bias gradient
 //           of the Linear that produced the residual stream) -- all accumulated with fp32 atomics after a
 //           per-block reduction.
+#include <cstdlib>
 #include "common.hpp"
 #include "../../include/avt_hip.h"
 
@@ -208,6 +209,74 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
+
+// ---- D = 768 (ViT-B): 96 16-byte chunks per row would leave half of every second load instruction idle with one row per
+// wave, so a wave takes TWO rows: 192 chunks = 3 full wave loads.  Chunk k = lane + 64 i belongs to row k / 96, column chunk
+// k % 96 (i = 0: row 0; i = 1: lanes 0-31 row 0, lanes 32-63 row 1; i = 2: row 1).
+constexpr int CPR96 = 96;
+__device__ __forceinline__ void split2(float s, bool r1, float& a0, float& a1) { a0 += r1 ? 0.f : s; a1 += r1 ? s : 0.f; }
+
+__global__ __launch_bounds__(256) void ln_fwd2_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16_t* __restrict__ y, int ldy,
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, float eps) {
+  constexpr int D = CPR96 * 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  int cc[3]; bool r1[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { const int k = lane + 64 * i; r1[i] = k >= CPR96; cc[i] = r1[i] ? k - CPR96 : k; }
+  float gam[3][8], bet[3][8];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    f32x4_t g0 = *(const f32x4_t*)(gamma + cc[i] * 8), g1 = *(const f32x4_t*)(gamma + cc[i] * 8 + 4);
+    f32x4_t b0 = *(const f32x4_t*)(beta + cc[i] * 8), b1 = *(const f32x4_t*)(beta + cc[i] * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gam[i][e] = g0[e]; gam[i][4 + e] = g1[e]; bet[i][e] = b0[e]; bet[i][4 + e] = b1[e]; }
+  }
+  const int npair = (rows + 1) >> 1;
+  for (int pair = blockIdx.x * 4 + wave; pair < npair; pair += gridDim.x * 4) {
+    const int row0 = pair * 2;
+    float v[3][8];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int row = row0 + (r1[i] ? 1 : 0);
+      u32x4_t w = (u32x4_t){0u, 0u, 0u, 0u};
+      if (row < rows) w = *(const u32x4_t*)(x + (size_t)row * ldx + cc[i] * 8);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[i][2 * e] = bflo(w[e]); v[i][2 * e + 1] = bfhi(w[e]); s += v[i][2 * e] + v[i][2 * e + 1]; }
+      split2(s, r1[i], s0, s1);
+    }
+    const float m0 = wave_sum(s0) * (1.f / D), m1 = wave_sum(s1) * (1.f / D);
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float m = r1[i] ? m1 : m0;
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - m; q += d * d; }
+      split2(q, r1[i], q0, q1);
+    }
+    const float rs0 = rsqrtf(wave_sum(q0) * (1.f / D) + eps), rs1 = rsqrtf(wave_sum(q1) * (1.f / D) + eps);
+    if (lane == 0) {
+      if (mean_out) { mean_out[row0] = m0; if (row0 + 1 < rows) mean_out[row0 + 1] = m1; }
+      if (rstd_out) { rstd_out[row0] = rs0; if (row0 + 1 < rows) rstd_out[row0 + 1] = rs1; }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int row = row0 + (r1[i] ? 1 : 0);
+      const float m = r1[i] ? m1 : m0, rs = r1[i] ? rs1 : rs0;
+      u32x4_t w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        w[e] = pack2bf((v[i][2 * e] - m) * rs * gam[i][2 * e] + bet[i][2 * e], (v[i][2 * e + 1] - m) * rs * gam[i][2 * e + 1] + bet[i][2 * e + 1]);
+      if (row < rows) *(u32x4_t*)(y + (size_t)row * ldy + cc[i] * 8) = w;
+    }
+  }
+}
+
+
 int pick_v(int D) { int nchunk = D / 8; return (nchunk + 63) / 64; }
 
 }  // namespace
@@ -220,6 +289,12 @@ extern "C" int avt_layernorm_fwd(const void* x, int ldx, const float* gamma, con
             "avt_layernorm_fwd: 16-byte alignment required");
   int grid = (rows + 3) / 4; if (grid > 4096) grid = 4096;
   hipStream_t s = (hipStream_t)stream;
+  if (D == 768 && rows >= 64) {           // two rows per wave: full 16-byte lanes (see ln_fwd2_kernel)
+    int g2 = ((rows + 1) / 2 + 3) / 4; if (g2 > 4096) g2 = 4096;
+    hipLaunchKernelGGL(ln_fwd2_kernel, dim3(g2), dim3(256), 0, s, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd, rows, eps);
+    AVT_LAUNCH_CHECK();
+    return 0;
+  }
 #define LN_FWD(V) hipLaunchKernelGGL((ln_fwd_kernel<V>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, gamma, beta, (bf16_t*)y, ldy, mean, rstd, rows, D, eps)
   switch (pick_v(D)) {
     case 1: LN_FWD(1); break; case 2: LN_FWD(2); break; case 3: LN_FWD(3); break; case 4: LN_FWD(4); break;
@@ -239,6 +314,8 @@ extern "C" int avt_layernorm_bwd(const void* dy, int lddy, const void* x, int ld
   AVT_CHECK(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (!dres || aligned16(dres)), "avt_layernorm_bwd: 16-byte alignment required");
   int grid = (rows + 3) / 4; if (grid > 512) grid = 512;          // 2 blocks of 4 waves per CU (register-limited), persistent over rows
   hipStream_t s = (hipStream_t)stream;
+  // (a two-rows-per-wave variant like ln_fwd2_kernel was measured for backward: 349-407 us against this kernel's 346 us at
+  //  252160 x 768 -- three input streams per row leave no registers for it to win; not kept)
 #define LN_BWD(V) hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, dgamma, dbeta, colsum, rows, D)
   switch (pick_v(D)) {
     case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break; case 4: LN_BWD(4); break;

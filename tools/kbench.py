@@ -1,0 +1,94 @@
+"""Per-kernel timing on the bench shapes (HIP events, many launches): python tools/kbench.py [names...]
+names: ln attn cls gemm wgrad sgd   (default: all).  Prints microseconds per launch and the achieved TB/s or TFLOP/s."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from avt_amd import ops
+
+B, T, S, D, H = int(os.environ.get('KB_BATCH', 128)), 10, 197, 768, 12
+N = B * T
+M = N * S
+want = set(sys.argv[1:]) or {'ln', 'attn', 'cls', 'gemm', 'wgrad', 'sgd'}
+r = lambda *s: (torch.rand(s, device='cuda') * 2 - 1).to(torch.bfloat16)
+
+
+def timeit(name, fn, bytes_=None, flops=None, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    extra = ''
+    if bytes_:
+        extra += f'  {bytes_ / us / 1e6:6.2f} TB/s'
+    if flops:
+        extra += f'  {flops / us / 1e6:7.1f} TF/s'
+    print(f'{name:34s} {us:9.1f} us{extra}', flush=True)
+    return us
+
+
+if 'ln' in want:
+    x, dy, dres = r(M, D), r(M, D), r(M, D)
+    g, b = torch.rand(D, device='cuda') + 0.5, torch.rand(D, device='cuda')
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
+    dg, db, cs = torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
+    timeit('ln_fwd  M x 768', lambda: ops.layernorm_fwd(x, g, b, 1e-6), bytes_=M * D * 4)
+    timeit('ln_bwd  M x 768 (+dres, colsum)', lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, dres=dres, colsum=cs), bytes_=M * D * 8)
+    del x, dy, dres, y
+if 'attn' in want:
+    qkv = r(M, 3 * D)
+    out, lse = ops.vit_attn_fwd(qkv, N, S, H)
+    do = r(M, D)
+    dbias = torch.zeros(3 * D, device='cuda')
+    fl = 4.0 * S * S * 64 * H * N
+    timeit('vit_attn_fwd', lambda: ops.vit_attn_fwd(qkv, N, S, H), flops=fl)
+    timeit('vit_attn_bwd', lambda: ops.vit_attn_bwd(qkv, out, do, lse, N, S, H, dbias=dbias), flops=2.5 * fl)
+    del qkv, out, do
+if 'cls' in want:
+    q, kv, do = r(N, D), r(M, 2 * D), r(N, D)
+    o, pr = ops.cls_attn_fwd(q, kv, N, S, H)
+    timeit('cls_attn_fwd', lambda: ops.cls_attn_fwd(q, kv, N, S, H), bytes_=M * 2 * D * 2)
+    timeit('cls_attn_bwd', lambda: ops.cls_attn_bwd(q, kv, pr, do, N, S, H), bytes_=M * 2 * D * 4)
+    del q, kv, do
+if 'gemm' in want:
+  for TILE in [int(t) for t in os.environ.get('KB_TILES', '0').split(',')]:
+    print(f'--- tile {TILE}'); ops.FORCE_TILE = TILE
+    bias3, bias1 = torch.rand(3072, device='cuda'), torch.rand(768, device='cuda')
+    x, w1, w2 = r(M, D), r(3072, D), r(D, 3072)
+    pre = torch.empty((M, 3072), device='cuda', dtype=torch.bfloat16)
+    act = torch.empty((M, 3072), device='cuda', dtype=torch.bfloat16)
+    cs3 = torch.zeros(3072, device='cuda')
+    fl = 2.0 * M * D * 3072
+    timeit('fc1 fwd +bias+gelu+gelu\'', lambda: ops.linear_fwd(x, w1, bias=bias3, act=ops.ACT_GELU_ERF, c2=pre, out=act), flops=fl)
+    timeit('fc1 fwd plain', lambda: ops.linear_fwd(x, w1, out=act), flops=fl)
+    timeit('fc2 dgrad x aux +colsum', lambda: ops.linear_dgrad(x, w2, act=ops.ACT_MUL_AUX, aux=pre, colsum=cs3, out=act), flops=fl)
+    y = torch.empty((M, D), device='cuda', dtype=torch.bfloat16)
+    timeit('fc2 fwd +bias+res', lambda: ops.linear_fwd(act, w2, bias=bias1, res=x, out=y), flops=fl)
+    timeit('fc1 dgrad', lambda: ops.linear_dgrad(act, w1, out=y), flops=fl)
+    wp = r(D, D)
+    timeit('proj fwd +bias+res', lambda: ops.linear_fwd(x, wp, bias=bias1, res=x, out=y), flops=2.0 * M * D * D)
+    timeit('proj dgrad', lambda: ops.linear_dgrad(x, wp, out=y), flops=2.0 * M * D * D)
+    wq = r(3 * D, D)
+    qkv = torch.empty((M, 3 * D), device='cuda', dtype=torch.bfloat16)
+    timeit('qkv fwd +bias', lambda: ops.linear_fwd(x, wq, bias=torch.zeros(3 * D, device='cuda'), out=qkv), flops=2.0 * M * D * 3 * D)
+    timeit('qkv dgrad', lambda: ops.linear_dgrad(qkv, wq, out=y), flops=2.0 * M * D * 3 * D)
+    if 'wgrad' in want:
+        dw = torch.zeros((3072, D), device='cuda')
+        timeit('fc1 wgrad', lambda: ops.linear_wgrad(act, x, dw), flops=fl)
+        dw2 = torch.zeros((D, 3072), device='cuda')
+        timeit('fc2 wgrad', lambda: ops.linear_wgrad(x, act, dw2), flops=fl)
+        dwq = torch.zeros((3 * D, D), device='cuda')
+        timeit('qkv wgrad', lambda: ops.linear_wgrad(qkv, x, dwq), flops=2.0 * M * D * 3 * D)
+        dwp = torch.zeros((D, D), device='cuda')
+        timeit('proj wgrad', lambda: ops.linear_wgrad(y, x, dwp), flops=2.0 * M * D * D)
+  ops.FORCE_TILE = 0
+if 'sgd' in want:
+    n = 396_120_000 // 64 * 64
+    p_, g_, m_ = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    sh = torch.zeros(n, device='cuda', dtype=torch.bfloat16)
+    timeit('sgd 396M', lambda: ops.sgd_step(p_, g_, m_, sh, 1e-4, 0.9, 1e-6), bytes_=n * 26)
