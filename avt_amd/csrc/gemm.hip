@@ -38,6 +38,8 @@ struct GemmParams {
   int out_f32;
   int splitk;
   int tiles_m, tiles_n;
+  size_t ws_bytes;
+  float* ws;                     // EPI 2: split-K partial slabs, [splitk * tiles][BM * BN] fp32 in accumulator order
   int strip_w;                   // > 0: tile order = strips of strip_w tile columns (see tile_of)
   uint32_t a_bytes, b_bytes;     // buffer-descriptor bounds
   uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
@@ -588,7 +590,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
                                               int row0, int col0) {
   // row0/col0: global coordinates of this wave's tile origin
   static_assert(WM == TM * 32 && WN == TN * 32 && TM <= 4, "wave tile geometry");
-  if (EPI == 1) {
+  if (EPI == 2) {
+    // deterministic weight-gradient epilogue: this block's partial tile goes to its own slab of the caller's workspace in
+    // accumulator order (full 1-KB wave stores); splitk_reduce_kernel adds the slabs in split order into C
+    const int NWV = (int)(blockDim.x >> 6);
+    const int slab = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splitk);      // = split * tiles + tile
+    float* dst = p.ws + (size_t)slab * (size_t)(NWV * TM * TN * 1024) + (size_t)wave * (TM * TN * 1024) + lane * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(f32x4_t*)(dst + ((i * TN + j) * 4 + q) * 256) = (f32x4_t){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    return;
+  } else if (EPI == 1) {
     // weight-gradient epilogue: fp32 accumulate into C (atomics; C is pre-zeroed or holds the running sum)
     float* C = (float*)p.C;
 #pragma unroll
@@ -897,6 +913,51 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   }
 }
 
+// Second pass of the deterministic split-K accumulate: one wave per 1-KB chunk (producing wave w, block (i, j), register
+// quad q) mirrors the producer's register layout, sums the chunk over the splits IN ORDER and adds the result to C (every C
+// element has exactly one owner, so plain read-modify-write; C keeps the running sum of earlier GEMMs into the same gradient).
+template <int TM, int TN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int ldc, int M, int N,
+                                                            int tiles_n, int ntile, int splitk) {
+  constexpr int NW = WGM * WGN, WM = TM * 32, WN = TN * 32, BM = WM * WGM, BN = WN * WGN;
+  constexpr int CHUNKS = NW * TM * TN * 4;                 // 1-KB chunks per tile
+  const int lane = threadIdx.x & 63;
+  const int chunk_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int t = chunk_id / CHUNKS, c = chunk_id % CHUNKS;
+  if (t >= ntile) return;
+  const int wave = c / (TM * TN * 4), rem = c % (TM * TN * 4);
+  const int i = rem / (TN * 4), j = (rem / 4) % TN, q = rem % 4;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const size_t slab = (size_t)BM * BN;
+  const float* src = ws + (size_t)t * slab + (size_t)c * 256 + lane * 4;
+  const size_t sstride = (size_t)ntile * slab;
+  f32x4_t v = *(const f32x4_t*)src;
+  int s_ = 1;
+  for (; s_ + 3 < splitk; s_ += 4) {                       // four independent loads in flight, added in split order
+    const f32x4_t a = *(const f32x4_t*)(src + (size_t)s_ * sstride), b = *(const f32x4_t*)(src + (size_t)(s_ + 1) * sstride);
+    const f32x4_t d = *(const f32x4_t*)(src + (size_t)(s_ + 2) * sstride), e = *(const f32x4_t*)(src + (size_t)(s_ + 3) * sstride);
+    v += a; v += b; v += d; v += e;
+  }
+  for (; s_ < splitk; ++s_) v += *(const f32x4_t*)(src + (size_t)s_ * sstride);
+  const int n = (t % tiles_n) * BN + wn * WN + j * 32 + (lane & 31);
+  const int m0 = (t / tiles_n) * BM + wm * WM + i * 32 + 8 * q + 4 * (lane >> 5);
+  if (n < N) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (m0 + k < M) C[(size_t)(m0 + k) * ldc + n] += v[k];
+  }
+}
+template <int TM, int TN, int WGM, int WGN>
+int launch_reduce(const GemmParams& p, hipStream_t s) {
+  const int ntile = p.tiles_m * p.tiles_n;
+  constexpr int CHUNKS = WGM * WGN * TM * TN * 4;
+  hipLaunchKernelGGL((splitk_reduce_kernel<TM, TN, WGM, WGN>), dim3((ntile * CHUNKS + 3) / 4), dim3(256), 0, s, (const float*)p.ws, (float*)p.C, p.ldc,
+                     p.M, p.N, p.tiles_n, ntile, p.splitk);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { avt_set_error("avt_gemm: reduce launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
 // Split-K factor for the accumulate (weight-gradient) epilogue: one workgroup per CU, so pick the factor whose block count
 // best fills whole rounds of the 256 CUs (576 blocks = 2.25 rounds wastes a quarter of the chip; 504 = 1.97 rounds does
 // not), keeping at least `kmin` K tiles per split.
@@ -951,10 +1012,16 @@ int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk,
   const int nk = (p.K + BK - 1) / BK;
   if (splitk <= 0) {                 // auto: about two blocks' worth of work per CU slot
     splitk = 1;
-    if (epi == 1) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk, (BM * BN >= 256 * 256) ? 1 : 2, 512 / BK);
+    if (epi >= 1) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk, (BM * BN >= 256 * 256) ? 1 : 2, 512 / BK);
   }
   if (splitk > nk) splitk = nk;
   p.splitk = splitk;
+  if (epi == 2) {                    // deterministic accumulate: only the weight-gradient layout (both operands reduction-major)
+    if (a_kmajor || b_kmajor) { avt_set_error("avt_gemm_accum_bf16: operands must both be stored reduction-index-major"); return -1; }
+    if ((size_t)p.tiles_m * p.tiles_n * splitk * BM * BN * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * BM * BN * 4); return -2; }
+    int rc = launch<BM, BN, WGM, WGN, BK, NSTAGE, false, false, 2, SPREAD, PR, MINW, NWL>(p, s);
+    return rc ? rc : launch_reduce<BM / WGM / 32, BN / WGN / 32, WGM, WGN>(p, s);
+  }
   return epi ? dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 1, SPREAD, PR, MINW, NWL>(p, a_kmajor, b_kmajor, s)
              : dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 0, SPREAD, PR, MINW, NWL>(p, a_kmajor, b_kmajor, s);
 }
@@ -1523,10 +1590,16 @@ int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
   const int nk = (p.K + 63) / 64;
   if (splitk <= 0) {
     splitk = 1;
-    if (epi == 1) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk, 1, 8);
+    if (epi >= 1) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk, 1, 8);
   }
   if (splitk > nk) splitk = nk;
   p.splitk = splitk;
+  if (epi == 2) {
+    if (a_kmajor || b_kmajor) { avt_set_error("avt_gemm_accum_bf16: operands must both be stored reduction-index-major"); return -1; }
+    if ((size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4); return -2; }
+    int rc = launch_8p<false, false, 2>(p, s);
+    return rc ? rc : launch_reduce<4, 2, 2, 4>(p, s);
+  }
   if (epi == 0) {
     if (a_kmajor && b_kmajor) return launch_8p<true, true, 0>(p, s);
     if (a_kmajor && !b_kmajor) return launch_8p<true, false, 0>(p, s);
@@ -1541,23 +1614,24 @@ int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
 
 }  // namespace
 
-extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,
-                             void* C, int ldc, int M, int N, int K,
-                             const float* bias, int act, const void* aux, int ldaux,
-                             void* C2, int ldc2, const void* res, int ldres, int res_period,
-                             float drop_p, uint64_t drop_seed, float* colsum,
-                             int out_mode, int splitk, int tile, void* stream) {
+static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,
+                     void* C, int ldc, int M, int N, int K,
+                     const float* bias, int act, const void* aux, int ldaux,
+                     void* C2, int ldc2, const void* res, int ldres, int res_period,
+                     float drop_p, uint64_t drop_seed, float* colsum,
+                     int out_mode, int splitk, int tile, void* ws, size_t ws_bytes, void* stream) {
   AVT_CHECK(A && B && C, "avt_gemm_bf16: null operand");
   AVT_CHECK(M > 0 && N > 0 && K > 0, "avt_gemm_bf16: bad dims M=%d N=%d K=%d", M, N, K);
   AVT_CHECK(aligned16(A) && aligned16(B) && aligned16(C), "avt_gemm_bf16: operands must be 16-byte aligned");
   AVT_CHECK(lda % 8 == 0 && ldb % 8 == 0, "avt_gemm_bf16: lda/ldb must be multiples of 8 (got %d, %d)", lda, ldb);
   AVT_CHECK(K % 8 == 0 || (!a_kmajor && !b_kmajor), "avt_gemm_bf16: K must be a multiple of 8 for k-major operands (K=%d)", K);
-  AVT_CHECK(out_mode >= 0 && out_mode <= 2, "avt_gemm_bf16: out_mode must be 0 (bf16), 1 (fp32) or 2 (fp32 atomic accumulate)");
+  AVT_CHECK(out_mode >= 0 && out_mode <= 3, "avt_gemm_bf16: out_mode must be 0 (bf16), 1 (fp32) or 2 (fp32 atomic accumulate)");
+  AVT_CHECK(out_mode != 3 || (ws && aligned16(ws)), "avt_gemm_accum_bf16: needs a 16-byte aligned workspace");
   AVT_CHECK(act >= 0 && act <= 3, "avt_gemm_bf16: bad act %d", act);
   AVT_CHECK(act < 3 || aux, "avt_gemm_bf16: act %d needs aux", act);
   AVT_CHECK(drop_p >= 0.f && drop_p < 1.f, "avt_gemm_bf16: bad dropout p");
   GemmParams p{};
-  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.C2 = (bf16_t*)C2;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C; p.C2 = (bf16_t*)C2; p.ws = (float*)ws; p.ws_bytes = ws_bytes;
   p.bias = bias; p.res = (const bf16_t*)res; p.aux = (const bf16_t*)aux; p.colsum = colsum;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldres = ldres; p.ldaux = ldaux;
   p.res_period = res_period; p.act = act; p.out_f32 = (out_mode == 1);
@@ -1571,7 +1645,7 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
   AVT_CHECK(ab < 0xFFFFFFF0ull && bb < 0xFFFFFFF0ull, "avt_gemm_bf16: operand larger than 4 GiB");
   p.a_bytes = (uint32_t)ab; p.b_bytes = (uint32_t)bb;
   hipStream_t s = (hipStream_t)stream;
-  const int epi = (out_mode == 2) ? 1 : 0;
+  const int epi = (out_mode == 2) ? 1 : (out_mode == 3 ? 2 : 0);
   if (epi == 0) {
     AVT_CHECK(N % 4 == 0 && ldc % 4 == 0 && (!C2 || ldc2 % 4 == 0) && (!res || ldres % 4 == 0) && (!aux || ldaux % 4 == 0),
               "avt_gemm_bf16: N and ldc/ldc2/ldres/ldaux must be multiples of 4 for the activation epilogue");
@@ -1587,7 +1661,7 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
   if (bm == 0) {
     long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (epi == 0) bm = (t256 >= 200) ? 256 : (t128 >= 192 ? 128 : 64);
+    if (epi == 0) bm = (t256 >= 200) ? 256 : (t128 >= 192 ? 128 : 64);   // epi 1 | 2: below
     else {
       long sk = ((K + 63) / 64) / 4; if (sk < 1) sk = 1; if (sk > 64) sk = 64;
       bm = (t256 * sk >= 256 && t256 < 4096) ? 256 : 128;
@@ -1619,4 +1693,32 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
   }
   avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 64, 128, 643, 256 / 2568 (one barrier per K tile) or 808 (8-phase) (got %d)", tile);
   return -1;
+}
+
+extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,
+                             void* C, int ldc, int M, int N, int K,
+                             const float* bias, int act, const void* aux, int ldaux,
+                             void* C2, int ldc2, const void* res, int ldres, int res_period,
+                             float drop_p, uint64_t drop_seed, float* colsum,
+                             int out_mode, int splitk, int tile, void* stream) {
+  AVT_CHECK(out_mode != 3, "avt_gemm_bf16: out_mode must be 0 (bf16), 1 (fp32) or 2 (fp32 atomic accumulate)");
+  return gemm_impl(A, a_kmajor, lda, B, b_kmajor, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, C2, ldc2, res, ldres, res_period,
+                   drop_p, drop_seed, colsum, out_mode, splitk, tile, nullptr, 0, stream);
+}
+
+extern "C" int avt_gemm_accum_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                                   int splitk, int tile, void* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_impl(A, 0, lda, B, 0, ldb, C, ldc, M, N, K, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, nullptr,
+                   3, splitk, tile, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t avt_gemm_accum_workspace_bytes(int M, int N, int K) {
+  // mirrors the automatic (tile = 0, splitk = 0) choice of gemm_impl for the accumulate epilogues
+  const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256), t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const int nk = (K + 63) / 64;
+  long sk = nk / 4; if (sk < 1) sk = 1; if (sk > 64) sk = 64;
+  const bool big = (t256 * sk >= 256 && t256 < 4096);
+  const long tiles = big ? t256 : t128;
+  int s = pick_splitk(tiles, nk, big ? 1 : 2, 8); if (s > nk) s = nk;
+  return (size_t)tiles * (size_t)s * (big ? 65536u : 16384u) * 4u;
 }

@@ -18,6 +18,7 @@ SIGNATURES = {
     'avt_abi_version': [],
     'avt_gemm_bf16': [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _U64, _P,
                       _I, _I, _I, _P],
+    'avt_gemm_accum_bf16': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, ctypes.c_size_t, _P],
     'avt_layernorm_fwd': [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P],
     'avt_layernorm_bwd': [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
     'avt_vit_attn_fwd': [_P, _P, _P, _I, _I, _I, _I, _F, _P],
@@ -68,6 +69,8 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.avt_gemm_accum_workspace_bytes.restype = ctypes.c_size_t
+    lib.avt_gemm_accum_workspace_bytes.argtypes = [_I, _I, _I]
     v = lib.avt_abi_version()
     if v != ABI_VERSION:
         raise AvtHipError(f'libavt_hip.so ABI version {v} != binding version {ABI_VERSION}')

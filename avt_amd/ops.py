@@ -87,6 +87,39 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
     return out
 
 
+# ---- deterministic weight-gradient accumulate ------------------------------------------------------------------------------
+DETERMINISTIC_WGRAD = True       # False: fp32 atomics straight into the gradient (out_mode 2), order-dependent in the last bits
+_WGRAD_WS = {}                   # (device index, stream) -> uint8 workspace; GEMMs on one stream are ordered, so they share it
+
+
+def _wgrad_workspace(device, nbytes):
+    key = (device.index, _stream())
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20), device=device, dtype=torch.uint8)
+        _WGRAD_WS[key] = ws
+    return ws
+
+
+def gemm_accum(A, B, C, M, N, K):
+    """C[M,N] (fp32) += sum_k A[k,m] B[k,n], both operands stored reduction-index-major; split-K partials go through a
+    workspace and are added in a fixed order (avt_gemm_accum_bf16) -- bit-reproducible weight gradients."""
+    if not DETERMINISTIC_WGRAD or FORCE_TILE:
+        return gemm(A, B, M, N, K, a_kmajor=False, b_kmajor=False, out=C, out_mode=OUT_ACCUM_F32)
+    _chk(A, BF16, 'A'); _chk(B, BF16, 'B'); _chk(C, torch.float32, 'C')
+    need = _lib.load().avt_gemm_accum_workspace_bytes(M, N, K)
+    ws = _wgrad_workspace(A.device, need)
+    trace = GEMM_TRACE
+    if trace is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.call('avt_gemm_accum_bf16', _p(A), _ld(A), _p(B), _ld(B), _p(C), _ld(C), M, N, K, 0, 0, _p(ws), ws.numel(), _stream())
+    if trace is not None:
+        ev1.record()
+        trace.append((gemm_variant(M, N, K, False, False, OUT_ACCUM_F32, 0), 2.0 * M * N * K, ev0, ev1))
+    return C
+
+
 # ---- the six contractions of a Linear (weight (out,in)) / HF Conv1D (weight (in,out)) layer ---------------------
 def linear_fwd(x, w, **kw):
     """y[M,N] = x[M,K] @ w[N,K]^T"""
@@ -101,7 +134,9 @@ def linear_dgrad(dy, w, **kw):
 def linear_wgrad(dy, x, dw, rows=None, **kw):
     """dw[N,K] (fp32) += dy[M,N]^T @ x[M,K]; ``rows`` limits the valid output rows (padded classifier)."""
     n = dw.size(0) if rows is None else rows
-    return gemm(dy, x, n, x.size(1), dy.size(0), a_kmajor=False, b_kmajor=False, out=dw, out_mode=OUT_ACCUM_F32, **kw)
+    if kw:
+        return gemm(dy, x, n, x.size(1), dy.size(0), a_kmajor=False, b_kmajor=False, out=dw, out_mode=OUT_ACCUM_F32, **kw)
+    return gemm_accum(dy, x, dw, n, x.size(1), dy.size(0))
 
 
 def conv1d_fwd(x, w, **kw):
@@ -116,7 +151,9 @@ def conv1d_dgrad(dy, w, **kw):
 
 def conv1d_wgrad(x, dy, dw, **kw):
     """dw[K,N] (fp32) += x[M,K]^T @ dy[M,N]"""
-    return gemm(x, dy, x.size(1), dy.size(1), x.size(0), a_kmajor=False, b_kmajor=False, out=dw, out_mode=OUT_ACCUM_F32, **kw)
+    if kw:
+        return gemm(x, dy, x.size(1), dy.size(1), x.size(0), a_kmajor=False, b_kmajor=False, out=dw, out_mode=OUT_ACCUM_F32, **kw)
+    return gemm_accum(x, dy, dw, x.size(1), dy.size(1), x.size(0))
 
 
 # ---- LayerNorm -------------------------------------------------------------------------------------------------------

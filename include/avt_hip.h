@@ -21,6 +21,7 @@
 #ifndef AVT_HIP_H_
 #define AVT_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -55,6 +56,15 @@ int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kma
                   void* C2, int ldc2, const void* res, int ldres, int res_period,
                   float drop_p, uint64_t drop_seed, float* colsum,
                   int out_mode, int splitk, int tile, void* stream);
+
+/* Deterministic weight-gradient accumulate: C[M,N] (fp32) += sum_k A[k,m] * B[k,n] with BOTH operands stored reduction-index-
+ * major (dW = dy^T x of a Linear, x^T dy of an HF Conv1D).  Same kernels as out_mode 2, but every (split, tile) workgroup
+ * writes its partial tile to its own slab of `workspace` and a second kernel adds the slabs in split order into C: no atomics,
+ * bit-reproducible, and cheaper than the atomics (66 MB of full-line stores + one pass instead of 16 M fp32 atomics for fc1).
+ * avt_gemm_accum_workspace_bytes(M, N, K) = bytes the automatic tile / split choice (tile = 0, splitk <= 0) needs. */
+int avt_gemm_accum_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                        int splitk, int tile, void* workspace, size_t workspace_bytes, void* stream);
+size_t avt_gemm_accum_workspace_bytes(int M, int N, int K);
 
 /* ---- LayerNorm ---------------------------------------------------------------------------------------------------
  * [timm] Block.norm1/norm2/VisionTransformer.norm (eps 1e-6); [hf] GPT2 ln_1/ln_2/ln_f (eps 1e-5).

@@ -453,3 +453,33 @@ def test_sgd_step(ops):
         assert float((p - pr.detach()).abs().max()) < 1e-5
         assert float(gg.abs().max()) == 0.0
         assert torch.equal(shadow, p.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize('M,P,Q', [(64, 128, 128), (500, 768, 768), (3152, 2304, 768), (50000, 3072, 768), (176, 3840, 768), (77, 64, 32), (1280, 768, 768)])
+def test_deterministic_wgrad_accumulate(ops, M, P, Q):
+    """avt_gemm_accum_bf16 (split-K slabs + ordered reduce): equals the fp32 reference, accumulates on top of C, and is
+    bit-identical from call to call -- unlike the atomic path, whose last bits depend on arrival order."""
+    dy, x = rnd((M, P), 1.0, 41), rnd((M, Q), 1.0, 42)
+    ref = dy.float().t() @ x.float()
+    base = rnd((P, Q), 1.0, 43, torch.float32)
+    outs = []
+    for _ in range(4):
+        dw = base.clone()
+        ops.linear_wgrad(dy, x, dw)
+        torch.cuda.synchronize()
+        outs.append(dw)
+    assert relerr(outs[0] - base, ref) < 2e-3
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    # strided operand rows (the CLS rows of a token tensor) and a row limit (padded classifier)
+    xs = torch.zeros((M * 3, Q), device='cuda', dtype=torch.bfloat16)
+    xs.view(M, 3 * Q)[:, :Q] = x
+    dw2 = base.clone()
+    ops.linear_wgrad(dy, xs.view(M, 3 * Q)[:, :Q], dw2)
+    torch.cuda.synchronize()
+    assert torch.equal(dw2, outs[0])
+    if P >= 128:
+        dw3 = base.clone()
+        ops.linear_wgrad(dy, x, dw3, rows=P - 17)
+        torch.cuda.synchronize()
+        assert relerr(dw3[:P - 17] - base[:P - 17], ref[:P - 17]) < 2e-3 and torch.equal(dw3[P - 17:], base[P - 17:])      # rows past the limit untouched

@@ -8,6 +8,7 @@ from avt_amd import ops
 B, T, S, D, H = int(os.environ.get('KB_BATCH', 128)), 10, 197, 768, 12
 N = B * T
 M = N * S
+ops.DETERMINISTIC_WGRAD = os.environ.get('KB_DET', '1') == '1'
 want = set(sys.argv[1:]) or {'ln', 'attn', 'cls', 'gemm', 'wgrad', 'sgd'}
 r = lambda *s: (torch.rand(s, device='cuda') * 2 - 1).to(torch.bfloat16)
 
