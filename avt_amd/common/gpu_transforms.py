@@ -1,0 +1,67 @@
+"""GPU input pipeline: the reference's per-clip CPU transform chain of func/train.py:550-592 --
+``ToTensorVideo -> Resize -> RandomHorizontalFlipVideo -> (ColorJitterVideo) -> x scale_pix_val -> (reverse channels) ->
+NormalizeVideo -> RandomCropVideo`` for training, ``... -> CenterCropVideo`` for evaluation -- as one fused HIP kernel over a
+whole batch of uint8 clips (``avt_video_preproc_u8``).  The random draws are made on the host with the same generators and
+distributions the reference's transforms use (``random.randint`` for the ``"248-280"`` size string, common/transforms.py:70-76;
+``random.random() < p`` for the flip, torchvision's RandomHorizontalFlipVideo; ``torch.randint`` for the crop corner, torchvision
+RandomCrop.get_params), so a seeded run draws the same sequence.
+
+Configured from the same ``data_train`` / ``data_eval`` keys (conf/data/default.yaml: scale_h, scale_w, crop_size, mean, std, flip_p,
+scale_pix_val, reverse_channels); colour jitter (0 in every AVT experiment) is not implemented and raises when requested.
+"""
+import random
+
+import torch
+
+from .. import ops
+
+
+class GpuClipTransform:
+    def __init__(self, scale_h, scale_w=-1, crop_size=224, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), flip_p=0.5,
+                 scale_pix_val=1.0, reverse_channels=False, train=True, color_jitter_brightness=0.0, color_jitter_contrast=0.0,
+                 color_jitter_saturation=0.0, color_jitter_hue=0.0, **_unused):
+        if any(v != 0 for v in (color_jitter_brightness, color_jitter_contrast, color_jitter_saturation, color_jitter_hue)):
+            raise NotImplementedError('colour jitter is 0 in the AVT experiments and not part of the fused kernel')
+        if crop_size is None:
+            raise NotImplementedError('the fused kernel writes a fixed-size batch: crop_size must be set')
+        self.scale_h, self.scale_w = scale_h, scale_w
+        self.crop = (crop_size, crop_size) if isinstance(crop_size, int) else tuple(crop_size)
+        self.mean, self.std = tuple(mean), tuple(std)
+        self.flip_p = flip_p if train else 0.0
+        self.scale_pix_val, self.reverse_channels, self.train = scale_pix_val, reverse_channels, train
+
+    @staticmethod
+    def _size(v):
+        """common/transforms.py:70-76: an int, or '<min>-<max>' drawn with random.randint (inclusive)."""
+        if isinstance(v, int):
+            return v
+        lo, hi = [int(e) for e in str(v).split('-')]
+        return random.randint(lo, hi)
+
+    def draw(self, H, W):
+        """One clip's (new_h, new_w, flip, crop_i, crop_j), in the order the reference's transform list consumes randomness."""
+        if isinstance(self.scale_w, int) and self.scale_w == -1:                 # func/train.py:510-521
+            target = self._size(self.scale_h)
+            s = target * 1.0 / min(H, W)
+            new_h, new_w = max(int(H * s), target), max(int(W * s), target)      # common/transforms.py:78-87
+        else:
+            new_h, new_w = self._size(self.scale_h), self._size(self.scale_w)
+        flip = int(random.random() < self.flip_p) if self.flip_p > 0 else 0
+        th, tw = self.crop
+        if new_h < th or new_w < tw:
+            raise ValueError(f'crop {self.crop} larger than the resized clip {(new_h, new_w)}')
+        if self.train:                                                           # torchvision RandomCrop.get_params
+            i = 0 if new_h == th else int(torch.randint(0, new_h - th + 1, size=(1,)).item())
+            j = 0 if new_w == tw else int(torch.randint(0, new_w - tw + 1, size=(1,)).item())
+        else:                                                                    # center_crop, common/transforms.py:112-121
+            i, j = int(round((new_h - th) / 2.0)), int(round((new_w - tw) / 2.0))
+        return new_h, new_w, flip, i, j
+
+    def __call__(self, clips_u8, params=None):
+        """clips_u8: uint8 (B, T, H, W, 3) on the GPU -> fp32 (B, T, 3, 1, crop_h, crop_w), the ``video`` entry of the sample
+        dict the model consumes.  ``params`` (B x 5 ints) overrides the draws (tests)."""
+        B, T, H, W, _ = clips_u8.shape
+        if params is None:
+            params = [self.draw(H, W) for _ in range(B)]
+        p = torch.tensor(params, dtype=torch.int32).to(clips_u8.device, non_blocking=True)
+        return ops.video_preproc(clips_u8.contiguous(), p, self.crop, self.scale_pix_val, self.mean, self.std, self.reverse_channels)

@@ -137,6 +137,15 @@ int avt_mse_shift_bwd(const float* dec, const float* x, const float* gloss, floa
 int avt_pad_cast_f32_to_bf16(const float* src, int lds, void* dst, int ldd, int rows, int cols, void* stream);
 int avt_add_rows_bf16(void* dst, long ldd, const void* src, long lds, int rows, int D, void* stream);
 
+/* ---- GPU input pipeline ----------------------------------------------------------------------------------
+ * The reference's per-clip CPU transform chain (func/train.py:550-569; common/transforms.py:60-91 resize, :124-146 to_tensor,
+ * :149-164 normalize, :167-175 hflip, RandomCropVideo / CenterCropVideo): uint8 frames (B,T,H,W,3) -> /255 -> bilinear resize
+ * (align_corners = False) to (new_h, new_w) -> optional horizontal flip -> x scale_pix -> optional channel reversal ->
+ * (v - mean) / std -> crop (OH, OW) at (crop_i, crop_j), written as fp32 (B,T,3,1,OH,OW).  params: int32 [B][5] =
+ * {new_h, new_w, flip, crop_i, crop_j} per clip (device memory; the random draws stay with the caller). mean3 / std3: host. */
+int avt_video_preproc_u8(const void* src, float* dst, const int* params, int B, int T, int H, int W, int OH, int OW,
+                         float scale_pix, const float* mean3, const float* std3, int reverse_channels, void* stream);
+
 /* ---- softmax cross-entropy -------------------------------------------------------------------------------------------
  * loss_fn/multidim_xentropy.py:11-25 (CrossEntropyLoss(ignore_index=-1, reduction='none')) + common/utils.py:17-44.
  * logits fp32 [R, ld], C valid columns; target int64 [R]; loss/lse fp32 [R]; rank int32 [R] (#logits > target logit,

@@ -366,6 +366,33 @@ def total_loss(losses, loss_wts):
 
 
 # --------------------------------------------------------------------------------------------------
+# Input pipeline (func/train.py:550-569 transform list; common/transforms.py functional forms)
+# --------------------------------------------------------------------------------------------------
+def resize_shape(clip_h, clip_w, target):
+    """common/transforms.py:78-87: shorter side -> target, the other side scaled, never below target."""
+    scale = target * 1.0 / min(clip_h, clip_w)
+    return max(int(clip_h * scale), target), max(int(clip_w * scale), target)
+
+
+def video_preproc(clip_u8, new_hw, flip, crop_ij, crop_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5),
+                  reverse_channels=False):
+    """One clip through the reference's training / eval transform chain with the random draws given explicitly.
+    clip_u8: uint8 (T, H, W, 3) -> float (3, T, h, w)."""
+    x = clip_u8.float().permute(3, 0, 1, 2) / 255.0                              # to_tensor, common/transforms.py:124-146
+    x = F.interpolate(x, size=tuple(new_hw), mode='bilinear')                    # resize, :60-91 (align_corners = None -> False)
+    if flip:
+        x = x.flip((-1,))                                                        # hflip, :167-175
+    x = x * scale_pix                                                            # func/train.py:559-560
+    if reverse_channels:
+        x = x[[2, 1, 0], ...]                                                    # func/train.py:561-564
+    m = torch.as_tensor(mean, dtype=x.dtype)[:, None, None, None]
+    sd = torch.as_tensor(std, dtype=x.dtype)[:, None, None, None]
+    x = (x - m) / sd                                                             # normalize, :149-164
+    i, j = crop_ij
+    return x[..., i:i + crop_hw[0], j:j + crop_hw[1]]                            # crop, :36-42
+
+
+# --------------------------------------------------------------------------------------------------
 # Optimiser + LR schedule (torch.optim.SGD nesterov; common/scheduler.py:57-75, 88-135)
 # --------------------------------------------------------------------------------------------------
 def sgd_nesterov_step(p, g, buf, lr, momentum=0.9, weight_decay=0.0, first=False):

@@ -11,6 +11,8 @@ runs only in the build container (needs /root/reference + HF transformers), comm
        models/base_model.py:251-273) and **roll-out** ``output_len_eval=3`` (models/future_prediction.py:168-202, HF KV cache):
        (a) tiny ViT (HF ViT inside the reference FrameLevelModel) + head; (b) full-size head on features, T=10, output_len_eval=4.
   G7   BASELINE config 5's backbone: full-depth ViT-L/16 (D=1024, L=24, H=16) CLS features on 1 frame from HF ViTModel.
+  G9   input pipeline: the reference's own common/transforms.py functions (to_tensor, resize, hflip, normalize, crop)
+       on random uint8 clips with explicit draws -- pins the fused GPU preprocessing kernel.
   G8   other head shapes sharing the kernels (expts/13_50s_avt.txt:16-17 and expts/04*): n_head=2/n_layer=8 and
        n_head=8/n_layer=8 tiny heads, one training step each.
 """
@@ -172,6 +174,43 @@ def main():
         keep['in/video'], keep['in/target'], keep['in/sub'] = video, target, sub
         np.savez_compressed(os.path.join(OUT, f'g8_head_{tag}.npz'), **G.to_np(keep))
         report.append(f'G8 {tag}: total loss {float(res["total_loss"]):.6f}')
+
+    # ---------------- G9: input pipeline -- the reference's own common/transforms.py functions ----------------------
+    tv = types.ModuleType('torchvision')
+    tvt = types.ModuleType('torchvision.transforms')
+    for nm in ('RandomCrop', 'RandomResizedCrop', 'ColorJitter', 'ToPILImage', 'ToTensor'):
+        setattr(tvt, nm, type(nm, (), {}))                   # class-level stand-ins: only the functional forms are exercised
+    tv.transforms = tvt
+    sys.modules.setdefault('torchvision', tv)
+    sys.modules.setdefault('torchvision.transforms', tvt)
+    import common.transforms as RT
+    g = torch.Generator().manual_seed(17)
+    B, T, H, W, CROP = 3, 2, 72, 128, 48
+    clips = torch.randint(0, 256, (B, T, H, W, 3), generator=g, dtype=torch.uint8)
+    draws = [dict(target=56, flip=0, crop=(3, 17), reverse=False, scale=1.0), dict(target=61, flip=1, crop=(13, 0), reverse=False, scale=1.0),
+             dict(target=50, flip=1, crop=(2, 40), reverse=True, scale=255.0)]
+    mean, std = (0.5, 0.45, 0.4), (0.5, 0.25, 0.2)
+    outs, params = [], []
+    for b, d in enumerate(draws):
+        x = RT.to_tensor(clips[b])
+        x = RT.resize(x, d['target'], 'bilinear')
+        nh, nw = x.shape[-2:]
+        assert (nh, nw) == O.resize_shape(H, W, d['target'])
+        if d['flip']:
+            x = RT.hflip(x)
+        x = x * d['scale']
+        if d['reverse']:
+            x = x[[2, 1, 0], ...]
+        x = RT.normalize(x, mean, std)
+        x = RT.crop(x, d['crop'][0], d['crop'][1], CROP, CROP)
+        outs.append(x)
+        mine = O.video_preproc(clips[b], (nh, nw), d['flip'], d['crop'], (CROP, CROP), d['scale'], mean, std, d['reverse'])
+        dd = float((mine - x).abs().max())
+        report.append(f'G9 clip {b}: restatement vs reference transforms max|d|={dd:.3e}')
+        assert dd < 1e-6
+        params.append([nh, nw, d['flip'], d['crop'][0], d['crop'][1], int(d['reverse']), d['scale']])
+    np.savez_compressed(os.path.join(OUT, 'g9_preproc.npz'), clips=clips.numpy(), params=np.asarray(params, dtype=np.float64),
+                        mean=np.asarray(mean), std=np.asarray(std), out=torch.stack(outs).numpy())
 
     with open(os.path.join(OUT, 'REPORT_r2.txt'), 'w') as f:
         f.write('Golden generation report (oracle/make_golden_r2.py), torch %s transformers %s\n' %

@@ -260,3 +260,22 @@ def test_init_model_partial_nonstrict_load(tmp_path):
     for k, v in src.backbone.model.state_dict().items():
         assert torch.equal(dst2.backbone.model.state_dict()[k], v), k
     assert not torch.equal(dst2.future_predictor.encoder.weight, src.future_predictor.encoder.weight)
+
+
+def test_gpu_clip_transform_draws_follow_the_reference_rules():
+    """Host side of the GPU input pipeline: size / flip / crop draws (no GPU needed)."""
+    import random
+    from avt_amd.common.gpu_transforms import GpuClipTransform
+    from oracle.avt_oracle import resize_shape
+    random.seed(0); torch.manual_seed(0)
+    tr = GpuClipTransform('248-280', -1, 224, train=True)
+    seen_flip = set()
+    for _ in range(50):
+        nh, nw, flip, i, j = tr.draw(256, 456)
+        assert 248 <= nh <= 280 and (nh, nw) == resize_shape(256, 456, nh) and 0 <= i <= nh - 224 and 0 <= j <= nw - 224
+        seen_flip.add(flip)
+    assert seen_flip == {0, 1}
+    ev = GpuClipTransform(248, -1, 224, train=False)
+    assert ev.draw(256, 456) == (248, 441, 0, 12, 108)          # centre crop: round((248-224)/2), round((441-224)/2)
+    with pytest.raises(NotImplementedError):
+        GpuClipTransform(248, color_jitter_hue=0.1)

@@ -537,3 +537,28 @@ def test_checkpoint_round_trip_with_the_reference_format(tmp_path):
     for i in s1:
         if float(s1[i]['momentum_buffer'].abs().max()) > 1e-6:
             assert rel(s2[i]['momentum_buffer'], s1[i]['momentum_buffer']) < 5e-2, i
+
+
+def test_weight_gradients_are_bit_reproducible():
+    """Two identical steps give bit-identical gradients for every weight MATRIX (split-K partial slabs reduced in a fixed order,
+    avt_gemm_accum_bf16; all activation gradients are atomics-free).  Bias / LayerNorm-affine / embedding gradients are column
+    sums accumulated with fp32 atomics across row blocks: equal to rounding, not bitwise."""
+    torch.manual_seed(0)
+    model = build_hip_model('vit', 192, 128, 2, 4, 50, vit=(192, 3, 3, 48))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(3)
+    video = (torch.rand((6, 5, 3, 1, 48, 48), generator=g) * 2 - 1).cuda()
+    target, sub = torch.randint(0, 50, (6,), generator=g).cuda(), torch.randint(-1, 50, (6, 5, 1), generator=g).cuda()
+    grads = []
+    for _ in range(3):
+        hip_step(model, video, target, sub)
+        grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    mats = [n for n, p in model.named_parameters() if p.ndim >= 2 and not n.endswith(('pos_embed', 'cls_token', 'wpe.weight'))]
+    assert len(mats) > 30
+    for n in mats:
+        assert torch.equal(grads[0][n], grads[1][n]) and torch.equal(grads[0][n], grads[2][n]), n
+    for n in grads[0]:
+        assert rel(grads[1][n], grads[0][n]) < 1e-4, n

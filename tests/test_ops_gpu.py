@@ -483,3 +483,33 @@ def test_deterministic_wgrad_accumulate(ops, M, P, Q):
         ops.linear_wgrad(dy, x, dw3, rows=P - 17)
         torch.cuda.synchronize()
         assert relerr(dw3[:P - 17] - base[:P - 17], ref[:P - 17]) < 2e-3 and torch.equal(dw3[P - 17:], base[P - 17:])      # rows past the limit untouched
+
+
+def test_video_preproc_vs_reference_golden_and_oracle(ops, golden_dir):
+    """Fused uint8 -> resize -> flip -> scale -> normalise -> crop kernel against (a) the golden produced by the
+    reference's own transform functions and (b) the oracle at the training geometry (456x256 frames -> 248..280 -> 224 crop).
+    fp32 in and out: tolerance 2e-5 of the output range (the bilinear weights are evaluated in a different association order)."""
+    import os
+    import numpy as np
+    from avt_amd import ops
+    from avt_amd.common.gpu_transforms import GpuClipTransform
+    from oracle import avt_oracle as O
+    z = np.load(os.path.join(golden_dir, 'g9_preproc.npz'))
+    clips, want = torch.from_numpy(z['clips']).cuda(), torch.from_numpy(z['out'])
+    for b, p in enumerate(z['params']):
+        prm = torch.tensor([[int(p[0]), int(p[1]), int(p[2]), int(p[3]), int(p[4])]], dtype=torch.int32).cuda()
+        got = ops.video_preproc(clips[b:b + 1], prm, tuple(want.shape[-2:]), float(p[6]), tuple(z['mean']), tuple(z['std']), bool(p[5]))
+        torch.cuda.synchronize()
+        got = got[0, :, :, 0].permute(1, 0, 2, 3).cpu()                       # (T,3,h,w) -> (3,T,h,w)
+        assert float((got - want[b]).abs().max()) < 2e-5 * max(float(want[b].abs().max()), 1.0), b
+    g = torch.Generator().manual_seed(3)
+    B, T, H, W = 3, 4, 256, 456
+    u8 = torch.randint(0, 256, (B, T, H, W, 3), generator=g, dtype=torch.uint8)
+    tr = GpuClipTransform('248-280', -1, 224, train=True)
+    params = [(248, 441, 0, 0, 0), (280, 498, 1, 56, 274), (263, 468, 1, 17, 100)]
+    out = tr(u8.cuda(), params=params)
+    torch.cuda.synchronize()
+    assert out.shape == (B, T, 3, 1, 224, 224)
+    for b, (nh, nw, fl, ci, cj) in enumerate(params):
+        ref = O.video_preproc(u8[b], (nh, nw), fl, (ci, cj), (224, 224))
+        assert float((out[b, :, :, 0].permute(1, 0, 2, 3).cpu() - ref).abs().max()) < 2e-5, b

@@ -192,3 +192,13 @@ def test_causality_of_the_head():
         a, _ = orc(v, target_shape=(1,)); b, _ = orc(v2, target_shape=(1,))
     assert float((a['past'] - b['past']).abs().max()) == 0.0
     assert float((a['future'] - b['future']).abs().max()) > 0
+
+
+def test_g9_input_pipeline(golden_dir):
+    """the oracle's restatement of the transform chain vs the reference's own common/transforms.py functions."""
+    z = np.load(os.path.join(golden_dir, 'g9_preproc.npz'))
+    clips, out = torch.from_numpy(z['clips']), torch.from_numpy(z['out'])
+    for b, p in enumerate(z['params']):
+        nh, nw, flip, ci, cj, rev, scale = int(p[0]), int(p[1]), int(p[2]), int(p[3]), int(p[4]), bool(p[5]), float(p[6])
+        got = O.video_preproc(clips[b], (nh, nw), flip, (ci, cj), out.shape[-2:], scale, tuple(z['mean']), tuple(z['std']), rev)
+        assert rel(got, out[b]) < 1e-6, b
