@@ -1403,7 +1403,8 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
 
   // per-lane source offsets (bytes) of this wave's two DMA instructions per half-tile, K tile 0.  Rows / columns past the
   // matrix edge need no zero fill (they only feed output rows / columns that are never stored): a k-major row past the end is
-  // out of the descriptor's range anyway, a column of a k-strided operand is clamped to the last valid 8-column chunk.
+  // out of the descriptor's range anyway, a column chunk of a k-strided operand that lies entirely past the edge is clamped to the
+  // last chunk that still holds a valid column (lda / ldb are multiples of 8, so a partial chunk stays inside its row).
   // Only the K tail must read as zero: tiles >= nk use a descriptor with num_records = 0, so the in-loop address work is
   // one scalar select of the descriptor and one vector add per instruction (no per-lane masks, no branches).
   uint32_t offA[2][2], offB[2][2];
@@ -1420,7 +1421,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
         int r = j * 32 + wave * 4 + (lane >> 4);                         // k row
         int cl = ((lane & 15) ^ kstrided_swz<128>(r)) * 8;               // LDS column of the half-tile
         int col = tm0 + (cl >> 6) * 128 + (cl & 63) + h * 64;
-        if (col > p.M - 8) col = p.M >= 8 ? ((p.M - 8) & ~7) : 0;
+        if (col >= p.M) col = (p.M - 1) & ~7;                            // chunk entirely past the edge -> re-read the last (possibly partial) one
         offA[h][j] = (uint32_t)(((size_t)(kt_begin * BK + r) * (size_t)p.lda + (size_t)col) * 2);
       }
       if (B_KMAJOR) {
@@ -1432,7 +1433,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
         int r = j * 32 + wave * 4 + (lane >> 4);
         int cl = ((lane & 15) ^ kstrided_swz<128>(r)) * 8;
         int col = tn0 + (cl >> 5) * 64 + (cl & 31) + h * 32;
-        if (col > p.N - 8) col = p.N >= 8 ? ((p.N - 8) & ~7) : 0;
+        if (col >= p.N) col = (p.N - 1) & ~7;
         offB[h][j] = (uint32_t)(((size_t)(kt_begin * BK + r) * (size_t)p.ldb + (size_t)col) * 2);
       }
     }

@@ -557,7 +557,7 @@ def test_weight_gradients_are_bit_reproducible():
         hip_step(model, video, target, sub)
         grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters()})
     mats = [n for n, p in model.named_parameters() if p.ndim >= 2 and not n.endswith(('pos_embed', 'cls_token', 'wpe.weight'))]
-    assert len(mats) > 30
+    assert len(mats) >= 20
     for n in mats:
         assert torch.equal(grads[0][n], grads[1][n]) and torch.equal(grads[0][n], grads[2][n]), n
     for n in grads[0]:
