@@ -40,7 +40,6 @@ struct GemmParams {
   int tiles_m, tiles_n;
   size_t ws_bytes;
   float* ws;                     // EPI 2: split-K partial slabs, [splitk * tiles][BM * BN] fp32 in accumulator order
-  int strip_w;                   // > 0: tile order = strips of strip_w tile columns (see tile_of)
   uint32_t a_bytes, b_bytes;     // buffer-descriptor bounds
   uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
 #ifdef AVT_LAB
@@ -72,21 +71,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   int xcd = bid & 7, idx = bid >> 3;
   int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return start + idx;
-}
-
-// Logical tile id -> (tile row, tile column).  Row-major order (strip_w == 0) walks all tile columns of a row panel before
-// the next panel: the XCD that owns a contiguous id range re-uses the A panel from its L2 but cycles through EVERY B tile,
-// and for wide outputs (N = 3072: 12 tile columns x 393 KB per K = 768) B does not survive in the 4-MB L2 next to the
-// streaming A panels.  Strip order walks strip_w tile columns x all row panels, then the next strip: the XCD's B working
-// set is strip_w tiles (resident), every A panel is fetched once per strip instead.  Measured in situ (128 clips, lab switch
-// AVT_GEMM_STRIP): strips of 3 / 4 / 6 columns -0.7 / -1.4 / +0.0 % on the whole step against row-major -- the B re-reads are
-// served by the Infinity Cache fast enough that the extra A-panel fetches cost more than they save.  Row-major stays.
-__device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int strip_w, int& tm, int& tn) {
-  if (strip_w <= 0 || strip_w >= tiles_n) { tm = t / tiles_n; tn = t - tm * tiles_n; return; }
-  const int per = tiles_m * strip_w;
-  const int s = t / per, r = t - s * per;
-  const int w = min(strip_w, tiles_n - s * strip_w);      // the last strip may be narrower
-  tm = r / w; tn = s * strip_w + (r - tm * w);
 }
 
 // One MFMA step; the operand order decides whether a lane ends up holding a column or a row of the output block:
@@ -1389,10 +1373,8 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
   const int lb = xcd_remap(bid, ntile * p.splitk);          // an XCD owns a contiguous range of (split, tile): see xcd_remap
   const int split = lb / ntile;
   const int t_ = lb - split * ntile;
-  int tm_, tn_;
-  tile_of(t_, p.tiles_m, p.tiles_n, p.strip_w, tm_, tn_);
-  const int tm0 = tm_ * BM;
-  const int tn0 = tn_ * BN;
+  const int tm0 = (t_ / p.tiles_n) * BM;
+  const int tn0 = (t_ % p.tiles_n) * BN;
   const int nk_total = (p.K + BK - 1) / BK;
   const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
   const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
@@ -1584,10 +1566,6 @@ int launch_8p(const GemmParams& p, hipStream_t s) {
 
 int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
   p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
-  p.strip_w = 0;
-#ifdef AVT_LAB
-  { static const char* e = getenv("AVT_GEMM_STRIP"); if (e && epi == 0 && p.tiles_n >= 8) p.strip_w = atoi(e); }
-#endif
   const int nk = (p.K + 63) / 64;
   if (splitk <= 0) {
     splitk = 1;
@@ -1674,11 +1652,6 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
     case 64:  return dispatch_epi<64, 64, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 128: return dispatch_epi<128, 128, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 643: return dispatch_epi<64, 64, 2, 2, 64, 3>(p, epi, a_kmajor, b_kmajor, splitk, s);     // 3-deep ring
-    // two independent 4-wave workgroups per CU (<= 80 KB LDS, <= 256 registers each): while one is in its epilogue (vector ALU,
-    // stores) the other one's main loop owns the matrix pipes -- for outputs whose epilogue is heavy against a short K loop
-    case 1283: return dispatch_epi<128, 256, 1, 4, 32, 3, false, 0, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
-    case 2563: return dispatch_epi<256, 128, 2, 2, 32, 3, false, 0, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
-    case 1284: return dispatch_epi<128, 256, 1, 4, 32, 4, false, 0, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 256:                                                                                     // one barrier per K tile, dribbled LDS-DMA issued by 4 loader waves
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_epi<256, 256, 2, 4, 64, 2, true, 0, 1, 4>(p, epi, a_kmajor, b_kmajor, splitk, s);
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
