@@ -164,7 +164,7 @@ def main(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=128, help='clips per GPU (weak scaling: fixed per GPU)')
+    ap.add_argument('--batch', type=int, default=256, help='clips per GPU (weak scaling: fixed per GPU; 256 clips = 2560 frames keep ~150 GB of activations resident)')
     ap.add_argument('--frames', type=int, default=10)
     ap.add_argument('--model', default='vit_base_patch16_224', choices=list(VIT))
     ap.add_argument('--bucket-mb', type=int, default=64)
