@@ -475,7 +475,7 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
   float cs[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) cs[k] = 0.f;
-#pragma unroll 1
+#pragma unroll (ACT == 0 || ACT == 3 ? 4 : 1)
   for (int i = 0; i < TM; ++i) {
     EpiBlk<TN> b;
     switch (i) {

@@ -67,6 +67,14 @@ if 'gemm' in want:
     fl = 2.0 * M * D * 3072
     timeit('fc1 fwd +bias+gelu+gelu\'', lambda: ops.linear_fwd(x, w1, bias=bias3, act=ops.ACT_GELU_ERF, c2=pre, out=act), flops=fl)
     timeit('fc1 fwd plain', lambda: ops.linear_fwd(x, w1, out=act), flops=fl)
+    if 'epi' in want:
+        timeit('  fc2 dgrad plain', lambda: ops.linear_dgrad(x, w2, out=act), flops=fl)
+        timeit('  fc2 dgrad x aux', lambda: ops.linear_dgrad(x, w2, act=ops.ACT_MUL_AUX, aux=pre, out=act), flops=fl)
+        timeit('  fc2 dgrad +colsum', lambda: ops.linear_dgrad(x, w2, colsum=cs3, out=act), flops=fl)
+        timeit('  fc2 dgrad +res', lambda: ops.linear_dgrad(x, w2, res=pre, out=act), flops=fl)
+        timeit('  fc1 fwd +bias', lambda: ops.linear_fwd(x, w1, bias=bias3, out=act), flops=fl)
+        timeit('  fc1 fwd +bias+gelu (no c2)', lambda: ops.linear_fwd(x, w1, bias=bias3, act=ops.ACT_GELU_ERF, out=act), flops=fl)
+        timeit('  fc1 fwd +c2 only', lambda: ops.linear_fwd(x, w1, c2=pre, out=act), flops=fl)
     timeit('fc2 dgrad x aux +colsum', lambda: ops.linear_dgrad(x, w2, act=ops.ACT_MUL_AUX, aux=pre, colsum=cs3, out=act), flops=fl)
     y = torch.empty((M, D), device='cuda', dtype=torch.bfloat16)
     timeit('fc2 fwd +bias+res', lambda: ops.linear_fwd(act, w2, bias=bias1, res=x, out=y), flops=fl)
