@@ -116,7 +116,7 @@ def gemm_accum(A, B, C, M, N, K):
     _lib.call('avt_gemm_accum_bf16', _p(A), _ld(A), _p(B), _ld(B), _p(C), _ld(C), M, N, K, 0, 0, _p(ws), ws.numel(), _stream())
     if trace is not None:
         ev1.record()
-        trace.append((gemm_variant(M, N, K, False, False, OUT_ACCUM_F32, 0), 2.0 * M * N * K, ev0, ev1))
+        trace.append((gemm_variant(M, N, K, False, False, OUT_ACCUM_F32, 0).replace(',1>', ',2>'), 2.0 * M * N * K, ev0, ev1))   # EPI 2 = slabs + ordered reduce
     return C
 
 
