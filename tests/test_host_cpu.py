@@ -169,6 +169,22 @@ for step in range(2):
 # no hook fired at all -> finish() still reduces everything
 red.start_step(); arena.grad.copy_(g_local); red.finish()
 assert torch.allclose(arena.grad, expect, atol=1e-5)
+# a module that ran forward twice this step (multi-crop clips: one fused node per crop, models/base_model.py:251-273): its
+# range may only be handed to the collective after the SECOND backward, which keeps accumulating into it
+red.start_step()
+model.segs[2]._fwd_calls = 2
+arena.grad.zero_()
+arena.grad[arena.offsets[3]:].add_(g_local[arena.offsets[3]:] * 0.25)         # first crop's contribution
+model.segs[2].grad_ready_hook(arena.params[3], arena.params[4])
+assert red._lo == arena.total, 'range released after the first of two backwards'
+arena.grad[arena.offsets[3]:].add_(g_local[arena.offsets[3]:] * 0.75)         # second crop
+model.segs[2].grad_ready_hook(arena.params[3], arena.params[4])
+assert red._lo == arena.offsets[3]
+arena.grad[:arena.offsets[3]].copy_(g_local[:arena.offsets[3]])
+model.segs[1].grad_ready_hook(arena.params[1], arena.params[2])
+model.segs[0].grad_ready_hook(arena.params[0], arena.params[0])
+red.finish()
+assert torch.allclose(arena.grad, expect, atol=1e-4), float((arena.grad - expect).abs().max())
 dist.barrier(); dist.destroy_process_group()
 print('OK', rank)
 '''
