@@ -182,6 +182,21 @@ __global__ __launch_bounds__(256) void pad_cast_kernel(const float* __restrict__
     dst[i] = c < cols ? f2bf(src[(size_t)r * lds + c]) : (bf16_t)0;
   }
 }
+// ReLU with its derivative mask (torch.nn.TransformerEncoderLayer's activation, models/temporal_aggregation.py:87): y = max(x, 0),
+// mask = x > 0 ? 1 : 0 (bf16), so that backward is the GEMM epilogue's "multiply by the saved derivative" (act 3)
+__global__ __launch_bounds__(256) void relu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, bf16_t* __restrict__ mask, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    u32x4_t w = *(const u32x4_t*)(x + i * 8), o, m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = bflo(w[e]), b = bfhi(w[e]);
+      o[e] = pack2bf(fmaxf(a, 0.f), fmaxf(b, 0.f));
+      m[e] = pack2bf(a > 0.f ? 1.f : 0.f, b > 0.f ? 1.f : 0.f);
+    }
+    *(u32x4_t*)(y + i * 8) = o;
+    *(u32x4_t*)(mask + i * 8) = m;
+  }
+}
 // dst[r, :] += src[r, :] for strided bf16 rows (the CLS rows of a [frames*S, D] tensor: ldd = S*D)
 __global__ __launch_bounds__(256) void add_rows_kernel(bf16_t* __restrict__ dst, long ldd, const bf16_t* __restrict__ src, long lds,
                                                        int rows, int D) {
@@ -300,6 +315,13 @@ extern "C" int avt_add_rows_bf16(void* dst, long ldd, const void* src, long lds,
   AVT_CHECK(D % 8 == 0 && ldd % 8 == 0 && lds % 8 == 0 && aligned16(dst) && aligned16(src), "avt_add_rows_bf16: D and strides must be multiples of 8, pointers 16-byte aligned");
   long n = (long)rows * (D / 8);
   hipLaunchKernelGGL(add_rows_kernel, dim3(GRID_FOR(n, 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst, ldd, (const bf16_t*)src, lds, rows, D);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_relu_bf16(const void* x, void* y, void* mask, long n, void* stream) {
+  AVT_CHECK(x && y && mask && n > 0 && n % 8 == 0, "avt_relu_bf16: n must be a positive multiple of 8");
+  AVT_CHECK(aligned16(x) && aligned16(y) && aligned16(mask), "avt_relu_bf16: 16-byte alignment required");
+  hipLaunchKernelGGL(relu_kernel, dim3(GRID_FOR(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (bf16_t*)mask, n / 8);
   AVT_LAUNCH_CHECK();
   return 0;
 }

@@ -227,18 +227,27 @@ def causal_attn_decode(qkv, kcache, vcache, B, H, hd, pos):
     return out
 
 
-def causal_attn_fwd(qkv, B, T, H, hd, drop_p=0.0, seed=0):
+def causal_attn_fwd(qkv, B, T, H, hd, drop_p=0.0, seed=0, causal=True):
     _chk(qkv, BF16, 'qkv')
     out = torch.empty((B * T, H * hd), device=qkv.device, dtype=BF16)
     probs = torch.empty((B, H, T, T), device=qkv.device, dtype=torch.float32)
-    _lib.call('avt_causal_attn_fwd', _p(qkv), _p(out), _p(probs), B, T, H, hd, float(hd) ** -0.5, float(drop_p), int(seed), _stream())
+    _lib.call('avt_head_attn_fwd', _p(qkv), _p(out), _p(probs), B, T, H, hd, float(hd) ** -0.5, float(drop_p), int(seed), int(causal), _stream())
     return out, probs
 
 
-def causal_attn_bwd(qkv, probs, dout, B, T, H, hd, drop_p=0.0, seed=0):
+def causal_attn_bwd(qkv, probs, dout, B, T, H, hd, drop_p=0.0, seed=0, causal=True):
     dqkv = torch.empty_like(qkv)
-    _lib.call('avt_causal_attn_bwd', _p(qkv), _p(probs), _p(dout), _p(dqkv), B, T, H, hd, float(hd) ** -0.5, float(drop_p), int(seed), _stream())
+    _lib.call('avt_head_attn_bwd', _p(qkv), _p(probs), _p(dout), _p(dqkv), B, T, H, hd, float(hd) ** -0.5, float(drop_p), int(seed), int(causal), _stream())
     return dqkv
+
+
+def relu(x):
+    """(max(x, 0), mask) with mask = bf16 1/0 = the derivative, consumed by gemm(act=ACT_MUL_AUX) in backward."""
+    _chk(x, BF16, 'x')
+    assert x.is_contiguous() and x.numel() % 8 == 0
+    y, mask = torch.empty_like(x), torch.empty_like(x)
+    _lib.call('avt_relu_bf16', _p(x), _p(y), _p(mask), x.numel(), _stream())
+    return y, mask
 
 
 # ---- patch embedding helpers ---------------------------------------------------------------------------------------------

@@ -108,6 +108,12 @@ int avt_causal_attn_fwd(const void* qkv, void* out, float* probs, int B, int T, 
                         float drop_p, uint64_t seed, void* stream);
 int avt_causal_attn_bwd(const void* qkv, const float* probs, const void* dout, void* dqkv, int B, int T, int H,
                         int head_dim, float scale, float drop_p, uint64_t seed, void* stream);
+/* The same kernels with the mask as an argument: causal = 0 is torch.nn.MultiheadAttention inside the TransformerEncoder
+ * aggregator (models/temporal_aggregation.py:86-90): every query sees all T keys. */
+int avt_head_attn_fwd(const void* qkv, void* out, float* probs, int B, int T, int H, int head_dim, float scale,
+                      float drop_p, uint64_t seed, int causal, void* stream);
+int avt_head_attn_bwd(const void* qkv, const float* probs, const void* dout, void* dqkv, int B, int T, int H,
+                      int head_dim, float scale, float drop_p, uint64_t seed, int causal, void* stream);
 
 /* ---- patch embedding helpers ([timm] PatchEmbed + cls_token/pos_embed, via models/video_classification.py:213-227) --
  * avt_im2col_patch16: video fp32 [N,3,H,W] -> bf16 rows [N*(P+1), 768], row n*(P+1) (CLS slot) zero, k = c*256+ky*16+kx.
@@ -136,6 +142,8 @@ int avt_mse_shift_bwd(const float* dec, const float* x, const float* gloss, floa
                       void* stream);
 int avt_pad_cast_f32_to_bf16(const float* src, int lds, void* dst, int ldd, int rows, int cols, void* stream);
 int avt_add_rows_bf16(void* dst, long ldd, const void* src, long lds, int rows, int D, void* stream);
+/* ReLU + derivative mask (bf16 0/1) -- nn.TransformerEncoderLayer's activation (models/temporal_aggregation.py:87). */
+int avt_relu_bf16(const void* x, void* y, void* mask, long n, void* stream);
 
 /* ---- GPU input pipeline ----------------------------------------------------------------------------------
  * The reference's per-clip CPU transform chain (func/train.py:550-569; common/transforms.py:60-91 resize, :124-146 to_tensor,

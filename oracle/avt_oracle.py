@@ -366,6 +366,52 @@ def total_loss(losses, loss_wts):
 
 
 # --------------------------------------------------------------------------------------------------
+# Transformer-encoder temporal aggregator (models/temporal_aggregation.py:50-147; cloze loss off)
+# --------------------------------------------------------------------------------------------------
+class _OraclePosEnc(nn.Module):
+    def __init__(self, d_model, max_len=1000):
+        super().__init__()
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)                             # :61
+        pe[:, 1::2] = torch.cos(position * div_term)                             # :62
+        self.register_buffer('pe', pe.unsqueeze(0).transpose(0, 1))              # (max_len, 1, d)
+
+
+class OracleTransformerAgg(nn.Module):
+    """Post-norm encoder layers written out (torch.nn.TransformerEncoderLayer: x = LN1(x + SA(x)); x = LN2(x + W2 relu(W1 x)),
+    dim_feedforward 2048, eps 1e-5; dropout is identity here -- parity runs are dropout-free) with torch's parameter names."""
+    def __init__(self, in_features, inter_rep=512, nheads=8, nlayers=6, agg_style='mean'):
+        super().__init__()
+        self.nheads, self.agg_style, self.inter_rep = nheads, agg_style, inter_rep
+        self.downproject = nn.Linear(in_features, inter_rep)                     # :84
+        self.pos_encoder = _OraclePosEnc(inter_rep)                              # :87
+        layer = nn.TransformerEncoderLayer(d_model=inter_rep, nhead=nheads)      # :85 (parameter container only)
+        self.transformer_encoder = nn.TransformerEncoder(layer, num_layers=nlayers, norm=nn.LayerNorm(inter_rep), enable_nested_tensor=False)
+
+    @property
+    def output_dim(self):
+        return self.inter_rep
+
+    def forward(self, feats):
+        b, t, _ = feats.shape
+        e, h = self.inter_rep, self.nheads
+        x = self.downproject(feats) + self.pos_encoder.pe[:t, 0][None]           # :121 (B, T, E)
+        for lay in self.transformer_encoder.layers:
+            a = lay.self_attn
+            q, k, v = F.linear(x, a.in_proj_weight, a.in_proj_bias).split(e, dim=-1)
+            q = q.view(b, t, h, e // h).transpose(1, 2) * (e // h) ** -0.5
+            k = k.view(b, t, h, e // h).transpose(1, 2)
+            v = v.view(b, t, h, e // h).transpose(1, 2)
+            att = (q @ k.transpose(-1, -2)).softmax(-1) @ v
+            x = lay.norm1(x + a.out_proj(att.transpose(1, 2).reshape(b, t, e)))
+            x = lay.norm2(x + lay.linear2(F.relu(lay.linear1(x))))
+        x = self.transformer_encoder.norm(x)
+        return (x.mean(dim=1) if self.agg_style == 'mean' else x[:, -1]), {}     # :138-141
+
+
+# --------------------------------------------------------------------------------------------------
 # Input pipeline (func/train.py:550-569 transform list; common/transforms.py functional forms)
 # --------------------------------------------------------------------------------------------------
 def resize_shape(clip_h, clip_w, target):

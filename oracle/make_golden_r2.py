@@ -13,6 +13,7 @@ runs only in the build container (needs /root/reference + HF transformers), comm
   G7   BASELINE config 5's backbone: full-depth ViT-L/16 (D=1024, L=24, H=16) CLS features on 1 frame from HF ViTModel.
   G9   input pipeline: the reference's own common/transforms.py functions (to_tensor, resize, hflip, normalize, crop)
        on random uint8 clips with explicit draws -- pins the fused GPU preprocessing kernel.
+  G10  the Transformer-encoder temporal aggregator (models/temporal_aggregation.py:73-147), eval mode, fwd + grads.
   G8   other head shapes sharing the kernels (expts/13_50s_avt.txt:16-17 and expts/04*): n_head=2/n_layer=8 and
        n_head=8/n_layer=8 tiny heads, one training step each.
 """
@@ -211,6 +212,35 @@ def main():
         params.append([nh, nw, d['flip'], d['crop'][0], d['crop'][1], int(d['reverse']), d['scale']])
     np.savez_compressed(os.path.join(OUT, 'g9_preproc.npz'), clips=clips.numpy(), params=np.asarray(params, dtype=np.float64),
                         mean=np.asarray(mean), std=np.asarray(std), out=torch.stack(outs).numpy())
+
+    # ---------------- G10: Transformer-encoder temporal aggregator (reference module, eval mode = dropout off) ---------
+    import models.temporal_aggregation as ref_ta
+    IN, E, NH, NL, T, B = 32, 64, 4, 2, 6, 3
+    ref = ref_ta.Transformer(IN, inter_rep=E, nheads=NH, nlayers=NL)
+    O.closed_form_fill_([(n, p) for n, p in ref.named_parameters()])
+    ref.eval()
+    g = torch.Generator().manual_seed(18)
+    feats = (torch.rand((B, T, IN), generator=g) * 2 - 1).requires_grad_()
+    wout = torch.rand((B, E), generator=g) * 2 - 1
+    agg, _ = ref(feats)
+    (agg * wout).sum().backward()
+    orc = O.OracleTransformerAgg(IN, inter_rep=E, nheads=NH, nlayers=NL)
+    orc.load_state_dict(ref.state_dict())
+    orc.eval()
+    f2 = feats.detach().clone().requires_grad_()
+    o_agg, _ = orc(f2)
+    (o_agg * wout).sum().backward()
+    d = float((o_agg - agg).abs().max())
+    dg = float((f2.grad - feats.grad).abs().max() / feats.grad.abs().max())
+    report.append(f'G10 Transformer aggregator: restatement vs reference max|d|={d:.3e} rel dgrad(input)={dg:.3e}')
+    assert d < 1e-5 and dg < 1e-4, report[-1]
+    keep = {'in/feats': feats.detach(), 'in/wout': wout, 'out/agg': agg.detach(), 'grad/feats': feats.grad.detach()}
+    for n in ['downproject.weight', 'downproject.bias', 'transformer_encoder.layers.0.self_attn.in_proj_weight',
+              'transformer_encoder.layers.0.self_attn.in_proj_bias', 'transformer_encoder.layers.1.self_attn.out_proj.weight',
+              'transformer_encoder.layers.1.linear1.weight', 'transformer_encoder.layers.0.linear2.bias',
+              'transformer_encoder.layers.0.norm1.weight', 'transformer_encoder.norm.bias']:
+        keep[f'grad/{n}'] = dict(ref.named_parameters())[n].grad.detach().clone()
+    np.savez_compressed(os.path.join(OUT, 'g10_transformer_agg.npz'), **G.to_np(keep))
 
     with open(os.path.join(OUT, 'REPORT_r2.txt'), 'w') as f:
         f.write('Golden generation report (oracle/make_golden_r2.py), torch %s transformers %s\n' %

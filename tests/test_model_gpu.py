@@ -562,3 +562,35 @@ def test_weight_gradients_are_bit_reproducible():
         assert torch.equal(grads[0][n], grads[1][n]) and torch.equal(grads[0][n], grads[2][n]), n
     for n in grads[0]:
         assert rel(grads[1][n], grads[0][n]) < 1e-4, n
+
+
+def test_g10_transformer_aggregator_vs_reference_golden(golden_dir):
+    """``temporal_aggregation.Transformer`` (nn.TransformerEncoder aggregator, reference :73-147) on the head's
+    kernels -- non-causal attention, ReLU + saved mask, post-norm LayerNorms -- forward and every stored gradient, eval mode."""
+    from avt_amd.models.temporal_aggregation import Mean, Transformer
+    g = load_golden(os.path.join(golden_dir, 'g10_transformer_agg.npz'))
+    m = Transformer(32, inter_rep=64, nheads=4, nlayers=2).cuda()
+    _fill(m)
+    m.eval()
+    feats = g['in/feats'].cuda().requires_grad_()
+    agg, aux = m(feats)
+    (agg * g['in/wout'].cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert aux == {} and m.output_dim == 64
+    assert rel(agg, g['out/agg']) < TOL_OUT, rel(agg, g['out/agg'])
+    assert rel(feats.grad, g['grad/feats']) < TOL_GRAD, rel(feats.grad, g['grad/feats'])
+    params = dict(m.named_parameters())
+    # parameter gradients: 1e-1 of max-abs -- ReLU is not smooth: a hidden unit whose pre-activation lies within bf16 rounding of
+    # zero switches one token's whole contribution on or off, and with 18 tokens per unit one flip moves a row by several per cent
+    from helpers import cosine
+    for k in [k for k in g if k.startswith('grad/') and k != 'grad/feats']:
+        assert rel(params[k[5:]].grad, g[k]) < 1e-1 and cosine(params[k[5:]].grad, g[k]) > 0.995, (k, rel(params[k[5:]].grad, g[k]))
+    # train mode (dropout 0.1 on): runs, differs from eval, finite gradients
+    m.train()
+    m.zero_grad()
+    a2, _ = m(feats.detach())
+    a2.sum().backward()
+    torch.cuda.synchronize()
+    assert rel(a2, agg) > 1e-3 and all(torch.isfinite(p.grad).all() for p in m.parameters())
+    mean, _ = Mean(32)(feats.detach())
+    assert torch.equal(mean, feats.detach().mean(1))

@@ -202,3 +202,18 @@ def test_g9_input_pipeline(golden_dir):
         nh, nw, flip, ci, cj, rev, scale = int(p[0]), int(p[1]), int(p[2]), int(p[3]), int(p[4]), bool(p[5]), float(p[6])
         got = O.video_preproc(clips[b], (nh, nw), flip, (ci, cj), out.shape[-2:], scale, tuple(z['mean']), tuple(z['std']), rev)
         assert rel(got, out[b]) < 1e-6, b
+
+
+def test_g10_transformer_aggregator(golden_dir):
+    """the Transformer-encoder temporal aggregator, oracle vs the reference module (eval mode, fwd + grads)."""
+    g = load_golden(os.path.join(golden_dir, 'g10_transformer_agg.npz'))
+    orc = O.OracleTransformerAgg(32, inter_rep=64, nheads=4, nlayers=2)
+    O.closed_form_fill_(list(orc.named_parameters()))
+    orc.eval()
+    feats = g['in/feats'].clone().requires_grad_()
+    agg, aux = orc(feats)
+    (agg * g['in/wout']).sum().backward()
+    assert aux == {} and rel(agg, g['out/agg']) < 1e-5 and rel(feats.grad, g['grad/feats']) < 1e-4
+    params = dict(orc.named_parameters())
+    for k in [k for k in g if k.startswith('grad/') and k != 'grad/feats']:
+        assert rel(params[k[5:]].grad, g[k]) < 1e-4, k
