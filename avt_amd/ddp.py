@@ -18,12 +18,19 @@ from .arena import ParamArena
 
 
 class GradReducer:
-    def __init__(self, model, bucket_bytes=64 << 20, process_group=None, overlap=True, always=False):
+    def __init__(self, model, bucket_bytes=64 << 20, process_group=None, overlap=True, always=False, mode='all_reduce'):
         self.model = model
         self.arena: ParamArena = model.arena
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.group = process_group
-        self.bucket_elems = max(bucket_bytes // 4, 1)
+        # 'all_reduce': one RCCL all-reduce per bucket (RCCL picks ring / tree / direct for the xGMI mesh itself).
+        # 'rs_ag': the same sum as an explicit reduce-scatter + all-gather pair per bucket (SURVEY 8e's full-mesh form: every
+        # rank reduces 1/world of the bucket, then the shards are exchanged) -- selectable so the two can be compared on a
+        # multi-GPU node; bucket edges are multiples of 64 * world elements so that every shard is 16-byte aligned.
+        assert mode in ('all_reduce', 'rs_ag')
+        self.mode = mode
+        quantum = 64 * max(self.world, 1)
+        self.bucket_elems = max(bucket_bytes // 4 // quantum, 1) * quantum
         self.overlap = overlap and self.arena.grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.arena.grad.is_cuda else None
         self._lo = self.arena.total         # everything in [_lo, total) has been produced
@@ -73,12 +80,20 @@ class GradReducer:
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                h = dist.all_reduce(a.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                h = self._reduce(a.grad[s:e])
         else:
-            h = dist.all_reduce(a.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            h = self._reduce(a.grad[s:e])
         self._handles.append(h)
         self.launched += 1
         self._sent = s
+
+    def _reduce(self, buf):
+        n = buf.numel()
+        if self.mode == 'rs_ag' and n % self.world == 0 and dist.get_backend(self.group) == 'nccl':
+            shard = buf.view(self.world, n // self.world)[dist.get_rank(self.group)]       # in-place: the rank's own chunk
+            dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group)
+            return dist.all_gather_into_tensor(buf, shard, group=self.group, async_op=True)
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Reduce whatever is left (everything, if no hook fired) and order the compute stream after the collectives."""

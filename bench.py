@@ -84,7 +84,7 @@ def build(args, device, world):
     opt = FusedSGD(model.parameters(), lr=1e-4 * world, momentum=0.9, nesterov=True, weight_decay=1e-6, arena=model.arena)
     op = Basic(model, device, None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
     trainer = Trainer(model, op, opt, None, {'cls_action': 1.0, 'past_cls_action': 1.0, 'feat': 1.0}, distributed=world > 1,
-                      bucket_bytes=args.bucket_mb << 20)
+                      bucket_bytes=args.bucket_mb << 20, reduce_mode=args.reduce_mode)
     rank = int(os.environ.get('RANK', 0))
     data = synthetic_batch(args.batch, args.frames, NUM_CLASSES, device, seed=42 + rank)
     return trainer, data
@@ -168,6 +168,7 @@ def main(argv=None):
     ap.add_argument('--frames', type=int, default=10)
     ap.add_argument('--model', default='vit_base_patch16_224', choices=list(VIT))
     ap.add_argument('--bucket-mb', type=int, default=64)
+    ap.add_argument('--reduce-mode', default='all_reduce', choices=['all_reduce', 'rs_ag'], help='gradient exchange per bucket: RCCL all-reduce, or reduce-scatter + all-gather')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-trace', action='store_true')
     argv = list(sys.argv[1:] if argv is None else argv)

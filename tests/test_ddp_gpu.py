@@ -93,7 +93,7 @@ torch.manual_seed(0)
 model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
 opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, arena=model.arena)
 op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
-tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=True, bucket_bytes=64 << 10, force_reducer=True)
+tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=True, bucket_bytes=64 << 10, force_reducer=True, reduce_mode=os.environ.get('AVT_TEST_REDUCE_MODE', 'all_reduce'))
 assert tr.reducer is not None
 g = torch.Generator().manual_seed(9)
 data = {'video': (torch.rand((2, 4, 3, 1, 32, 32), generator=g) * 2 - 1).cuda(), 'target': {'action': torch.randint(0, 17, (2,), generator=g).cuda()},
@@ -109,7 +109,8 @@ print('OK nccl', tr.reducer.launched)
 '''
 
 
-def test_rccl_executes_the_bucketed_allreduce_on_one_gpu(tmp_path):
+@pytest.mark.parametrize('mode', ['all_reduce', 'rs_ag'])
+def test_rccl_executes_the_bucketed_allreduce_on_one_gpu(tmp_path, mode):
     """backend='nccl' (= RCCL) with world_size 1: init_process_group, rank-0 broadcast, the bucketed all_reduce launched from
     the backward segment hooks on the side stream, finish() -- the same code path the 8-GPU run takes, on the box we have."""
     if not torch.cuda.is_available():
@@ -117,7 +118,7 @@ def test_rccl_executes_the_bucketed_allreduce_on_one_gpu(tmp_path):
     script = tmp_path / 'nccl_worker.py'
     script.write_text(NCCL_WORKER)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29561', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0',
-               HSA_ENABLE_IPC_MODE_LEGACY='0')
+               HSA_ENABLE_IPC_MODE_LEGACY='0', AVT_TEST_REDUCE_MODE=mode)
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and 'OK nccl' in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
 
