@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from avt_amd import ops
 
-B, T, S, D, H = int(os.environ.get('KB_BATCH', 128)), 10, 197, 768, 12
+B, T, S, D, H = int(os.environ.get('KB_BATCH', 128)), 10, int(os.environ.get('KB_S', 197)), 768, 12
 N = B * T
 M = N * S
 ops.DETERMINISTIC_WGRAD = os.environ.get('KB_DET', '1') == '1'
