@@ -251,6 +251,17 @@ def main(cfg, steps=10, batch_size=None, log_every=1, ckpt=None):
                       grad_clip=cfg.train.train_one_epoch_fn.get('grad_clip_params', None))
     feat_shape = tuple(cfg.get('synthetic', Cfg()).get('feat_shape', (3, 1, 224, 224)))
     data = synthetic_batch(B, T, C, device, seed=cfg.get('seed', 42) + rank, feat_shape=feat_shape)
+    # synthetic.uint8_source: [H, W] -> the clips start as uint8 frames (what a video decoder hands over) and go through the fused
+    # GPU input pipeline every step (resize / flip / normalise / crop with per-clip random draws, func/train.py:550-569)
+    u8_hw = cfg.get('synthetic', Cfg()).get('uint8_source', None)
+    gpu_tf, clips_u8 = None, None
+    if u8_hw:
+        from ..common.gpu_transforms import GpuClipTransform
+        dt = cfg.data_train
+        gpu_tf = GpuClipTransform(dt.scale_h, dt.scale_w, dt.crop_size, dt.mean, dt.std, dt.get('flip_p', 0.5),
+                                  dt.get('scale_pix_val', 1.0), dt.get('reverse_channels', False), train=True)
+        g = torch.Generator(device=device).manual_seed(cfg.get('seed', 42) + rank)
+        clips_u8 = torch.randint(0, 256, (B, T, int(u8_hw[0]), int(u8_hw[1]), 3), device=device, dtype=torch.uint8, generator=g)
     start = 0
     import os
     if ckpt and os.path.isfile(ckpt):
@@ -258,6 +269,8 @@ def main(cfg, steps=10, batch_size=None, log_every=1, ckpt=None):
         logging.warning('Loaded model from %s (ep %f)', ckpt, start)
     for it in range(steps):
         t0 = time.time()
+        if gpu_tf is not None:
+            data['video'] = gpu_tf(clips_u8)
         loss, _, _, accs = trainer.step(data, sync_loss=True)
         dt = time.time() - t0
         if rank == 0 and it % log_every == 0:

@@ -481,6 +481,11 @@ def test_train_net_entry_runs_the_composed_experiment(tmp_path):
     assert len(lines) == 3, r.stdout[-2000:]
     losses = [float(l.split('loss ')[1].split()[0]) for l in lines]
     assert all(l == l and 0 < l < 100 for l in losses), losses
+    # the same experiment fed by uint8 frames through the fused GPU input pipeline (expts/01's 248-280 resize, 224 crop)
+    r = subprocess.run([sys.executable, os.path.join(root, 'train_net.py'), '-c', os.path.join(root, 'expts', '01_ek100_avt.txt'),
+                        '--steps', '2', '--batch', '2', 'synthetic.uint8_source=[256,456]'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len([l for l in r.stdout.splitlines() if l.startswith('iter ')]) == 2, r.stdout[-2000:]
 
 
 def test_checkpoint_round_trip_with_the_reference_format(tmp_path):

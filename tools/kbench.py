@@ -9,7 +9,7 @@ B, T, S, D, H = int(os.environ.get('KB_BATCH', 128)), 10, int(os.environ.get('KB
 N = B * T
 M = N * S
 ops.DETERMINISTIC_WGRAD = os.environ.get('KB_DET', '1') == '1'
-want = set(sys.argv[1:]) or {'ln', 'attn', 'cls', 'gemm', 'wgrad', 'sgd'}
+want = set(sys.argv[1:]) or {'ln', 'attn', 'cls', 'gemm', 'wgrad', 'sgd', 'preproc'}
 r = lambda *s: (torch.rand(s, device='cuda') * 2 - 1).to(torch.bfloat16)
 
 
@@ -96,6 +96,13 @@ if 'gemm' in want:
         dwp = torch.zeros((D, D), device='cuda')
         timeit('proj wgrad', lambda: ops.linear_wgrad(y, x, dwp), flops=2.0 * M * D * D)
   ops.FORCE_TILE = 0
+if 'preproc' in want:
+    from avt_amd.common.gpu_transforms import GpuClipTransform
+    tf = GpuClipTransform('248-280', -1, 224, train=True)
+    Bp = 64
+    u8 = torch.randint(0, 256, (Bp, T, 256, 456, 3), device='cuda', dtype=torch.uint8)
+    prm = [tf.draw(256, 456) for _ in range(Bp)]
+    timeit(f'video_preproc {Bp}x{T} frames 256x456 -> 224^2', lambda: tf(u8, params=prm), bytes_=Bp * T * (256 * 456 * 3 + 3 * 224 * 224 * 4))
 if 'sgd' in want:
     n = 396_120_000 // 64 * 64
     p_, g_, m_ = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
