@@ -57,6 +57,7 @@ class ParamArena:
                 self.params[n] = p
                 self.name_of[id(p)] = n
         self._version = None
+        self._transposed = {}            # name -> bf16 (in, out) copy of a Linear weight's shadow (see transposed_of)
         self.refresh_shadow(force=True)
 
     # ---- views -------------------------------------------------------------------------------------------------
@@ -103,9 +104,28 @@ class ParamArena:
         if force or v != self._version:
             ops.cast_to_bf16(self.master, self.shadow)
             self._version = v
+            self.refresh_transposed()
 
     def mark_shadow_current(self):
         self._version = self._current_version()
+        self.refresh_transposed()
+
+    def transposed_of(self, name):
+        """bf16 W^T (in, out) of the 2-D parameter ``name``, kept next to the shadow and refreshed whenever the shadow is
+        (one 64x64-tile transpose kernel per registered matrix and optimizer step, ~0.3 ms for ViT-B).  With it the data
+        gradient dx = dy W reads the weight k-major like the forward does: qkv / fc1 / fc2 data gradients run 5-9 % faster
+        than through transposing LDS reads (measured: 754 vs 796, 953 vs 1036, 1158 vs 1273 us at 128 clips)."""
+        t = self._transposed.get(name)
+        if t is None:
+            out_f, in_f = self.shapes[name]
+            t = torch.empty((in_f, out_f), device=self.device, dtype=torch.bfloat16)
+            self._transposed[name] = t
+            ops.transpose_into(self.shadow_of(name), t)
+        return t
+
+    def refresh_transposed(self):
+        for name, t in self._transposed.items():
+            ops.transpose_into(self.shadow_of(name), t)
 
     def grads_attached(self):
         """Cheap check (first / last parameter): ``zero_grad(set_to_none=True)`` drops every ``.grad`` or none."""
@@ -141,6 +161,9 @@ class ParamArena:
 
     def gr(self, param, rows=None):
         return self.grad_of(self.name_of[id(param)], rows)
+
+    def sh_t(self, param):
+        return self.transposed_of(self.name_of[id(param)])
 
 
 def get_arena(module: torch.nn.Module, padded_numel_fn=None) -> ParamArena:

@@ -197,6 +197,21 @@ __global__ __launch_bounds__(256) void relu_kernel(const bf16_t* __restrict__ x,
     *(u32x4_t*)(mask + i * 8) = m;
   }
 }
+// dst[c][r] = src[r][c] (bf16), 64 x 64 tiles through LDS: the transposed bf16 shadow of a Linear weight, refreshed once per
+// optimizer step, lets the data-gradient GEMM read the weight k-major (ds_read_b128) instead of through transposing LDS reads
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, long lds_, bf16_t* __restrict__ dst, long ldd, int rows, int cols) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(size_t)(r0 + r) * lds_ + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < cols && r0 + r < rows) dst[(size_t)(c0 + c) * ldd + r0 + r] = tile[r][c];
+  }
+}
 // dst[r, :] += src[r, :] for strided bf16 rows (the CLS rows of a [frames*S, D] tensor: ldd = S*D)
 __global__ __launch_bounds__(256) void add_rows_kernel(bf16_t* __restrict__ dst, long ldd, const bf16_t* __restrict__ src, long lds,
                                                        int rows, int D) {
@@ -322,6 +337,13 @@ extern "C" int avt_relu_bf16(const void* x, void* y, void* mask, long n, void* s
   AVT_CHECK(x && y && mask && n > 0 && n % 8 == 0, "avt_relu_bf16: n must be a positive multiple of 8");
   AVT_CHECK(aligned16(x) && aligned16(y) && aligned16(mask), "avt_relu_bf16: 16-byte alignment required");
   hipLaunchKernelGGL(relu_kernel, dim3(GRID_FOR(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (bf16_t*)mask, n / 8);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_transpose_bf16(const void* src, long ld_src, void* dst, long ld_dst, int rows, int cols, void* stream) {
+  AVT_CHECK(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "avt_transpose_bf16: bad argument");
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src,
+                     (bf16_t*)dst, ld_dst, rows, cols);
   AVT_LAUNCH_CHECK();
   return 0;
 }

@@ -28,6 +28,7 @@ SIGNATURES = {
     'avt_head_attn_fwd': [_P, _P, _P, _I, _I, _I, _I, _F, _F, _U64, _I, _P],
     'avt_head_attn_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _U64, _I, _P],
     'avt_relu_bf16': [_P, _P, _P, _L, _P],
+    'avt_transpose_bf16': [_P, _L, _P, _L, _I, _I, _P],
     'avt_im2col_patch16': [_P, _P, _I, _I, _I, _P],
     'avt_posres_prep': [_P, _P, _P, _P, _I, _I, _P],
     'avt_patch_embed_bwd_reduce': [_P, _P, _P, _P, _I, _I, _I, _P],

@@ -164,7 +164,7 @@ def _last_block_backward(m: HipViT, arena, blk, saved, dx2, N, prev_bias):
     ops.colsum(datt, gb[2 * D:])
     ops.linear_wgrad(dq, _cls_rows(ln1, N, S, D), gw[:D])
     ops.linear_wgrad(dkv, ln1, gw[D:])
-    dln1 = ops.linear_dgrad(dkv, wqkv[D:])                                              # [N*S, D]
+    dln1 = ops.linear_fwd(dkv, arena.sh_t(blk.attn.qkv.weight)[:, D:])                  # [N*S, D] = dkv @ Wkv, W^T columns D..3D
     dln1_cls = _cls_rows(dln1, N, S, D)
     ops.linear_dgrad(dq, wqkv[:D], res=dln1_cls, out=dln1_cls)                          # CLS rows += dq @ Wq, in place
     dx = ops.layernorm_bwd(dln1, x, mean1, rstd1, blk.norm1.weight, gr(blk.norm1.weight), gr(blk.norm1.bias), colsum=prev_bias)
@@ -178,7 +178,7 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
     D, H, S = m.embed_dim, m.num_heads, m.seq
     N = dfeat.size(0)
     M = N * S
-    sh, gr = arena.sh, arena.gr
+    sh, gr, sh_t = arena.sh, arena.gr, arena.sh_t
     hook = m.grad_ready_hook
     x, meanf, rstdf = saved['final']
     last = m.blocks[-1]
@@ -207,10 +207,11 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
         saved['blocks'][i] = None
         # x2 = act @ W2^T + b2 + x1          (db2 was accumulated by the producer of dx)
         ops.linear_wgrad(dx, act, gr(blk.mlp.fc2.weight))
-        dh = ops.linear_dgrad(dx, sh(blk.mlp.fc2.weight), act=ops.ACT_MUL_AUX, aux=pre, colsum=gr(blk.mlp.fc1.bias))
+        # data gradients of qkv / fc1 / fc2 read the transposed bf16 shadow W^T k-major (arena.transposed_of); proj stays as it is
+        dh = ops.linear_fwd(dx, sh_t(blk.mlp.fc2.weight), act=ops.ACT_MUL_AUX, aux=pre, colsum=gr(blk.mlp.fc1.bias))
         del act, pre
         ops.linear_wgrad(dh, ln2, gr(blk.mlp.fc1.weight))
-        dln2 = ops.linear_dgrad(dh, sh(blk.mlp.fc1.weight))
+        dln2 = ops.linear_fwd(dh, sh_t(blk.mlp.fc1.weight))
         del dh, ln2
         dx1 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, blk.norm2.weight, gr(blk.norm2.weight), gr(blk.norm2.bias),
                                 dres=dx, colsum=gr(blk.attn.proj.bias))
@@ -220,7 +221,7 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
         dqkv = ops.vit_attn_bwd(qkv, att, datt, lse, N, S, H, dbias=gr(blk.attn.qkv.bias))
         del datt, att, qkv
         ops.linear_wgrad(dqkv, ln1, gr(blk.attn.qkv.weight))
-        dln1 = ops.linear_dgrad(dqkv, sh(blk.attn.qkv.weight))
+        dln1 = ops.linear_fwd(dqkv, sh_t(blk.attn.qkv.weight))
         del dqkv, ln1
         prev_bias = gr(m.blocks[i - 1].mlp.fc2.bias) if i > 0 else None
         dx = ops.layernorm_bwd(dln1, x, mean1, rstd1, blk.norm1.weight, gr(blk.norm1.weight), gr(blk.norm1.bias),

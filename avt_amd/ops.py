@@ -241,6 +241,13 @@ def causal_attn_bwd(qkv, probs, dout, B, T, H, hd, drop_p=0.0, seed=0, causal=Tr
     return dqkv
 
 
+def transpose_into(src, dst):
+    """dst[c, r] = src[r, c]; 2-D bf16 views with unit inner stride."""
+    _chk(src, BF16, 'src'); _chk(dst, BF16, 'dst')
+    assert dst.shape == (src.size(1), src.size(0))
+    _lib.call('avt_transpose_bf16', _p(src), _ld(src), _p(dst), _ld(dst), src.size(0), src.size(1), _stream())
+
+
 def relu(x):
     """(max(x, 0), mask) with mask = bf16 1/0 = the derivative, consumed by gemm(act=ACT_MUL_AUX) in backward."""
     _chk(x, BF16, 'x')

@@ -513,3 +513,17 @@ def test_video_preproc_vs_reference_golden_and_oracle(ops, golden_dir):
     for b, (nh, nw, fl, ci, cj) in enumerate(params):
         ref = O.video_preproc(u8[b], (nh, nw), fl, (ci, cj), (224, 224))
         assert float((out[b, :, :, 0].permute(1, 0, 2, 3).cpu() - ref).abs().max()) < 2e-5, b
+
+
+def test_transpose_bf16(ops):
+    for (r, c) in [(768, 2304), (100, 37), (3072, 768), (64, 64)]:
+        src = rnd((r, c), 1.0, 96)
+        dst = torch.empty((c, r), device='cuda', dtype=torch.bfloat16)
+        ops.transpose_into(src, dst)
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src.t().contiguous())
+    big = rnd((200, 300), 1.0, 97)
+    dst = torch.zeros((64, 128), device='cuda', dtype=torch.bfloat16)
+    ops.transpose_into(big[10:138, 5:69], dst)                                     # strided source view
+    torch.cuda.synchronize()
+    assert torch.equal(dst, big[10:138, 5:69].t().contiguous())

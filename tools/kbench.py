@@ -96,6 +96,16 @@ if 'gemm' in want:
         dwp = torch.zeros((D, D), device='cuda')
         timeit('proj wgrad', lambda: ops.linear_wgrad(y, x, dwp), flops=2.0 * M * D * D)
   ops.FORCE_TILE = 0
+if 'layout' in want:
+    # the same contraction with the weight stored [N][K] (k-major, ds_read_b128) vs [K][N] (transposing reads): is a transposed
+    # bf16 shadow of the weights worth keeping for the data-gradient GEMMs?
+    for name, K_, N_ in [('proj dgrad', 768, 768), ('qkv dgrad', 2304, 768), ('fc1 dgrad', 3072, 768), ('fc2 dgrad', 768, 3072)]:
+        a_, wk, wn = r(M, K_), r(N_, K_), r(K_, N_)
+        o_ = torch.empty((M, N_), device='cuda', dtype=torch.bfloat16)
+        fl_ = 2.0 * M * K_ * N_
+        timeit(f'{name} NT (W^T shadow)', lambda: ops.gemm(a_, wk, M, N_, K_, a_kmajor=True, b_kmajor=True, out=o_), flops=fl_)
+        timeit(f'{name} NN (today)', lambda: ops.gemm(a_, wn, M, N_, K_, a_kmajor=True, b_kmajor=False, out=o_), flops=fl_)
+        del a_, o_
 if 'preproc' in want:
     from avt_amd.common.gpu_transforms import GpuClipTransform
     tf = GpuClipTransform('248-280', -1, 224, train=True)
