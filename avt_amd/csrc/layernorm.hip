@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
-template <int V>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
+template <int V, int MINW = 1, bool PF = true>
+__global__ __launch_bounds__(256, MINW) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const bf16_t* __restrict__ dres, int lddres,
                                                      bf16_t* __restrict__ dx, int lddx, float* __restrict__ dgamma,
@@ -128,13 +128,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     nmean = ok ? mean_in[row] : 0.f; nrstd = ok ? rstd_in[row] : 0.f;
   };
   int row = blockIdx.x * 4 + wave;
-  fetch(row);
+  if (PF) fetch(row);
   for (; row < rows; row += rstep) {
+    if (!PF) fetch(row);
     u32x4_t cx[V], cd[V], cr[V];
 #pragma unroll
     for (int i = 0; i < V; ++i) { cx[i] = nx[i]; cd[i] = nd[i]; cr[i] = nr[i]; }
     const float mean = nmean, rstd = nrstd;
-    fetch(row + rstep);
+    if (PF) fetch(row + rstep);
     float xh[V][8], g[V][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -316,9 +317,18 @@ extern "C" int avt_layernorm_bwd(const void* dy, int lddy, const void* x, int ld
   hipStream_t s = (hipStream_t)stream;
   // (a two-rows-per-wave variant like ln_fwd2_kernel was measured for backward: 349-407 us against this kernel's 346 us at
   //  252160 x 768 -- three input streams per row leave no registers for it to win; not kept)
+  if (pick_v(D) == 2) {
+    // D = 768 / 1024: three waves per SIMD without the software prefetch (150 VGPRs) beat two waves with it (175 VGPRs):
+    // 300 vs 364 us at 252160 x 768 -- more rows in flight per CU than the one-row-ahead pipeline gave
+    int g = (rows + 3) / 4; if (g > 768) g = 768;
+    hipLaunchKernelGGL((ln_bwd_kernel<2, 3, false>), dim3(g), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma,
+                       (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, dgamma, dbeta, colsum, rows, D);
+    AVT_LAUNCH_CHECK();
+    return 0;
+  }
 #define LN_BWD(V) hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, dgamma, dbeta, colsum, rows, D)
   switch (pick_v(D)) {
-    case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break; case 4: LN_BWD(4); break;
+    case 1: LN_BWD(1); break; case 3: LN_BWD(3); break; case 4: LN_BWD(4); break;
     case 5: LN_BWD(5); break; case 6: LN_BWD(6); break; case 7: LN_BWD(7); break; default: LN_BWD(8); break;
   }
 #undef LN_BWD
