@@ -53,7 +53,7 @@ def init_distributed_mode(backend=None, allow_single=False):
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     if torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local % torch.cuda.device_count())
     if not dist.is_initialized():
         kw = {}
         if backend == 'nccl':

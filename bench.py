@@ -132,7 +132,7 @@ def self_launch(args, argv):
     import socket
     import subprocess
     ndev = torch.cuda.device_count()
-    if ndev < args.gpus:
+    if ndev < args.gpus and args.backend == 'nccl':
         raise SystemExit(f'bench.py --gpus {args.gpus}: this node exposes {ndev} GPU(s); refusing to oversubscribe '
                          f'(RCCL needs one device per rank)')
     with socket.socket() as sk:
@@ -169,6 +169,7 @@ def main(argv=None):
     ap.add_argument('--model', default='vit_base_patch16_224', choices=list(VIT))
     ap.add_argument('--bucket-mb', type=int, default=64)
     ap.add_argument('--reduce-mode', default='all_reduce', choices=['all_reduce', 'rs_ag'], help='gradient exchange per bucket: RCCL all-reduce, or reduce-scatter + all-gather')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="'gloo' lets several ranks share one GPU (a functional check of the N > 1 path on a 1-GPU box; never a measurement)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-trace', action='store_true')
     argv = list(sys.argv[1:] if argv is None else argv)
@@ -183,7 +184,9 @@ def main(argv=None):
     import torch.distributed as dist
     from avt_amd import ops
     from avt_amd.common import utils
-    dist_on, rank, world, local = utils.init_distributed_mode('nccl')
+    dist_on, rank, world, local = utils.init_distributed_mode(args.backend)
+    if args.backend == 'gloo':
+        local %= max(torch.cuda.device_count(), 1)             # ranks share the devices that exist
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     trainer, data = build(args, device, world)
@@ -248,7 +251,7 @@ def main(argv=None):
         out = {'metric': f'training clips/sec ({name}+AVT-h, {args.frames}x224^2 frames)',
                'value': round(clips, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-               'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+               'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic' if args.backend == 'nccl' else 'synthetic (gloo functional check: ranks share devices, NOT a measurement)',
                'config': {'workload': f'{args.model} + AVT-h(2048x6x4) fwd+bwd+SGD-nesterov, T={args.frames} x 224^2, C={NUM_CLASSES}, '
                                       f'{args.batch} clips/GPU, dropout 0.1/0.2 on, fp32 master weights / bf16 MFMA',
                           'clips_per_gpu': args.batch, 'global_batch': args.batch * world, 'frames': args.frames,

@@ -129,3 +129,20 @@ def test_bench_refuses_more_ranks_than_devices():
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(max(n, 2)), '--steps', '1', '--warmup', '0'],
                        capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and 'refusing to oversubscribe' in (p.stdout + p.stderr)
+
+
+def test_bench_two_ranks_end_to_end_over_gloo():
+    """The N > 1 path of bench.py end to end on the box we have: `python bench.py --gpus 2` spawns its own ranks (torch.distributed.run
+    on 127.0.0.1), both ranks train on cuda:0 over gloo (RCCL needs one device per rank), rank 0 prints ONE JSON line with
+    n_gpus = 2, the whole-job rate and both per-rank rates.  A functional check, not a measurement."""
+    import json
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--batch', '2', '--steps', '2',
+                        '--warmup', '1', '--no-cpu-baseline'], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2' and len(d['per_rank_clips_per_s']) == 2
+    assert d['value'] > 0 and 'cpu_baseline' not in d
