@@ -7,7 +7,7 @@ distributions the reference's transforms use (``random.randint`` for the ``"248-
 RandomCrop.get_params), so a seeded run draws the same sequence.
 
 Configured from the same ``data_train`` / ``data_eval`` keys (conf/data/default.yaml: scale_h, scale_w, crop_size, mean, std, flip_p,
-scale_pix_val, reverse_channels); colour jitter (0 in every AVT experiment) is not implemented and raises when requested.
+scale_pix_val, reverse_channels, eval_num_crops, eval_flip_crops); colour jitter (0 in every AVT experiment) is not implemented and raises when requested.
 """
 import random
 
@@ -18,7 +18,7 @@ from .. import ops
 
 class GpuClipTransform:
     def __init__(self, scale_h, scale_w=-1, crop_size=224, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), flip_p=0.5,
-                 scale_pix_val=1.0, reverse_channels=False, train=True, color_jitter_brightness=0.0, color_jitter_contrast=0.0,
+                 scale_pix_val=1.0, reverse_channels=False, train=True, eval_num_crops=1, eval_flip_crops=False, color_jitter_brightness=0.0, color_jitter_contrast=0.0,
                  color_jitter_saturation=0.0, color_jitter_hue=0.0, **_unused):
         if any(v != 0 for v in (color_jitter_brightness, color_jitter_contrast, color_jitter_saturation, color_jitter_hue)):
             raise NotImplementedError('colour jitter is 0 in the AVT experiments and not part of the fused kernel')
@@ -29,6 +29,9 @@ class GpuClipTransform:
         self.mean, self.std = tuple(mean), tuple(std)
         self.flip_p = flip_p if train else 0.0
         self.scale_pix_val, self.reverse_channels, self.train = scale_pix_val, reverse_channels, train
+        if eval_num_crops not in (1, 3):
+            raise NotImplementedError('Not supported')               # common/transforms.py:271
+        self.num_crops, self.flip_crops = (1, False) if train else (eval_num_crops, bool(eval_flip_crops))
 
     @staticmethod
     def _size(v):
@@ -57,11 +60,33 @@ class GpuClipTransform:
             i, j = int(round((new_h - th) / 2.0)), int(round((new_w - tw) / 2.0))
         return new_h, new_w, flip, i, j
 
+    def eval_crops(self, H, W):
+        """MultiCropVideo (common/transforms.py:254-296): [(new_h, new_w, flip, i, j)] for the 1 or 3 crops, then their mirror
+        images when ``eval_flip_crops`` (a mirrored crop at column j = the crop at new_w - tw - j of the mirrored frame)."""
+        new_h, new_w, _, ci, cj = self.draw(H, W)
+        th, tw = self.crop
+        pos = [(ci, cj)] if self.num_crops == 1 else [(0, 0), (ci, cj), (new_h - th, new_w - tw)]
+        out = [(new_h, new_w, 0, i, j) for i, j in pos]
+        if self.flip_crops:
+            out += [(new_h, new_w, 1, i, new_w - tw - j) for i, j in pos]
+        return out
+
     def __call__(self, clips_u8, params=None):
         """clips_u8: uint8 (B, T, H, W, 3) on the GPU -> fp32 (B, T, 3, 1, crop_h, crop_w), the ``video`` entry of the sample
         dict the model consumes.  ``params`` (B x 5 ints) overrides the draws (tests)."""
         B, T, H, W, _ = clips_u8.shape
+        multi = (not self.train) and (self.num_crops > 1 or self.flip_crops) and params is None
         if params is None:
-            params = [self.draw(H, W) for _ in range(B)]
+            if multi:
+                per_clip = [self.eval_crops(H, W) for _ in range(B)]
+                nc = len(per_clip[0])
+                params = [tuple(c) + (b,) for b in range(B) for c in per_clip[b]]           # output clip b * nc + crop
+            else:
+                params = [tuple(self.draw(H, W)) + (b,) for b in range(B)]
+        else:
+            params = [tuple(q) + ((b,) if len(q) == 5 else ()) for b, q in enumerate(params)]
         p = torch.tensor(params, dtype=torch.int32).to(clips_u8.device, non_blocking=True)
-        return ops.video_preproc(clips_u8.contiguous(), p, self.crop, self.scale_pix_val, self.mean, self.std, self.reverse_channels)
+        out = ops.video_preproc(clips_u8.contiguous(), p, self.crop, self.scale_pix_val, self.mean, self.std, self.reverse_channels)
+        if multi:                                   # (B * crops, T, 3, 1, h, w) -> the model's 7-D (B, #clips, #crops, C, T', H, W)
+            out = out.view(B, nc, T, 3, 1, *self.crop).permute(0, 2, 1, 3, 4, 5, 6)
+        return out

@@ -6,6 +6,10 @@
 // resized intermediate never exists.  One thread per output pixel (all three channels: the source is channel-interleaved),
 // writes are coalesced along x into the (B, T, 3, 1, OH, OW) fp32 batch the backbone's patch embedding reads.  HBM-bound and
 // tiny next to the model (0.95 MB per frame).  The random draws stay on the host (params), as in the reference.
+// Every OUTPUT clip has its own parameter row {new_h, new_w, flip, crop_i, crop_j, source clip}: the evaluation transform
+// MultiCropVideo (common/transforms.py:254-296: top-left / centre / bottom-right crops, optionally followed by their mirror
+// images) is 3 or 6 output clips reading one source clip -- a mirrored crop at column j is the crop at new_w - crop_w - j of
+// the mirrored frame.
 #include "common.hpp"
 #include "../../include/avt_hip.h"
 
@@ -20,8 +24,8 @@ __global__ __launch_bounds__(256) void video_preproc_kernel(const uint8_t* __res
     const int y = (int)(r % OH); r /= OH;
     const int t = (int)(r % T);
     const int b = (int)(r / T);
-    const int* pp = params + b * 5;
-    const int new_h = pp[0], new_w = pp[1], flip = pp[2], ci = pp[3], cj = pp[4];
+    const int* pp = params + b * 6;
+    const int new_h = pp[0], new_w = pp[1], flip = pp[2], ci = pp[3], cj = pp[4], sb = pp[5];      // sb: source clip (several crops may share one)
     const int yr = y + ci;
     int xr = x + cj;
     if (flip) xr = new_w - 1 - xr;
@@ -32,7 +36,7 @@ __global__ __launch_bounds__(256) void video_preproc_kernel(const uint8_t* __res
     const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
     const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
     const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-    const uint8_t* f = src + ((size_t)b * T + t) * (size_t)H * W * 3;
+    const uint8_t* f = src + ((size_t)sb * T + t) * (size_t)H * W * 3;
     const uint8_t* p00 = f + ((size_t)y0 * W + x0) * 3;
     const uint8_t* p01 = f + ((size_t)y0 * W + x1) * 3;
     const uint8_t* p10 = f + ((size_t)y1 * W + x0) * 3;

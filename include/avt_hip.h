@@ -152,8 +152,9 @@ int avt_relu_bf16(const void* x, void* y, void* mask, long n, void* stream);
  * The reference's per-clip CPU transform chain (func/train.py:550-569; common/transforms.py:60-91 resize, :124-146 to_tensor,
  * :149-164 normalize, :167-175 hflip, RandomCropVideo / CenterCropVideo): uint8 frames (B,T,H,W,3) -> /255 -> bilinear resize
  * (align_corners = False) to (new_h, new_w) -> optional horizontal flip -> x scale_pix -> optional channel reversal ->
- * (v - mean) / std -> crop (OH, OW) at (crop_i, crop_j), written as fp32 (B,T,3,1,OH,OW).  params: int32 [B][5] =
- * {new_h, new_w, flip, crop_i, crop_j} per clip (device memory; the random draws stay with the caller). mean3 / std3: host. */
+ * (v - mean) / std -> crop (OH, OW) at (crop_i, crop_j), written as fp32 (B,T,3,1,OH,OW).  params: int32 [B][6] =
+ * {new_h, new_w, flip, crop_i, crop_j, source clip} per OUTPUT clip (device memory; the random draws stay with the caller; the
+ * evaluation MultiCropVideo, common/transforms.py:254-296, is several output clips reading one source clip). mean3 / std3: host. */
 int avt_video_preproc_u8(const void* src, float* dst, const int* params, int B, int T, int H, int W, int OH, int OW,
                          float scale_pix, const float* mean3, const float* std3, int reverse_channels, void* stream);
 

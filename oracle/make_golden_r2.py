@@ -210,8 +210,15 @@ def main():
         report.append(f'G9 clip {b}: restatement vs reference transforms max|d|={dd:.3e}')
         assert dd < 1e-6
         params.append([nh, nw, d['flip'], d['crop'][0], d['crop'][1], int(d['reverse']), d['scale']])
+    # evaluation chain: Resize(int) -> scale -> normalize -> MultiCropVideo(crop, 3 crops, flips) with the reference's multi_crop
+    MC_T, MC_C = 56, 48
+    mc = []
+    for b in range(2):
+        x = RT.normalize(RT.resize(RT.to_tensor(clips[b]), MC_T, 'bilinear') * 1.0, mean, std)
+        mc.append(torch.stack(RT.multi_crop(x, (MC_C, MC_C), 3, True), 0))                 # (6, C, T, h, w)
     np.savez_compressed(os.path.join(OUT, 'g9_preproc.npz'), clips=clips.numpy(), params=np.asarray(params, dtype=np.float64),
-                        mean=np.asarray(mean), std=np.asarray(std), out=torch.stack(outs).numpy())
+                        mean=np.asarray(mean), std=np.asarray(std), out=torch.stack(outs).numpy(),
+                        mc_target=np.int64(MC_T), mc_crop=np.int64(MC_C), mc_out=torch.stack(mc).numpy())
 
     # ---------------- G10: Transformer-encoder temporal aggregator (reference module, eval mode = dropout off) ---------
     import models.temporal_aggregation as ref_ta

@@ -293,5 +293,8 @@ def test_gpu_clip_transform_draws_follow_the_reference_rules():
     assert seen_flip == {0, 1}
     ev = GpuClipTransform(248, -1, 224, train=False)
     assert ev.draw(256, 456) == (248, 441, 0, 12, 108)          # centre crop: round((248-224)/2), round((441-224)/2)
+    mc = GpuClipTransform(248, -1, 224, train=False, eval_num_crops=3, eval_flip_crops=True).eval_crops(256, 456)
+    assert mc == [(248, 441, 0, 0, 0), (248, 441, 0, 12, 108), (248, 441, 0, 24, 217),
+                  (248, 441, 1, 0, 217), (248, 441, 1, 12, 109), (248, 441, 1, 24, 0)]
     with pytest.raises(NotImplementedError):
         GpuClipTransform(248, color_jitter_hue=0.1)

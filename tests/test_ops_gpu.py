@@ -497,7 +497,7 @@ def test_video_preproc_vs_reference_golden_and_oracle(ops, golden_dir):
     z = np.load(os.path.join(golden_dir, 'g9_preproc.npz'))
     clips, want = torch.from_numpy(z['clips']).cuda(), torch.from_numpy(z['out'])
     for b, p in enumerate(z['params']):
-        prm = torch.tensor([[int(p[0]), int(p[1]), int(p[2]), int(p[3]), int(p[4])]], dtype=torch.int32).cuda()
+        prm = torch.tensor([[int(p[0]), int(p[1]), int(p[2]), int(p[3]), int(p[4]), 0]], dtype=torch.int32).cuda()
         got = ops.video_preproc(clips[b:b + 1], prm, tuple(want.shape[-2:]), float(p[6]), tuple(z['mean']), tuple(z['std']), bool(p[5]))
         torch.cuda.synchronize()
         got = got[0, :, :, 0].permute(1, 0, 2, 3).cpu()                       # (T,3,h,w) -> (3,T,h,w)
@@ -513,6 +513,14 @@ def test_video_preproc_vs_reference_golden_and_oracle(ops, golden_dir):
     for b, (nh, nw, fl, ci, cj) in enumerate(params):
         ref = O.video_preproc(u8[b], (nh, nw), fl, (ci, cj), (224, 224))
         assert float((out[b, :, :, 0].permute(1, 0, 2, 3).cpu() - ref).abs().max()) < 2e-5, b
+    # evaluation: MultiCropVideo, 3 crops + their mirror images, against the golden from the reference's multi_crop / hflip
+    ev = GpuClipTransform(int(z['mc_target']), -1, int(z['mc_crop']), tuple(z['mean']), tuple(z['std']), train=False, eval_num_crops=3, eval_flip_crops=True)
+    mc = ev(clips[:2])
+    torch.cuda.synchronize()
+    want_mc = torch.from_numpy(z['mc_out'])                                   # (2, 6, 3, T, h, w)
+    assert mc.shape == (2, clips.size(1), 6, 3, 1, int(z['mc_crop']), int(z['mc_crop']))
+    got_mc = mc[:, :, :, :, 0].permute(0, 2, 3, 1, 4, 5).cpu()              # (B, T, crops, C, h, w) -> (B, crops, C, T, h, w)
+    assert float((got_mc - want_mc).abs().max()) < 2e-5 * max(float(want_mc.abs().max()), 1.0)
 
 
 def test_transpose_bf16(ops):
