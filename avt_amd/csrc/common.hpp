@@ -129,3 +129,10 @@ void avt_set_error(const char* fmt, ...);
 #define AVT_LAUNCH_CHECK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) { \
   avt_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); return (int)e__; } } while (0)
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---- run-to-run identical parameter gradients ----------------------------------------------------------
+// Kernels that fold many workgroups into one fp32 vector (bias / gamma / beta / embedding gradients) either merge with fp32
+// atomics (order = arrival order: the last bits differ from run to run) or, when the caller passes a partials workspace,
+// store one partial vector per workgroup ("slot") with plain stores: part[(q * nslots + slot) * n + i], q = quantity.
+// avt_reduce_partials then adds the slots in a FIXED tree (a function of nslots only) and does out_q[i] += sum.
+int avt_reduce_partials(const float* part, int nslots, long n, float* const* outs, int nq, hipStream_t stream);

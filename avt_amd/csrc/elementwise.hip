@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const bf16_t* __rest
 // the 19 k (s, chunk) columns of a ViT-B still give a few thousand workgroups of work in flight (fp32 atomics merge the parts)
 __global__ __launch_bounds__(256) void patch_bwd_reduce_kernel(const bf16_t* __restrict__ dx, float* __restrict__ dpos,
                                                                float* __restrict__ dcls, float* __restrict__ dbias,
-                                                               int N, int S, int D, int frames_per_block) {
+                                                               int N, int S, int D, int frames_per_block, float* __restrict__ part) {
   const int nch = D / 8;
   const long total = (long)S * nch;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -125,6 +125,12 @@ __global__ __launch_bounds__(256) void patch_bwd_reduce_kernel(const bf16_t* __r
 #pragma unroll
     for (int e = 0; e < 4; ++e) { acc[2 * e] += bflo(w[e]); acc[2 * e + 1] += bfhi(w[e]); }
   }
+  if (part) {                                            // slot = frame group: [gy][S*D]; dcls / dbias are folded from dpos afterwards
+    float* dst = part + (size_t)blockIdx.y * ((size_t)S * D) + (size_t)s * D + c * 8;
+    *(f32x4_t*)dst = (f32x4_t){acc[0], acc[1], acc[2], acc[3]};
+    *(f32x4_t*)(dst + 4) = (f32x4_t){acc[4], acc[5], acc[6], acc[7]};
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     unsafeAtomicAdd(&dpos[(size_t)s * D + c * 8 + e], acc[e]);
@@ -133,8 +139,40 @@ __global__ __launch_bounds__(256) void patch_bwd_reduce_kernel(const bf16_t* __r
   }
 }
 
+// fixed-order merge of per-workgroup partial vectors (common.hpp): block = 32 slot groups x 32 columns; a thread adds its
+// group's contiguous slots with four interleaved accumulators, thread 0 of a column adds the 32 group sums in order.
+struct ReduceOuts { float* o[4]; float* keep; };     // keep: the sums of quantity 0 are also STORED there (may alias slot 0 of part)
+__global__ __launch_bounds__(1024) void partials_reduce_kernel(const float* part, int nslots, long n, ReduceOuts outs) {
+  __shared__ float red[32][33];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const long col = (long)blockIdx.x * 32 + c;
+  const int q = blockIdx.y;
+  const int per = (nslots + 31) / 32;
+  const int s0 = g * per;
+  int s1 = s0 + per; if (s1 > nslots) s1 = nslots;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < n) {
+    const float* src = part + ((size_t)q * nslots) * (size_t)n + col;
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      a0 += src[(size_t)s * n]; a1 += src[(size_t)(s + 1) * n]; a2 += src[(size_t)(s + 2) * n]; a3 += src[(size_t)(s + 3) * n];
+    }
+    for (; s < s1; ++s) a0 += src[(size_t)s * n];
+  }
+  red[g][c] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0 && col < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += red[k][c];
+    if (outs.o[q]) outs.o[q][col] += t;
+    if (q == 0 && outs.keep) outs.keep[col] = t;
+  }
+}
+
 // column sums of a bf16 matrix: out[n] += sum_m x[m][n]   (bias gradients that have no producer to fuse into)
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int ld, float* __restrict__ out, int M, int N, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int ld, float* __restrict__ out, int M, int N, int rows_per_block,
+                                                     float* __restrict__ part) {
   const int nch = N / 8;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= nch) return;
@@ -145,6 +183,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
     u32x4_t w = *(const u32x4_t*)(x + (size_t)m * ld + c * 8);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { acc[2 * e] += bflo(w[e]); acc[2 * e + 1] += bfhi(w[e]); }
+  }
+  if (part) {
+    float* dst = part + (size_t)blockIdx.y * N + c * 8;
+    *(f32x4_t*)dst = (f32x4_t){acc[0], acc[1], acc[2], acc[3]};
+    *(f32x4_t*)(dst + 4) = (f32x4_t){acc[4], acc[5], acc[6], acc[7]};
+    return;
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) unsafeAtomicAdd(&out[c * 8 + e], acc[e]);
@@ -282,25 +326,63 @@ extern "C" int avt_embed_pos_bwd(const void* dh, void* denc, float* dwpe, int B,
   AVT_LAUNCH_CHECK();
   return 0;
 }
-extern "C" int avt_patch_embed_bwd_reduce(const void* dx, float* dpos, float* dcls, float* dbias, int N, int S, int D, void* stream) {
+static int reduce_partials_keep(const float* part, int nslots, long n, float* const* outs, int nq, float* keep, hipStream_t stream) {
+  if (nslots <= 0 || n <= 0 || nq < 1 || nq > 4) { avt_set_error("avt_reduce_partials: bad shape"); return -1; }
+  ReduceOuts o{};
+  for (int q = 0; q < nq; ++q) o.o[q] = outs[q];
+  o.keep = keep;
+  hipLaunchKernelGGL(partials_reduce_kernel, dim3((unsigned)((n + 31) / 32), nq), dim3(1024), 0, stream, part, nslots, n, o);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+int avt_reduce_partials(const float* part, int nslots, long n, float* const* outs, int nq, hipStream_t stream) {
+  return reduce_partials_keep(part, nslots, n, outs, nq, nullptr, stream);
+}
+
+extern "C" size_t avt_patch_embed_bwd_reduce_workspace_bytes(int N, int S, int D) {
+  (void)N;
+  return (size_t)16 * (size_t)S * (size_t)D * 4;                 // at most 16 frame groups
+}
+extern "C" size_t avt_colsum_workspace_bytes(int M, int N) {
+  (void)M;
+  return (size_t)2048 * (size_t)N * 4;                           // at most 2048 row groups
+}
+
+extern "C" int avt_patch_embed_bwd_reduce(const void* dx, float* dpos, float* dcls, float* dbias, int N, int S, int D,
+                                          float* part, size_t part_bytes, void* stream) {
   AVT_CHECK(dx && dpos && dcls && dbias && N > 0 && S > 0 && D > 0 && D % 8 == 0, "avt_patch_embed_bwd_reduce: bad argument");
   AVT_CHECK(aligned16(dx), "avt_patch_embed_bwd_reduce: 16-byte alignment required");
   long total = (long)S * (D / 8);
   int gx = (int)((total + 255) / 256);
   int gy = 1024 / gx; if (gy < 1) gy = 1; if (gy > 16) gy = 16; if (gy > (N + 7) / 8) gy = (N + 7) / 8;   // few frame groups: the fp32 atomics of the groups collide
   int fpb = (N + gy - 1) / gy; gy = (N + fpb - 1) / fpb;
-  hipLaunchKernelGGL(patch_bwd_reduce_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, dpos, dcls, dbias, N, S, D, fpb);
+  AVT_CHECK(!part || (aligned16(part) && part_bytes >= (size_t)gy * S * D * 4), "avt_patch_embed_bwd_reduce: partials workspace too small or misaligned");
+  hipLaunchKernelGGL(patch_bwd_reduce_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, dpos, dcls, dbias, N, S, D, fpb, part);
   AVT_LAUNCH_CHECK();
+  if (part) {
+    // frame groups -> dpos (the per-position sums stay in slot 0), then row 0 -> dcls and rows 1.. -> dbias in row order
+    float* o1[1] = {dpos};
+    int rc = reduce_partials_keep(part, gy, (long)S * D, o1, 1, part, (hipStream_t)stream);
+    if (rc) return rc;
+    float* o2[1] = {dcls};
+    rc = avt_reduce_partials(part, 1, D, o2, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    if (S > 1) { float* o3[1] = {dbias}; rc = avt_reduce_partials(part + D, S - 1, D, o3, 1, (hipStream_t)stream); }
+    return rc;
+  }
   return 0;
 }
-extern "C" int avt_colsum_bf16(const void* x, int ld, float* out, int M, int N, void* stream) {
+extern "C" int avt_colsum_bf16(const void* x, int ld, float* out, int M, int N, float* part, size_t part_bytes, void* stream) {
   AVT_CHECK(x && out && M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "avt_colsum_bf16: N and ld must be multiples of 8");
   AVT_CHECK(aligned16(x), "avt_colsum_bf16: 16-byte alignment required");
   int nch = N / 8, gx = (nch + 255) / 256;
   int gy = 2048 / gx; if (gy < 1) gy = 1; if (gy > (M + 15) / 16) gy = (M + 15) / 16;
   int rpb = (M + gy - 1) / gy;
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, out, M, N, rpb);
+  gy = (M + rpb - 1) / rpb;
+  AVT_CHECK(!part || (aligned16(part) && part_bytes >= (size_t)gy * N * 4), "avt_colsum_bf16: partials workspace too small or misaligned");
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, out, M, N, rpb, part);
   AVT_LAUNCH_CHECK();
+  if (part) { float* o1[1] = {out}; return avt_reduce_partials(part, gy, N, o1, 1, (hipStream_t)stream); }
   return 0;
 }
 extern "C" int avt_mse_shift_fwd(const float* dec, const float* x, float* loss, int B, int T, int F, void* stream) {

@@ -31,6 +31,7 @@ namespace {
 struct GemmParams {
   const bf16_t* A; const bf16_t* B; void* C; bf16_t* C2;
   const float* bias; const bf16_t* res; const bf16_t* aux; float* colsum;
+  float* colsum_part;                      // [row slots][N] partial column sums (one row per wave row of the grid) instead of atomics
   int M, N, K;
   int lda, ldb, ldc, ldc2, ldres, ldaux;
   int res_period;
@@ -301,7 +302,7 @@ __device__ __forceinline__ void epi_row(EpiLane& e, const GemmParams& p, const f
   }
 }
 template <int WN>
-__device__ __forceinline__ void epi_flush_colsum(EpiLane& e, const GemmParams& p, int lane) {
+__device__ __forceinline__ void epi_flush_colsum(EpiLane& e, const GemmParams& p, int lane, int slot) {
   if (!p.colsum) return;
   constexpr int LPR = WN / 8;
   // lanes sharing (lane % LPR) own the same 8 columns: fold the row groups, one atomic per column
@@ -313,7 +314,10 @@ __device__ __forceinline__ void epi_flush_colsum(EpiLane& e, const GemmParams& p
   if (lane < LPR && e.ncol_ok) {
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      if (e.n + q < p.N) unsafeAtomicAdd(&p.colsum[e.n + q], e.csum[q]);
+      if (e.n + q < p.N) {
+        if (p.colsum_part) p.colsum_part[(size_t)slot * p.N + e.n + q] = e.csum[q];
+        else unsafeAtomicAdd(&p.colsum[e.n + q], e.csum[q]);
+      }
   }
 }
 // per-wave LDS of the activation epilogue: general path = fp32 patch [32][WN+4] + 2 second-operand buffers [32][WN] bf16,
@@ -563,8 +567,14 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
       for (int o = LPR; o < 64; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
     }
     if (lane < LPR && col0 + cl < p.N) {
+      if (p.colsum_part) {
+        float* dst = p.colsum_part + (size_t)(row0 / (TM * 32)) * p.N + col0 + cl;
+        *(f32x4_t*)dst = (f32x4_t){cs[0], cs[1], cs[2], cs[3]};
+        *(f32x4_t*)(dst + 4) = (f32x4_t){cs[4], cs[5], cs[6], cs[7]};
+      } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) unsafeAtomicAdd(&p.colsum[col0 + cl + q], cs[q]);
+        for (int q = 0; q < 8; ++q) unsafeAtomicAdd(&p.colsum[col0 + cl + q], cs[q]);
+      }
     }
   }
 }
@@ -687,7 +697,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
       for (int itr = 0; itr < IT; ++itr)
         epi_row(e, p, rows[itr], row0 + i * 32 + itr * RPI + rl, prim[itr], staged);
     }
-    epi_flush_colsum<WN>(e, p, lane);
+    epi_flush_colsum<WN>(e, p, lane, row0 / WM);
   }
 }
 
@@ -1593,12 +1603,13 @@ int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
 
 }  // namespace
 
+static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kmajor, int splitk, int K, hipStream_t s);
 static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,
                      void* C, int ldc, int M, int N, int K,
                      const float* bias, int act, const void* aux, int ldaux,
                      void* C2, int ldc2, const void* res, int ldres, int res_period,
                      float drop_p, uint64_t drop_seed, float* colsum,
-                     int out_mode, int splitk, int tile, void* ws, size_t ws_bytes, void* stream) {
+                     int out_mode, int splitk, int tile, void* ws, size_t ws_bytes, float* part, size_t part_bytes, void* stream) {
   AVT_CHECK(A && B && C, "avt_gemm_bf16: null operand");
   AVT_CHECK(M > 0 && N > 0 && K > 0, "avt_gemm_bf16: bad dims M=%d N=%d K=%d", M, N, K);
   AVT_CHECK(aligned16(A) && aligned16(B) && aligned16(C), "avt_gemm_bf16: operands must be 16-byte aligned");
@@ -1648,6 +1659,30 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
   }
   if (tile == 0 && bm == 256 && (K % 64 == 0 || (!a_kmajor && !b_kmajor))) bm = 808;       // default big-tile kernel: the 8-phase schedule
   if (tile == 0 && bm == 64 && epi == 0 && a_kmajor && b_kmajor) bm = 643;                   // all-k-major small outputs: 3-deep ring (+15-25 % on the head's data gradients)
+  int nslots = 0;
+  if (colsum && part) {
+    // one partial row per wave row of the grid: every tile shape here has two wave rows per tile
+    const int BM = (bm == 64 || bm == 643) ? 64 : (bm == 128 ? 128 : 256);
+    nslots = ((M + BM - 1) / BM) * 2;
+    AVT_CHECK(aligned16(part) && part_bytes >= (size_t)nslots * N * 4, "avt_gemm_bf16: partials workspace too small or misaligned (%zu bytes needed)", (size_t)nslots * N * 4);
+    p.colsum_part = part;
+  }
+  int rc = gemm_dispatch(p, bm, epi, a_kmajor, b_kmajor, splitk, K, s);
+  if (rc == 0 && nslots) { float* outs[1] = {colsum}; rc = avt_reduce_partials(part, nslots, N, outs, 1, s); }
+  return rc;
+}
+
+extern "C" size_t avt_gemm_colsum_workspace_bytes(int M, int N, int tile) {
+  // mirrors gemm_impl's automatic tile choice for the activation epilogue; two wave rows per tile
+  int BM = (tile == 64 || tile == 643) ? 64 : (tile == 128 ? 128 : 256);
+  if (tile == 0) {
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256), t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    BM = (t256 >= 200) ? 256 : (t128 >= 192 ? 128 : 64);
+  }
+  return (size_t)(((M + BM - 1) / BM) * 2) * (size_t)N * 4;
+}
+
+static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kmajor, int splitk, int K, hipStream_t s) {
   switch (bm) {
     case 64:  return dispatch_epi<64, 64, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 128: return dispatch_epi<128, 128, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
@@ -1665,7 +1700,7 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
 #endif
     default: break;
   }
-  avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 64, 128, 643, 256 / 2568 (one barrier per K tile) or 808 (8-phase) (got %d)", tile);
+  avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 64, 128, 643, 256 / 2568 (one barrier per K tile) or 808 (8-phase) (got %d)", bm);
   return -1;
 }
 
@@ -1674,16 +1709,16 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
                              const float* bias, int act, const void* aux, int ldaux,
                              void* C2, int ldc2, const void* res, int ldres, int res_period,
                              float drop_p, uint64_t drop_seed, float* colsum,
-                             int out_mode, int splitk, int tile, void* stream) {
+                             int out_mode, int splitk, int tile, float* part, size_t part_bytes, void* stream) {
   AVT_CHECK(out_mode != 3, "avt_gemm_bf16: out_mode must be 0 (bf16), 1 (fp32) or 2 (fp32 atomic accumulate)");
   return gemm_impl(A, a_kmajor, lda, B, b_kmajor, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, C2, ldc2, res, ldres, res_period,
-                   drop_p, drop_seed, colsum, out_mode, splitk, tile, nullptr, 0, stream);
+                   drop_p, drop_seed, colsum, out_mode, splitk, tile, nullptr, 0, part, part_bytes, stream);
 }
 
 extern "C" int avt_gemm_accum_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                                    int splitk, int tile, void* workspace, size_t workspace_bytes, void* stream) {
   return gemm_impl(A, 0, lda, B, 0, ldb, C, ldc, M, N, K, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, nullptr,
-                   3, splitk, tile, workspace, workspace_bytes, stream);
+                   3, splitk, tile, workspace, workspace_bytes, nullptr, 0, stream);
 }
 
 extern "C" size_t avt_gemm_accum_workspace_bytes(int M, int N, int K) {

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256, MINW) void ln_bwd_kernel(const bf16_t* __restr
                                                      const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                      const float* __restrict__ gamma, const bf16_t* __restrict__ dres, int lddres,
                                                      bf16_t* __restrict__ dx, int lddx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, float* __restrict__ colsum, int rows, int D) {
+                                                     float* __restrict__ dbeta, float* __restrict__ colsum, int rows, int D,
+                                                     float* __restrict__ part) {
   __shared__ float red[3][4][64 * 8];    // [quantity][wave][lane*8+e] scratch for one chunk column at a time
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -198,11 +199,16 @@ __global__ __launch_bounds__(256, MINW) void ln_bwd_kernel(const bf16_t* __restr
       if (cc < nchunk) {
         float sg = red[0][0][idx] + red[0][1][idx] + red[0][2][idx] + red[0][3][idx];
         float sb = red[1][0][idx] + red[1][1][idx] + red[1][2][idx] + red[1][3][idx];
-        if (dgamma) unsafeAtomicAdd(&dgamma[cc * 8 + e], sg);
-        if (dbeta) unsafeAtomicAdd(&dbeta[cc * 8 + e], sb);
-        if (colsum) {
-          float sc = red[2][0][idx] + red[2][1][idx] + red[2][2][idx] + red[2][3][idx];
-          unsafeAtomicAdd(&colsum[cc * 8 + e], sc);
+        float sc = colsum ? red[2][0][idx] + red[2][1][idx] + red[2][2][idx] + red[2][3][idx] : 0.f;
+        if (part) {                                    // one partial vector per workgroup and quantity, merged in fixed order afterwards
+          const size_t qs = (size_t)gridDim.x * D;
+          float* dst = part + (size_t)blockIdx.x * D + cc * 8 + e;
+          dst[0] = sg; dst[qs] = sb;
+          if (colsum) dst[2 * qs] = sc;
+        } else {
+          if (dgamma) unsafeAtomicAdd(&dgamma[cc * 8 + e], sg);
+          if (dbeta) unsafeAtomicAdd(&dbeta[cc * 8 + e], sb);
+          if (colsum) unsafeAtomicAdd(&colsum[cc * 8 + e], sc);
         }
       }
     }
@@ -308,7 +314,8 @@ extern "C" int avt_layernorm_fwd(const void* x, int ldx, const float* gamma, con
 
 extern "C" int avt_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
                                  const float* gamma, const void* dres, int lddres, void* dx, int lddx,
-                                 float* dgamma, float* dbeta, float* colsum, int rows, int D, void* stream) {
+                                 float* dgamma, float* dbeta, float* colsum, int rows, int D,
+                                 float* part, size_t part_bytes, void* stream) {
   AVT_CHECK(dy && x && mean && rstd && gamma && dx, "avt_layernorm_bwd: null argument");
   AVT_CHECK(rows > 0 && D > 0 && D % 8 == 0 && D <= 64 * 8 * MAXV, "avt_layernorm_bwd: D must be a multiple of 8 and <= 4096 (D=%d)", D);
   AVT_CHECK(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && (!dres || lddres % 8 == 0), "avt_layernorm_bwd: leading dims must be multiples of 8");
@@ -321,17 +328,28 @@ extern "C" int avt_layernorm_bwd(const void* dy, int lddy, const void* x, int ld
     // D = 768 / 1024: three waves per SIMD without the software prefetch (150 VGPRs) beat two waves with it (175 VGPRs):
     // 300 vs 364 us at 252160 x 768 -- more rows in flight per CU than the one-row-ahead pipeline gave
     int g = (rows + 3) / 4; if (g > 768) g = 768;
+    grid = g;
+    AVT_CHECK(!part || part_bytes >= (size_t)3 * grid * D * 4, "avt_layernorm_bwd: partials workspace too small");
     hipLaunchKernelGGL((ln_bwd_kernel<2, 3, false>), dim3(g), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma,
-                       (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, dgamma, dbeta, colsum, rows, D);
+                       (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, dgamma, dbeta, colsum, rows, D, part);
     AVT_LAUNCH_CHECK();
-    return 0;
-  }
-#define LN_BWD(V) hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, dgamma, dbeta, colsum, rows, D)
-  switch (pick_v(D)) {
-    case 1: LN_BWD(1); break; case 3: LN_BWD(3); break; case 4: LN_BWD(4); break;
-    case 5: LN_BWD(5); break; case 6: LN_BWD(6); break; case 7: LN_BWD(7); break; default: LN_BWD(8); break;
-  }
+  } else {
+    AVT_CHECK(!part || part_bytes >= (size_t)3 * grid * D * 4, "avt_layernorm_bwd: partials workspace too small");
+#define LN_BWD(V) hipLaunchKernelGGL((ln_bwd_kernel<V>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma, (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, dgamma, dbeta, colsum, rows, D, part)
+    switch (pick_v(D)) {
+      case 1: LN_BWD(1); break; case 3: LN_BWD(3); break; case 4: LN_BWD(4); break;
+      case 5: LN_BWD(5); break; case 6: LN_BWD(6); break; case 7: LN_BWD(7); break; default: LN_BWD(8); break;
+    }
 #undef LN_BWD
-  AVT_LAUNCH_CHECK();
+    AVT_LAUNCH_CHECK();
+  }
+  if (part) {
+    float* outs[3] = {dgamma, dbeta, colsum};
+    return avt_reduce_partials(part, grid, D, outs, colsum ? 3 : 2, s);
+  }
   return 0;
+}
+extern "C" size_t avt_layernorm_bwd_workspace_bytes(int rows, int D) {
+  (void)rows;
+  return (size_t)3 * 768 * (size_t)D * 4;                          // at most 768 workgroups x {dgamma, dbeta, colsum}
 }

@@ -228,12 +228,15 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
 //     barrier 2 (Q, dO landed; nobody reads K/V tiles any more)  ->  request K, V of the NEXT item
 //     phase B: dK, dV of this wave's 16 keys (needs the Q, dO tiles + own K / V strips, taken before barrier 2)
 // so the global -> LDS latency of every tile hides behind the other phase.  Column sums of dq|dk|dv (the qkv bias gradient)
-// are kept in LDS per head for the whole kernel and flushed once.
+// are kept in LDS per head for the whole kernel and flushed once.  Every wave stores the sums of its strip into its own row of
+// a staging array; after the next barrier the rows are added in wave order by the column's owner thread, so the per-workgroup
+// sums do not depend on which wave arrived first.  The flush stores one partial vector per workgroup when the caller gave a
+// partials workspace (merged in fixed order by avt_reduce_partials: bit-identical from run to run), else fp32 atomics.
 template <int NKT, bool ALL_LIVE>
 __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                 const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                 bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
-                                                                int S, int H, int items, float scale, long long* dbg) {
+                                                                float* __restrict__ part, int S, int H, int items, float scale, long long* dbg) {
   long long tcs = 0, tca = 0, tcb = 0, tc0 = dbg ? __builtin_readcyclecounter() : 0;
   constexpr int NP = (NKT + 1) / 2;
   constexpr int KP = NP * 32;                // rows of every LDS tile (zero padded)
@@ -249,6 +252,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
   float* lse_s = (float*)(smem + 4 * RM);    // lse * log2(e)
   float* dq_s = lse_s + KP;                  // D[q] * scale,  D[q] = sum_d dO[q,d] O[q,d]
   float* bias_s = dq_s + KP;                 // [H][3*64] column sums of dq | dk | dv
+  float* stage_s = bias_s + H * 192;         // [NKT][3*64] this item's sums per wave
+  int prev_head = -1;
   const int D = H * HD, ld = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = 64 * NKT;
   const int g = lane >> 4;
@@ -296,6 +301,15 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
     // a wave may have skipped them and the count would be wrong -> wait for everything)
     if (ALL_LIVE) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // barrier 1
+    if (dbias && prev_head >= 0) {                         // dk | dv sums of the previous item, in wave order
+      for (int c = 64 + tid; c < 192; c += nthr) {
+        float t = bias_s[prev_head * 192 + c];
+#pragma unroll
+        for (int w = 0; w < NKT; ++w) t += stage_s[w * 192 + c];
+        bias_s[prev_head * 192 + c] = t;
+      }
+    }
+    prev_head = head;
     stage_head_dma(base, ld, S, Qs, KP, wv, NKT, lane);
     stage_head_dma(dobase, D, S, dOs, KP, wv, NKT, lane);
     for (int i = tid; i < KP; i += nthr) lse_s[i] = (i < S) ? lse_g[i] * LOG2E : 0.f;
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v = lsum16((q < S) ? acc[dt][r] : 0.f);
-            if ((lane & 15) == 0) atomicAdd(&bias_h[dt * 16 + 4 * g + r], v);
+            if ((lane & 15) == 0) stage_s[wave * 192 + dt * 16 + 4 * g + r] = v;
           }
         }
       }
@@ -366,6 +380,14 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
     bv[0] = frag_rm(Vs, wave, 0, lane); bv[1] = frag_rm(Vs, wave, 1, lane);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // Q, dO landed (this wave's share); strips are in registers
     __syncthreads();                                                // barrier 2
+    if (dbias) {                                                    // dq sums of this item, in wave order
+      for (int c = tid; c < 64; c += nthr) {
+        float t = bias_h[c];
+#pragma unroll
+        for (int w = 0; w < NKT; ++w) t += stage_s[w * 192 + c];
+        bias_h[c] = t;
+      }
+    }
     if (item + gridDim.x < items) {
       const int nitem = item + gridDim.x;
       const bf16_t* nbase = qkv + (size_t)(nitem / H) * S * ld + (nitem % H) * HD;
@@ -427,7 +449,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
           for (int r = 0; r < 4; ++r) {
             float vk = lsum16((key < S) ? adk[dt][r] : 0.f);
             float vv = lsum16((key < S) ? adv[dt][r] : 0.f);
-            if ((lane & 15) == 0) { atomicAdd(&bias_h[64 + dt * 16 + 4 * g + r], vk); atomicAdd(&bias_h[128 + dt * 16 + 4 * g + r], vv); }
+            if ((lane & 15) == 0) { stage_s[wave * 192 + 64 + dt * 16 + 4 * g + r] = vk; stage_s[wave * 192 + 128 + dt * 16 + 4 * g + r] = vv; }
           }
         }
       }
@@ -437,10 +459,21 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
   }
   if (dbias) {
     __syncthreads();
+    if (prev_head >= 0) {
+      for (int c = 64 + tid; c < 192; c += nthr) {
+        float t = bias_s[prev_head * 192 + c];
+#pragma unroll
+        for (int w = 0; w < NKT; ++w) t += stage_s[w * 192 + c];
+        bias_s[prev_head * 192 + c] = t;
+      }
+    }
+    __syncthreads();
     for (int i = tid; i < H * 192; i += nthr) {
       const int hh = i / 192, c = i % 192;
       const float v = bias_s[i];
-      if (v != 0.f) unsafeAtomicAdd(&dbias[(c >> 6) * D + hh * HD + (c & 63)], v);
+      const int o = (c >> 6) * D + hh * HD + (c & 63);
+      if (part) part[(size_t)blockIdx.x * (3 * D) + o] = v;
+      else if (v != 0.f) unsafeAtomicAdd(&dbias[o], v);
     }
   }
   if (dbg && lane == 0) {
@@ -452,7 +485,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
 int pick_nkt(int S) { int n = (S + 15) / 16; if (n <= 1) return 1; if (n <= 2) return 2; if (n <= 4) return 4; if (n <= 8) return 8; return 13; }
 
 template <int NKT> size_t fwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128; }     // K, V x 2 buffers
-template <int NKT> size_t bwd_smem(int H) { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128 + (size_t)(2 * NP * 32 + H * 192) * 4; }
+template <int NKT> size_t bwd_smem(int H) { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128 + (size_t)(2 * NP * 32 + H * 192 + NKT * 192) * 4; }
 
 template <int NKT>
 int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, int H, float scale, hipStream_t s) {
@@ -470,7 +503,7 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, in
 }
 template <int NKT>
 int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, float* dbias,
-               int frames, int S, int H, float scale, hipStream_t s) {
+               float* part, size_t part_bytes, int frames, int S, int H, float scale, hipStream_t s) {
   size_t sm = bwd_smem<NKT>(H);
   if (sm > 160 * 1024) { avt_set_error("avt_vit_attn_bwd: H = %d needs more LDS than a CU has", H); return -1; }
   (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -487,8 +520,11 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
   const int per_cu = (int)((160 * 1024) / sm) < 1 ? 1 : (int)((160 * 1024) / sm);
   int grid = 256 * (per_cu > 8 ? 8 : per_cu);
   if (grid > items) grid = items;
-  if (all_live) hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT, true>), dim3(grid), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, S, H, items, scale, dbg);
-  else hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT, false>), dim3(grid), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, S, H, items, scale, dbg);
+  if (!dbias) part = nullptr;
+  if (part && part_bytes < (size_t)grid * 3 * H * HD * 4) { avt_set_error("avt_vit_attn_bwd: partials workspace too small"); return -1; }
+  if (all_live) hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT, true>), dim3(grid), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, part, S, H, items, scale, dbg);
+  else hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT, false>), dim3(grid), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, part, S, H, items, scale, dbg);
+  if (part) { float* outs[1] = {dbias}; return avt_reduce_partials(part, grid, 3L * H * HD, outs, 1, s); }
   return 0;
 }
 
@@ -512,8 +548,12 @@ extern "C" int avt_vit_attn_fwd(const void* qkv, void* out, float* lse, int fram
   return 0;
 }
 
+extern "C" size_t avt_vit_attn_bwd_workspace_bytes(int frames, int S, int H) {
+  (void)frames; (void)S;
+  return (size_t)2048 * 3 * (size_t)H * HD * 4;                   // at most 256 x 8 persistent workgroups
+}
 extern "C" int avt_vit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
-                                int frames, int S, int H, int head_dim, float scale, void* stream) {
+                                int frames, int S, int H, int head_dim, float scale, float* part, size_t part_bytes, void* stream) {
   AVT_CHECK(qkv && out && dout && lse && dqkv, "avt_vit_attn_bwd: null argument");
   AVT_CHECK(head_dim == 64, "avt_vit_attn_bwd: head_dim must be 64 (got %d)", head_dim);
   AVT_CHECK(S >= 1 && S <= 208, "avt_vit_attn_bwd: S must be in [1, 208] (got %d)", S);
@@ -522,11 +562,11 @@ extern "C" int avt_vit_attn_bwd(const void* qkv, const void* out, const void* do
   const bf16_t* q = (const bf16_t*)qkv; const bf16_t* o = (const bf16_t*)out; const bf16_t* d = (const bf16_t*)dout; bf16_t* dq = (bf16_t*)dqkv;
   int rc = 0;
   switch (pick_nkt(S)) {
-    case 1: rc = launch_bwd<1>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
-    case 2: rc = launch_bwd<2>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
-    case 4: rc = launch_bwd<4>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
-    case 8: rc = launch_bwd<8>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
-    default: rc = launch_bwd<13>(q, o, d, lse, dq, dbias, frames, S, H, scale, s); break;
+    case 1: rc = launch_bwd<1>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s); break;
+    case 2: rc = launch_bwd<2>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s); break;
+    case 4: rc = launch_bwd<4>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s); break;
+    case 8: rc = launch_bwd<8>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s); break;
+    default: rc = launch_bwd<13>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s); break;
   }
   if (rc) return rc;
   AVT_LAUNCH_CHECK();

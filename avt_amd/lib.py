@@ -9,20 +9,20 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AVT_HIP_LIB') or os.path.join(_HERE, 'libavt_hip.so')      # AVT_HIP_LIB: A/B a differently built library (lab use)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
-_P, _I, _F, _L, _U64 = c_void_p, c_int, c_float, c_long, c_uint64
+_P, _I, _F, _L, _U64, _SZ = c_void_p, c_int, c_float, c_long, c_uint64, ctypes.c_size_t
 
 # name -> argtypes (restype is int unless noted); must mirror include/avt_hip.h exactly
 SIGNATURES = {
     'avt_abi_version': [],
     'avt_gemm_bf16': [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _U64, _P,
-                      _I, _I, _I, _P],
+                      _I, _I, _I, _P, _SZ, _P],
     'avt_gemm_accum_bf16': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, ctypes.c_size_t, _P],
     'avt_layernorm_fwd': [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P],
-    'avt_layernorm_bwd': [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P],
+    'avt_layernorm_bwd': [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _SZ, _P],
     'avt_vit_attn_fwd': [_P, _P, _P, _I, _I, _I, _I, _F, _P],
-    'avt_vit_attn_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    'avt_vit_attn_bwd': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _SZ, _P],
     'avt_causal_attn_fwd': [_P, _P, _P, _I, _I, _I, _I, _F, _F, _U64, _P],
     'avt_causal_attn_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _U64, _P],
     'avt_head_attn_fwd': [_P, _P, _P, _I, _I, _I, _I, _F, _F, _U64, _I, _P],
@@ -31,13 +31,13 @@ SIGNATURES = {
     'avt_transpose_bf16': [_P, _L, _P, _L, _I, _I, _P],
     'avt_im2col_patch16': [_P, _P, _I, _I, _I, _P],
     'avt_posres_prep': [_P, _P, _P, _P, _I, _I, _P],
-    'avt_patch_embed_bwd_reduce': [_P, _P, _P, _P, _I, _I, _I, _P],
+    'avt_patch_embed_bwd_reduce': [_P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P],
     'avt_cast_f32_to_bf16': [_P, _P, _L, _P],
     'avt_cast_bf16_to_f32': [_P, _P, _L, _P],
     'avt_dropout_bf16': [_P, _P, _L, _F, _U64, _P],
     'avt_embed_pos_fwd': [_P, _P, _P, _I, _I, _I, _F, _U64, _P],
     'avt_embed_pos_bwd': [_P, _P, _P, _I, _I, _I, _F, _U64, _P],
-    'avt_colsum_bf16': [_P, _I, _P, _I, _I, _P],
+    'avt_colsum_bf16': [_P, _I, _P, _I, _I, _P, _SZ, _P],
     'avt_mse_shift_fwd': [_P, _P, _P, _I, _I, _I, _P],
     'avt_mse_shift_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     'avt_pad_cast_f32_to_bf16': [_P, _I, _P, _I, _I, _I, _P],
@@ -52,6 +52,17 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+# workspace-size queries (return size_t, cannot fail)
+SIZE_QUERIES = {
+    'avt_gemm_accum_workspace_bytes': [_I, _I, _I],
+    'avt_gemm_colsum_workspace_bytes': [_I, _I, _I],
+    'avt_layernorm_bwd_workspace_bytes': [_I, _I],
+    'avt_vit_attn_bwd_workspace_bytes': [_I, _I, _I],
+    'avt_patch_embed_bwd_reduce_workspace_bytes': [_I, _I, _I],
+    'avt_colsum_workspace_bytes': [_I, _I],
+}
 
 
 class AvtHipError(RuntimeError):
@@ -74,8 +85,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = c_int
-    lib.avt_gemm_accum_workspace_bytes.restype = ctypes.c_size_t
-    lib.avt_gemm_accum_workspace_bytes.argtypes = [_I, _I, _I]
+    for name, argtypes in SIZE_QUERIES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_size_t
     v = lib.avt_abi_version()
     if v != ABI_VERSION:
         raise AvtHipError(f'libavt_hip.so ABI version {v} != binding version {ABI_VERSION}')

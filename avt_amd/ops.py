@@ -58,6 +58,26 @@ def _chk(t, dtype, name):
         raise _lib.AvtHipError(f'{name} must be {dtype}, got {t.dtype}')
 
 
+# ---- run-to-run identical bias / LayerNorm / embedding gradients ---------------------------------------------------------
+# True: every kernel that folds many workgroups into one fp32 vector stores per-workgroup partials into a scratch workspace
+# and a second kernel adds them in a fixed order (include/avt_hip.h, "partials").  False: fp32 atomics (arrival order).
+DETERMINISTIC_REDUCTIONS = True
+_PART_WS = {}                    # (device index, stream) -> fp32 scratch shared by all calls on that stream (they are ordered)
+
+
+def _partials(device, query, *dims):
+    """(pointer, bytes) of the partials workspace for one call, or (None, 0) with the atomics path selected."""
+    if not DETERMINISTIC_REDUCTIONS:
+        return None, 0
+    need = getattr(_lib.load(), query)(*dims)
+    key = (device.index, _stream())
+    ws = _PART_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 16 << 20), device=device, dtype=torch.uint8)
+        _PART_WS[key] = ws
+    return ws.data_ptr(), ws.numel()
+
+
 def _ld(t):
     """Leading dimension (elements) of a 2-D row-major view with unit inner stride."""
     assert t.dim() == 2 and t.stride(1) == 1, 'expected a 2-D tensor with unit inner stride'
@@ -77,10 +97,11 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
     if trace is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
+    part, part_bytes = _partials(A.device, 'avt_gemm_colsum_workspace_bytes', M, N, tile) if colsum is not None else (None, 0)
     _lib.call('avt_gemm_bf16', _p(A), int(a_kmajor), _ld(A), _p(B), int(b_kmajor), _ld(B), _p(out), _ld(out), M, N, K,
               _p(bias), act, _p(aux), _ld(aux) if aux is not None else 0, _p(c2), _ld(c2) if c2 is not None else 0,
               _p(res), _ld(res) if res is not None else 0, res_period, float(drop_p), int(seed), _p(colsum),
-              out_mode, splitk, tile, _stream())
+              out_mode, splitk, tile, part, part_bytes, _stream())
     if trace is not None:
         ev1.record()
         trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile), 2.0 * M * N * K, ev0, ev1))
@@ -178,8 +199,10 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, colsum=
     if dx is None:
         dx = torch.empty((rows, D), device=x.device, dtype=BF16)
         lddx = D
+    part, part_bytes = _partials(x.device, 'avt_layernorm_bwd_workspace_bytes', rows, D)
     _lib.call('avt_layernorm_bwd', _p(dy), _ld(dy), _p(x), ldx, _p(mean), _p(rstd), _p(gamma), _p(dres),
-              _ld(dres) if dres is not None else 0, _p(dx), lddx, _p(dgamma), _p(dbeta), _p(colsum), rows, D, _stream())
+              _ld(dres) if dres is not None else 0, _p(dx), lddx, _p(dgamma), _p(dbeta), _p(colsum), rows, D,
+              part, part_bytes, _stream())
     return dx
 
 
@@ -195,7 +218,9 @@ def vit_attn_fwd(qkv, frames, S, H):
 
 def vit_attn_bwd(qkv, out, dout, lse, frames, S, H, dbias=None):
     dqkv = torch.empty_like(qkv)
-    _lib.call('avt_vit_attn_bwd', _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(dbias), frames, S, H, 64, 0.125, _stream())
+    part, part_bytes = _partials(qkv.device, 'avt_vit_attn_bwd_workspace_bytes', frames, S, H) if dbias is not None else (None, 0)
+    _lib.call('avt_vit_attn_bwd', _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(dbias), frames, S, H, 64, 0.125,
+              part, part_bytes, _stream())
     return dqkv
 
 
@@ -276,7 +301,8 @@ def posres_prep(pos, cls, bias, S, D):
 
 
 def patch_embed_bwd_reduce(dx0, dpos, dcls, dbias, N, S, D):
-    _lib.call('avt_patch_embed_bwd_reduce', _p(dx0), _p(dpos), _p(dcls), _p(dbias), N, S, D, _stream())
+    part, part_bytes = _partials(dx0.device, 'avt_patch_embed_bwd_reduce_workspace_bytes', N, S, D)
+    _lib.call('avt_patch_embed_bwd_reduce', _p(dx0), _p(dpos), _p(dcls), _p(dbias), N, S, D, part, part_bytes, _stream())
 
 
 # ---- elementwise ---------------------------------------------------------------------------------------------------------
@@ -316,7 +342,8 @@ def embed_pos_bwd(dh, dwpe, B, T, E, p, seed):
 
 def colsum(x, out):
     _chk(x, BF16, 'x')
-    _lib.call('avt_colsum_bf16', _p(x), _ld(x), _p(out), x.size(0), x.size(1), _stream())
+    part, part_bytes = _partials(x.device, 'avt_colsum_workspace_bytes', x.size(0), x.size(1))
+    _lib.call('avt_colsum_bf16', _p(x), _ld(x), _p(out), x.size(0), x.size(1), part, part_bytes, _stream())
 
 
 def mse_shift_fwd(dec, x):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 2
+#define AVT_ABI_VERSION 3
 
 const char* avt_last_error(void);
 int avt_abi_version(void);
@@ -45,7 +45,7 @@ int avt_abi_version(void);
  *     v = acc + bias[n];  act 3: v *= aux[m,n] (backward of an activation whose derivative was saved);
  *     act 1|2: C2[m,n] = gelu_erf'|gelu_tanh'(v) (optional, saved for backward), v = gelu_erf|gelu_tanh(v);
  *     act 0 with C2: C2[m,n] = v;  dropout(drop_p, drop_seed, element index m*N+n);
- *     v += res[(res_period ? m % res_period : m), n];  colsum[n] += v (fp32 atomics; over the bf16-rounded values when C is bf16);  C[m,n] = v
+ *     v += res[(res_period ? m % res_period : m), n];  colsum[n] += v (over the bf16-rounded values when C is bf16; see "partials" below);  C[m,n] = v
  * out_mode 2: C (fp32) += acc with atomics, no epilogue; splitk > 1 splits the reduction over workgroups
  *             (splitk <= 0 picks a factor that fills the chip).  Used for weight gradients.
  * tile: 0 = choose; 64 | 128 | 256 | 808 (256x256 tile, 8-phase schedule) force a kernel.  Requirements: 16-B aligned pointers, lda/ldb % 8 == 0,
@@ -55,7 +55,17 @@ int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kma
                   const float* bias, int act, const void* aux, int ldaux,
                   void* C2, int ldc2, const void* res, int ldres, int res_period,
                   float drop_p, uint64_t drop_seed, float* colsum,
-                  int out_mode, int splitk, int tile, void* stream);
+                  int out_mode, int splitk, int tile, float* partials, size_t partials_bytes, void* stream);
+size_t avt_gemm_colsum_workspace_bytes(int M, int N, int tile);
+
+/* ---- "partials": run-to-run identical parameter gradients ----------------------------------------------------------
+ * Every entry point that folds many workgroups into one fp32 vector (colsum of avt_gemm_bf16, dgamma / dbeta / colsum of
+ * avt_layernorm_bwd, dbias of avt_vit_attn_bwd, avt_colsum_bf16, avt_patch_embed_bwd_reduce) takes a `partials` workspace
+ * (16-byte aligned fp32, `partials_bytes` long; the matching *_workspace_bytes query gives an upper bound).  NULL: the
+ * workgroups merge with fp32 atomics, so the last bits of the result depend on arrival order.  Non-NULL: every workgroup stores
+ * its partial vector, and a second kernel adds them in an order that depends on the problem shape only, then accumulates into
+ * the destination -- two runs on the same inputs give the same bits.  The workspace is scratch: it may be shared by all calls
+ * on one stream.  (PyTorch's own autograd uses atomics for none of these reductions either.) */
 
 /* Deterministic weight-gradient accumulate: C[M,N] (fp32) += sum_k A[k,m] * B[k,n] with BOTH operands stored reduction-index-
  * major (dW = dy^T x of a Linear, x^T dy of an HF Conv1D).  Same kernels as out_mode 2, but every (split, tile) workgroup
@@ -74,7 +84,9 @@ int avt_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* b
                       float* mean, float* rstd, int rows, int D, float eps, void* stream);
 int avt_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* mean, const float* rstd,
                       const float* gamma, const void* dres, int lddres, void* dx, int lddx,
-                      float* dgamma, float* dbeta, float* colsum, int rows, int D, void* stream);
+                      float* dgamma, float* dbeta, float* colsum, int rows, int D,
+                      float* partials, size_t partials_bytes, void* stream);
+size_t avt_layernorm_bwd_workspace_bytes(int rows, int D);
 
 /* ---- ViT spatial attention core ----------------------------------------------------------------------------------
  * [timm] Attention.forward: softmax(q k^T * scale) v per (frame, head); qkv [frames*S, 3*H*64] with columns [q|k|v]
@@ -82,7 +94,8 @@ int avt_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const fl
  * bwd writes dqkv (same layout) and accumulates dbias[3*H*64] += column sums of dqkv (may be NULL). */
 int avt_vit_attn_fwd(const void* qkv, void* out, float* lse, int frames, int S, int H, int head_dim, float scale, void* stream);
 int avt_vit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
-                     int frames, int S, int H, int head_dim, float scale, void* stream);
+                     int frames, int S, int H, int head_dim, float scale, float* partials, size_t partials_bytes, void* stream);
+size_t avt_vit_attn_bwd_workspace_bytes(int frames, int S, int H);
 
 /* ---- single-query attention ---------------------------------------------------------------------------------------
  * avt_cls_attn_*: the LAST ViT block's attention for the CLS query only.  [timm] VisionTransformer.forward_features returns
@@ -121,7 +134,9 @@ int avt_head_attn_bwd(const void* qkv, const float* probs, const void* dout, voi
  * avt_patch_embed_bwd_reduce: dx0 bf16 [N,S,D] -> dpos[S,D] += sum_n; dcls[D] += row 0; dbias[D] += rows >= 1. */
 int avt_im2col_patch16(const float* video, void* patches, int N, int Himg, int Wimg, void* stream);
 int avt_posres_prep(const float* pos, const float* cls, const float* bias, void* R, int S, int D, void* stream);
-int avt_patch_embed_bwd_reduce(const void* dx, float* dpos, float* dcls, float* dbias, int N, int S, int D, void* stream);
+int avt_patch_embed_bwd_reduce(const void* dx, float* dpos, float* dcls, float* dbias, int N, int S, int D,
+                               float* partials, size_t partials_bytes, void* stream);
+size_t avt_patch_embed_bwd_reduce_workspace_bytes(int N, int S, int D);
 
 /* ---- elementwise ---------------------------------------------------------------------------------------------------
  * casts (bf16 shadow of fp32 parameters), dropout (nn.Dropout, models/base_model.py:81,204,215; also its own backward),
@@ -136,7 +151,8 @@ int avt_cast_bf16_to_f32(const void* src, float* dst, long n, void* stream);
 int avt_dropout_bf16(const void* x, void* y, long n, float p, uint64_t seed, void* stream);
 int avt_embed_pos_fwd(const void* enc, const float* wpe, void* h, int B, int T, int E, float p, uint64_t seed, void* stream);
 int avt_embed_pos_bwd(const void* dh, void* denc, float* dwpe, int B, int T, int E, float p, uint64_t seed, void* stream);
-int avt_colsum_bf16(const void* x, int ld, float* out, int M, int N, void* stream);
+int avt_colsum_bf16(const void* x, int ld, float* out, int M, int N, float* partials, size_t partials_bytes, void* stream);
+size_t avt_colsum_workspace_bytes(int M, int N);
 int avt_mse_shift_fwd(const float* dec, const float* x, float* loss, int B, int T, int F, void* stream);
 int avt_mse_shift_bwd(const float* dec, const float* x, const float* gloss, float* ddec, float* dx, int B, int T, int F,
                       void* stream);

@@ -19,7 +19,7 @@ def test_abi_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, 'include', 'avt_hip.h')).read()
     declared = set(re.findall(r'^(?:int|size_t|const char\*)\s+(avt_\w+)\s*\(', header, flags=re.M))
     assert declared, 'no declarations parsed'
-    bound = set(lib.SIGNATURES) | {'avt_last_error', 'avt_gemm_accum_workspace_bytes'}
+    bound = set(lib.SIGNATURES) | set(lib.SIZE_QUERIES) | {'avt_last_error'}
     assert declared == bound, declared ^ bound
     l = lib.load()                       # dlopen; getattr on every symbol; ABI version check
     for name in declared:
@@ -30,13 +30,18 @@ def test_abi_library_exports_every_declared_symbol():
         m = re.search(r'int\s+' + name + r'\s*\((.*?)\);', header, flags=re.S)
         args = [a for a in m.group(1).split(',') if a.strip() and a.strip() != 'void']
         assert len(args) == len(lib.SIGNATURES[name]), (name, len(args), len(lib.SIGNATURES[name]))
+    for name in lib.SIZE_QUERIES:
+        m = re.search(r'size_t\s+' + name + r'\s*\((.*?)\);', header, flags=re.S)
+        args = [a for a in m.group(1).split(',') if a.strip() and a.strip() != 'void']
+        assert len(args) == len(lib.SIZE_QUERIES[name]), (name, len(args))
+        assert getattr(l, name)(*([64] * len(args))) > 0
 
 
 def test_host_side_validation_rejects_bad_calls_without_a_gpu():
     """Shape/alignment violations are rejected on the host before any launch (no GPU needed to see the error)."""
     from avt_amd import lib
     with pytest.raises(lib.AvtHipError, match='null operand'):
-        lib.call('avt_gemm_bf16', None, 1, 8, None, 1, 8, None, 8, 8, 8, 8, None, 0, None, 0, None, 0, None, 0, 0, 0.0, 0, None, 0, 0, 0, None)
+        lib.call('avt_gemm_bf16', None, 1, 8, None, 1, 8, None, 8, 8, 8, 8, None, 0, None, 0, None, 0, None, 0, 0, 0.0, 0, None, 0, 0, 0, None, 0, None)
     with pytest.raises(lib.AvtHipError, match='head_dim must be 64'):
         lib.call('avt_vit_attn_fwd', 16, 16, 16, 1, 5, 1, 32, 0.125, None)
     with pytest.raises(lib.AvtHipError, match='multiple of 8'):

@@ -178,6 +178,80 @@ def test_big_tile_gemm_and_attention_bit_reproducible(ops):
         assert torch.equal(ops.vit_attn_bwd(qkv, o0, o0, l0, frames, S, H), d0)
 
 
+def test_column_sum_reductions_are_bit_reproducible(ops):
+    """Every many-workgroups -> one fp32 vector reduction (GEMM colsum at each tile shape incl. ragged edges, LayerNorm backward,
+    ViT attention dbias, colsum, patch-embed reduce) gives the same BITS on repeated calls with the partials workspace, and agrees
+    with the atomics path (and with a float64 host sum) to rounding."""
+    def both(fn):
+        outs = []
+        for det in (True, True, True, False):
+            ops.DETERMINISTIC_REDUCTIONS = det
+            try:
+                outs.append([o.clone() for o in fn()])
+            finally:
+                ops.DETERMINISTIC_REDUCTIONS = True
+        torch.cuda.synchronize()
+        for a, b, c, d in zip(*outs):
+            assert torch.equal(a, b) and torch.equal(a, c)
+            assert relerr(d, a) < 1e-5
+        return outs[0]
+    # GEMM epilogue column sums: fast path (N % 8 == 0) and general path (fp32 out), ragged M and N, accumulate into non-zero
+    for (M, N, K, tile, om) in [(1000, 264, 64, 64, ops.OUT_BF16), (1000, 264, 64, 128, ops.OUT_BF16), (5000, 776, 128, 808, ops.OUT_BF16),
+                                (5000, 768, 128, 256, ops.OUT_BF16), (777, 100, 64, 0, ops.OUT_F32), (70000, 768, 64, 0, ops.OUT_BF16)]:
+        a, b = rnd((M, K), 0.5, 41), rnd((N, K), 0.5, 42)
+        aux = rnd((M, N), 1.0, 43)
+        def run():
+            cs = torch.full((N,), 0.5, device='cuda')
+            out = ops.gemm(a, b, M, N, K, act=ops.ACT_MUL_AUX, aux=aux, colsum=cs, tile=tile, out_mode=om)
+            return cs, out
+        cs, out = both(run)
+        assert relerr(cs - 0.5, out.double().sum(0).float()) < 1e-4, (M, N, tile)
+    # LayerNorm backward: dgamma, dbeta, colsum (D = 768 two-row variant and a generic D)
+    for rows, D in [(5000, 768), (3001, 512), (300, 1024)]:
+        x, dy, dres = rnd((rows, D), 1.0, 44), rnd((rows, D), 1.0, 45), rnd((rows, D), 1.0, 46)
+        gam = torch.rand(D, device='cuda') + 0.5
+        _, mean, rstd = ops.layernorm_fwd(x, gam, torch.zeros(D, device='cuda'), 1e-6)
+        def run():
+            dg, db, cs = (torch.full((D,), 0.25, device='cuda') for _ in range(3))
+            dx = ops.layernorm_bwd(dy, x, mean, rstd, gam, dg, db, dres=dres, colsum=cs)
+            return dg, db, cs, dx
+        dg, db, cs, dx = both(run)
+        xh = (x.double() - mean.double()[:, None]) * rstd.double()[:, None]
+        assert relerr(db - 0.25, dy.double().sum(0).float()) < 1e-4
+        assert relerr(dg - 0.25, (dy.double() * xh).sum(0).float()) < 1e-4
+        assert relerr(cs - 0.25, dx.double().sum(0).float()) < 1e-4
+    # ViT attention bias gradient
+    for frames, S, H in [(60, 197, 12), (7, 10, 3), (300, 50, 4)]:
+        qkv = rnd((frames * S, 3 * H * 64), 1.0, 47)
+        o, l = ops.vit_attn_fwd(qkv, frames, S, H)
+        do = rnd((frames * S, H * 64), 1.0, 48)
+        def run():
+            dbias = torch.full((3 * H * 64,), 0.125, device='cuda')
+            dqkv = ops.vit_attn_bwd(qkv, o, do, l, frames, S, H, dbias=dbias)
+            return dbias, dqkv
+        dbias, dqkv = both(run)
+        assert relerr(dbias - 0.125, dqkv.double().sum(0).float()) < 2e-3, (frames, S, H)     # the kernel sums the fp32 values, dqkv is their bf16 rounding
+    # plain column sums and the patch-embedding reduce
+    for M, N in [(100000, 768), (33, 8), (5000, 2304)]:
+        x = rnd((M, N), 1.0, 49)
+        def run():
+            out = torch.full((N,), 2.0, device='cuda')
+            ops.colsum(x, out)
+            return (out,)
+        out, = both(run)
+        assert relerr(out - 2.0, x.double().sum(0).float()) < 1e-4
+    for N_, S, D in [(300, 197, 768), (5, 10, 192)]:
+        dx = rnd((N_ * S, D), 1.0, 50)
+        def run():
+            dpos, dcls, dbias = torch.full((S * D,), 1.0, device='cuda'), torch.full((D,), 1.0, device='cuda'), torch.full((D,), 1.0, device='cuda')
+            ops.patch_embed_bwd_reduce(dx, dpos, dcls, dbias, N_, S, D)
+            return dpos, dcls, dbias
+        dpos, dcls, dbias = both(run)
+        ref = dx.double().view(N_, S, D).sum(0)
+        assert relerr(dpos - 1.0, ref.float().view(-1)) < 1e-4
+        assert relerr(dcls - 1.0, ref[0].float()) < 1e-4 and relerr(dbias - 1.0, ref[1:].sum(0).float()) < 1e-4
+
+
 def test_gemm_epilogue_dropout(ops):
     M, N, K = 256, 256, 64
     a, b = rnd((M, K), 0.5, 15), rnd((N, K), 0.5, 16)
