@@ -7,7 +7,9 @@ distributions the reference's transforms use (``random.randint`` for the ``"248-
 RandomCrop.get_params), so a seeded run draws the same sequence.
 
 Configured from the same ``data_train`` / ``data_eval`` keys (conf/data/default.yaml: scale_h, scale_w, crop_size, mean, std, flip_p,
-scale_pix_val, reverse_channels, eval_num_crops, eval_flip_crops); colour jitter (0 in every AVT experiment) is not implemented and raises when requested.
+scale_pix_val, reverse_channels, eval_num_crops, eval_flip_crops).  Colour jitter is 0 in every AVT experiment
+(conf/data/default.yaml:37-40): non-zero strengths raise, and the zero-strength ``ColorJitterVideo`` of the TRAINING chain is reproduced
+for what it still does -- its float -> PIL -> float round trip cuts the resized pixels to 8 bits (``quantize_u8`` of the kernel).
 """
 import random
 
@@ -32,6 +34,7 @@ class GpuClipTransform:
         if eval_num_crops not in (1, 3):
             raise NotImplementedError('Not supported')               # common/transforms.py:271
         self.num_crops, self.flip_crops = (1, False) if train else (eval_num_crops, bool(eval_flip_crops))
+        self.quantize_u8 = bool(train)              # ColorJitterVideo is in transform_train only (func/train.py:554-557)
 
     @staticmethod
     def _size(v):
@@ -86,7 +89,8 @@ class GpuClipTransform:
         else:
             params = [tuple(q) + ((b,) if len(q) == 5 else ()) for b, q in enumerate(params)]
         p = torch.tensor(params, dtype=torch.int32).to(clips_u8.device, non_blocking=True)
-        out = ops.video_preproc(clips_u8.contiguous(), p, self.crop, self.scale_pix_val, self.mean, self.std, self.reverse_channels)
+        out = ops.video_preproc(clips_u8.contiguous(), p, self.crop, self.scale_pix_val, self.mean, self.std, self.reverse_channels,
+                                quantize_u8=self.quantize_u8)
         if multi:                                   # (B * crops, T, 3, 1, h, w) -> the model's 7-D (B, #clips, #crops, C, T', H, W)
             out = out.view(B, nc, T, 3, 1, *self.crop).permute(0, 2, 1, 3, 4, 5, 6)
         return out

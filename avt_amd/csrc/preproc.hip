@@ -10,6 +10,10 @@
 // MultiCropVideo (common/transforms.py:254-296: top-left / centre / bottom-right crops, optionally followed by their mirror
 // images) is 3 or 6 output clips reading one source clip -- a mirrored crop at column j is the crop at new_w - crop_w - j of
 // the mirrored frame.
+// quantize_u8: the training chain runs ColorJitterVideo between the flip and the scaling (func/train.py:554-557) with all four
+// strengths 0 in every AVT experiment (conf/data/default.yaml:37-40).  torchvision's ColorJitter then changes nothing, but the
+// wrapper (common/transforms.py:399-421) still converts the resized float clip to a PIL image and back: torchvision 0.8.2
+// to_pil_image does pic.mul(255).byte() (truncation), to_tensor divides by 255 -- the resized pixels are cut to 8 bits.
 #include "common.hpp"
 #include "../../include/avt_hip.h"
 
@@ -17,7 +21,7 @@ namespace {
 __global__ __launch_bounds__(256) void video_preproc_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
                                                             const int* __restrict__ params, int T, int H, int W, int OH, int OW,
                                                             float scale_pix, float m0, float m1, float m2, float is0, float is1,
-                                                            float is2, int reverse, long total) {
+                                                            float is2, int reverse, int quantize, long total) {
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int x = (int)(idx % OW);
     long r = idx / OW;
@@ -46,7 +50,8 @@ __global__ __launch_bounds__(256) void video_preproc_kernel(const uint8_t* __res
     for (int c = 0; c < 3; ++c) {
       const int sc = reverse ? 2 - c : c;
       const float k = 1.f / 255.f;
-      const float v = hy * (hx * (p00[sc] * k) + lx * (p01[sc] * k)) + ly * (hx * (p10[sc] * k) + lx * (p11[sc] * k));
+      float v = hy * (hx * (p00[sc] * k) + lx * (p01[sc] * k)) + ly * (hx * (p10[sc] * k) + lx * (p11[sc] * k));
+      if (quantize) v = floorf(v * 255.f) / 255.f;
       const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), is = c == 0 ? is0 : (c == 1 ? is1 : is2);
       o[(size_t)c * OH * OW] = (v * scale_pix - m) * is;
     }
@@ -55,14 +60,15 @@ __global__ __launch_bounds__(256) void video_preproc_kernel(const uint8_t* __res
 }  // namespace
 
 extern "C" int avt_video_preproc_u8(const void* src, float* dst, const int* params, int B, int T, int H, int W, int OH, int OW,
-                                    float scale_pix, const float* mean3, const float* std3, int reverse_channels, void* stream) {
+                                    float scale_pix, const float* mean3, const float* std3, int reverse_channels, int quantize_u8,
+                                    void* stream) {
   AVT_CHECK(src && dst && params && mean3 && std3, "avt_video_preproc_u8: null argument");
   AVT_CHECK(B > 0 && T > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "avt_video_preproc_u8: bad shape");
   AVT_CHECK(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "avt_video_preproc_u8: zero std");
   const long total = (long)B * T * OH * OW;
   long g = (total + 255) / 256; if (g > 16384) g = 16384;
   hipLaunchKernelGGL(video_preproc_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, dst, params, T, H, W,
-                     OH, OW, scale_pix, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2], reverse_channels, total);
+                     OH, OW, scale_pix, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2], reverse_channels, quantize_u8, total);
   AVT_LAUNCH_CHECK();
   return 0;
 }

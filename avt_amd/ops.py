@@ -379,9 +379,11 @@ def add_rows(dst, src):
 
 
 # ---- input pipeline ------------------------------------------------------------------------------------------------------------
-def video_preproc(src_u8, params, out_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), reverse_channels=False):
+def video_preproc(src_u8, params, out_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), reverse_channels=False,
+                  quantize_u8=False):
     """uint8 (B,T,H,W,3) -> fp32 (B,T,3,1,OH,OW): /255, bilinear resize, flip, scale, normalise, crop in one kernel.
-    params: int32 (Bout,6) = new_h, new_w, flip, crop_i, crop_j, source clip per OUTPUT clip (on the device)."""
+    params: int32 (Bout,6) = new_h, new_w, flip, crop_i, crop_j, source clip per OUTPUT clip (on the device).
+    quantize_u8: cut the resized pixels to 8 bits first (the training chain's zero-strength ColorJitterVideo round trip)."""
     import ctypes
     _chk(src_u8, torch.uint8, 'src'); _chk(params, torch.int32, 'params')
     assert src_u8.dim() == 5 and src_u8.size(-1) == 3 and src_u8.is_contiguous() and params.is_contiguous()
@@ -392,7 +394,7 @@ def video_preproc(src_u8, params, out_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), s
     out = torch.empty((B, T, 3, 1, OH, OW), device=src_u8.device, dtype=torch.float32)
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
     _lib.call('avt_video_preproc_u8', _p(src_u8), _p(out), _p(params), B, T, H, W, OH, OW, float(scale_pix),
-              ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p), int(reverse_channels), _stream())
+              ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p), int(reverse_channels), int(quantize_u8), _stream())
     return out
 
 

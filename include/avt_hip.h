@@ -170,9 +170,13 @@ int avt_relu_bf16(const void* x, void* y, void* mask, long n, void* stream);
  * (align_corners = False) to (new_h, new_w) -> optional horizontal flip -> x scale_pix -> optional channel reversal ->
  * (v - mean) / std -> crop (OH, OW) at (crop_i, crop_j), written as fp32 (B,T,3,1,OH,OW).  params: int32 [B][6] =
  * {new_h, new_w, flip, crop_i, crop_j, source clip} per OUTPUT clip (device memory; the random draws stay with the caller; the
- * evaluation MultiCropVideo, common/transforms.py:254-296, is several output clips reading one source clip). mean3 / std3: host. */
+ * evaluation MultiCropVideo, common/transforms.py:254-296, is several output clips reading one source clip). mean3 / std3: host.
+ * quantize_u8 != 0: the resized pixels are cut to 8 bits (floor(v * 255) / 255) before scaling -- what the training chain's
+ * ColorJitterVideo (common/transforms.py:399-421, strengths 0 in every AVT experiment) does through its float -> PIL -> float
+ * round trip (torchvision 0.8.2 to_pil_image: pic.mul(255).byte(); to_tensor: / 255). */
 int avt_video_preproc_u8(const void* src, float* dst, const int* params, int B, int T, int H, int W, int OH, int OW,
-                         float scale_pix, const float* mean3, const float* std3, int reverse_channels, void* stream);
+                         float scale_pix, const float* mean3, const float* std3, int reverse_channels, int quantize_u8,
+                         void* stream);
 
 /* ---- softmax cross-entropy -------------------------------------------------------------------------------------------
  * loss_fn/multidim_xentropy.py:11-25 (CrossEntropyLoss(ignore_index=-1, reduction='none')) + common/utils.py:17-44.

@@ -421,13 +421,19 @@ def resize_shape(clip_h, clip_w, target):
 
 
 def video_preproc(clip_u8, new_hw, flip, crop_ij, crop_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5),
-                  reverse_channels=False):
+                  reverse_channels=False, color_jitter_roundtrip=False):
     """One clip through the reference's training / eval transform chain with the random draws given explicitly.
-    clip_u8: uint8 (T, H, W, 3) -> float (3, T, h, w)."""
+    clip_u8: uint8 (T, H, W, 3) -> float (3, T, h, w).
+    color_jitter_roundtrip: the training chain's ColorJitterVideo (func/train.py:554-557, common/transforms.py:399-421) with all
+    strengths 0 (conf/data/default.yaml:37-40): torchvision's ColorJitter (0.8.2, env.yaml:305 -- absent from /root/reference and
+    from this image) leaves the image unchanged, but the wrapper's ToPILImage()/ToTensor() round trip does
+    ``pic.mul(255).byte()`` (torchvision.transforms.functional.to_pil_image) and ``/ 255`` (to_tensor)."""
     x = clip_u8.float().permute(3, 0, 1, 2) / 255.0                              # to_tensor, common/transforms.py:124-146
     x = F.interpolate(x, size=tuple(new_hw), mode='bilinear')                    # resize, :60-91 (align_corners = None -> False)
     if flip:
         x = x.flip((-1,))                                                        # hflip, :167-175
+    if color_jitter_roundtrip:
+        x = x.mul(255).byte().float().div(255)                                   # ColorJitterVideo with zero strengths, :417-421
     x = x * scale_pix                                                            # func/train.py:559-560
     if reverse_channels:
         x = x[[2, 1, 0], ...]                                                    # func/train.py:561-564

@@ -562,7 +562,9 @@ def test_deterministic_wgrad_accumulate(ops, M, P, Q):
 def test_video_preproc_vs_reference_golden_and_oracle(ops, golden_dir):
     """Fused uint8 -> resize -> flip -> scale -> normalise -> crop kernel against (a) the golden produced by the
     reference's own transform functions and (b) the oracle at the training geometry (456x256 frames -> 248..280 -> 224 crop).
-    fp32 in and out: tolerance 2e-5 of the output range (the bilinear weights are evaluated in a different association order)."""
+    fp32 in and out: tolerance 2e-5 of the output range (the bilinear weights are evaluated in a different association order).
+    The training chain's ColorJitterVideo round trip (8-bit cut of the resized pixels) is checked against the oracle's restatement
+    of torchvision 0.8.2's to_pil_image / to_tensor -- torchvision is not in this image, so that step has no reference-made golden."""
     import os
     import numpy as np
     from avt_amd import ops
@@ -584,6 +586,17 @@ def test_video_preproc_vs_reference_golden_and_oracle(ops, golden_dir):
     out = tr(u8.cuda(), params=params)
     torch.cuda.synchronize()
     assert out.shape == (B, T, 3, 1, 224, 224)
+    # the training transform includes the zero-strength ColorJitterVideo's float -> uint8 -> float round trip: a resized pixel
+    # within rounding of an integer level may land on the neighbouring level (1/255 before the division by std = 0.5)
+    assert tr.quantize_u8
+    for b, (nh, nw, fl, ci, cj) in enumerate(params):
+        ref = O.video_preproc(u8[b], (nh, nw), fl, (ci, cj), (224, 224), color_jitter_roundtrip=True)
+        d = (out[b, :, :, 0].permute(1, 0, 2, 3).cpu() - ref).abs()
+        assert float(d.max()) < 2.0 / 255 + 2e-5 and float((d > 2e-5).float().mean()) < 1e-4, (b, float(d.max()), float((d > 2e-5).float().mean()))
+        plain = O.video_preproc(u8[b], (nh, nw), fl, (ci, cj), (224, 224))
+        assert float((ref - plain).abs().max()) > 1e-3                          # the round trip is not a no-op
+    tr.quantize_u8 = False
+    out = tr(u8.cuda(), params=params)
     for b, (nh, nw, fl, ci, cj) in enumerate(params):
         ref = O.video_preproc(u8[b], (nh, nw), fl, (ci, cj), (224, 224))
         assert float((out[b, :, :, 0].permute(1, 0, 2, 3).cpu() - ref).abs().max()) < 2e-5, b

@@ -202,6 +202,16 @@ def test_g9_input_pipeline(golden_dir):
         nh, nw, flip, ci, cj, rev, scale = int(p[0]), int(p[1]), int(p[2]), int(p[3]), int(p[4]), bool(p[5]), float(p[6])
         got = O.video_preproc(clips[b], (nh, nw), flip, (ci, cj), out.shape[-2:], scale, tuple(z['mean']), tuple(z['std']), rev)
         assert rel(got, out[b]) < 1e-6, b
+    # training chain: the zero-strength ColorJitterVideo round trip leaves 8-bit pixel levels (torchvision 0.8.2 to_pil_image /
+    # to_tensor restated; torchvision is not in this image) -- every output maps back to an integer level, at most one below the
+    # unquantised value
+    p = z['params'][0]
+    kw = dict(new_hw=(int(p[0]), int(p[1])), flip=int(p[2]), crop_ij=(int(p[3]), int(p[4])), crop_hw=tuple(out.shape[-2:]))
+    q = O.video_preproc(clips[0], color_jitter_roundtrip=True, **kw)
+    plain = O.video_preproc(clips[0], **kw)
+    lv, lv0 = (q * 0.5 + 0.5) * 255, (plain * 0.5 + 0.5) * 255
+    assert float((lv - lv.round()).abs().max()) < 1e-3
+    assert float((lv0 - lv).min()) > -1e-3 and float((lv0 - lv).max()) < 1.0 + 1e-3
 
 
 def test_g10_transformer_aggregator(golden_dir):
