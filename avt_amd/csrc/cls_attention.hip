@@ -18,24 +18,28 @@
 namespace {
 constexpr int CLS_SMAX = 256;
 
-__device__ __forceinline__ void load_row64(const bf16_t* p, float (&r)[64]) {
+// A wave walks its item's keys 8 rows at a time: lane = (row r8 = lane >> 3, chunk ch = lane & 7) loads 16 bytes = dims
+// [8 ch, 8 ch + 8) of key 8 g + r8, so one load instruction covers eight full 128-byte rows (the earlier one-row-per-lane layout
+// touched 64 rows per instruction, 16 bytes each, and lived off L1 reuse: 2.6-2.7 TB/s).  Per-key scalars go through LDS.
+__device__ __forceinline__ void unpack8(u32x4_t w, float (&r)[8]) {
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    u32x4_t w = *(const u32x4_t*)(p + c * 8);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { r[c * 8 + 2 * e] = bflo(w[e]); r[c * 8 + 2 * e + 1] = bfhi(w[e]); }
-  }
+  for (int e = 0; e < 4; ++e) { r[2 * e] = bflo(w[e]); r[2 * e + 1] = bfhi(w[e]); }
 }
-__device__ __forceinline__ float dot_row64(const bf16_t* p, const float (&r)[64]) {
+__device__ __forceinline__ float dot8(u32x4_t w, const float (&r)[8]) {
   float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    u32x4_t w = *(const u32x4_t*)(p + c * 8);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { s0 = fmaf(bflo(w[e]), r[c * 8 + 2 * e], s0); s1 = fmaf(bfhi(w[e]), r[c * 8 + 2 * e + 1], s1); }
-  }
+  for (int e = 0; e < 4; ++e) { s0 = fmaf(bflo(w[e]), r[2 * e], s0); s1 = fmaf(bfhi(w[e]), r[2 * e + 1], s1); }
   return s0 + s1;
 }
+__device__ __forceinline__ float row8_sum(float v) {          // over the 8 lanes of a row group
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+  return v;
+}
+__device__ __forceinline__ float col8_sum(float v) {          // over the 8 row groups
+  v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+  return v;
+}
+constexpr int CLS_UNROLL = 5;                                  // key groups (of 8 rows) in flight per wave
 
 __global__ __launch_bounds__(256) void cls_attn_fwd_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ kv, int ldkv,
                                                            bf16_t* __restrict__ out, int ldo, float* __restrict__ probs,
@@ -46,16 +50,31 @@ __global__ __launch_bounds__(256) void cls_attn_fwd_kernel(const bf16_t* __restr
   if (item >= items) return;                       // whole wave leaves; no block-level barrier below
   const int n = item / H, h = item % H;
   const int D = H * 64;
-  float qr[64];
-  load_row64(q + (size_t)n * ldq + h * 64, qr);
-  const bf16_t* kbase = kv + (size_t)n * S * ldkv + h * 64;
+  const int r8 = lane >> 3, ch = lane & 7;
+  float qr[8];
+  unpack8(*(const u32x4_t*)(q + (size_t)n * ldq + h * 64 + ch * 8), qr);
+  const bf16_t* kbase = kv + (size_t)n * S * ldkv + h * 64 + ch * 8;
+  const int ngroups = (S + 7) / 8;
+  for (int g0 = 0; g0 < ngroups; g0 += CLS_UNROLL) {
+    u32x4_t w[CLS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < CLS_UNROLL; ++u) {
+      const int j = (g0 + u) * 8 + r8;
+      w[u] = (u32x4_t){0u, 0u, 0u, 0u};
+      if (j < S) w[u] = *(const u32x4_t*)(kbase + (size_t)j * ldkv);
+    }
+#pragma unroll
+    for (int u = 0; u < CLS_UNROLL; ++u) {
+      const int j = (g0 + u) * 8 + r8;
+      const float sc = row8_sum(dot8(w[u], qr)) * scale;
+      if (ch == 0 && j < S) P[wave][j] = sc;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   float s[4], mx = -3.0e38f;
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = jj * 64 + lane;
-    s[jj] = -3.0e38f;
-    if (j < S) { s[jj] = dot_row64(kbase + (size_t)j * ldkv, qr) * scale; mx = fmaxf(mx, s[jj]); }
-  }
+  for (int jj = 0; jj < 4; ++jj) { const int j = jj * 64 + lane; s[jj] = (j < S) ? P[wave][j] : -3.0e38f; mx = fmaxf(mx, s[jj]); }
   mx = wave_max(mx);
   float sum = 0.f;
 #pragma unroll
@@ -70,93 +89,116 @@ __global__ __launch_bounds__(256) void cls_attn_fwd_kernel(const bf16_t* __restr
   }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // out[d] = sum_j p_j v[j][d]: lane = (key parity, dim pair); row reads are 128 contiguous bytes per key
-  const int dp = lane & 31, par = lane >> 5;
-  const bf16_t* vbase = kbase + D + dp * 2;
-  float a0 = 0.f, a1 = 0.f;
-  for (int j = par; j < S; j += 2) {
-    const uint32_t w = *(const uint32_t*)(vbase + (size_t)j * ldkv);
-    const float p = P[wave][j];
-    a0 = fmaf(p, bflo(w), a0); a1 = fmaf(p, bfhi(w), a1);
+  // out[d] = sum_j p_j v[j][d]: every lane accumulates its 8 dims over the rows of its row group
+  const bf16_t* vbase = kbase + D;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int g0 = 0; g0 < ngroups; g0 += CLS_UNROLL) {
+    u32x4_t w[CLS_UNROLL];
+    float pj[CLS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < CLS_UNROLL; ++u) {
+      const int j = (g0 + u) * 8 + r8;
+      w[u] = (u32x4_t){0u, 0u, 0u, 0u}; pj[u] = 0.f;
+      if (j < S) { w[u] = *(const u32x4_t*)(vbase + (size_t)j * ldkv); pj[u] = P[wave][j]; }
+    }
+#pragma unroll
+    for (int u = 0; u < CLS_UNROLL; ++u) {
+      float v[8];
+      unpack8(w[u], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj[u], v[e], acc[e]);
+    }
   }
-  a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
-  if (par == 0) *(uint32_t*)(out + (size_t)n * ldo + h * 64 + dp * 2) = pack2bf(a0, a1);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = col8_sum(acc[e]);
+  if (r8 == 0) {
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2bf(acc[2 * e], acc[2 * e + 1]);
+    *(u32x4_t*)(out + (size_t)n * ldo + h * 64 + ch * 8) = o;
+  }
 }
 
 __global__ __launch_bounds__(256) void cls_attn_bwd_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ kv, int ldkv,
                                                            const float* __restrict__ probs, const bf16_t* __restrict__ dout, int lddo,
                                                            bf16_t* __restrict__ dq, int lddq, bf16_t* __restrict__ dkv, int lddkv,
                                                            int S, int H, float scale, int items) {
-  __shared__ float DS[4][CLS_SMAX];
+  __shared__ float PP[4][CLS_SMAX];     // p_j
+  __shared__ float DP[4][CLS_SMAX];     // dp_j = do . v_j
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int item = blockIdx.x * 4 + wave;
   if (item >= items) return;
   const int n = item / H, h = item % H;
   const int D = H * 64;
-  float dor[64];
-  load_row64(dout + (size_t)n * lddo + h * 64, dor);
-  const bf16_t* kbase = kv + (size_t)n * S * ldkv + h * 64;
+  const int r8 = lane >> 3, ch = lane & 7;
+  float dor[8], qr[8];
+  unpack8(*(const u32x4_t*)(dout + (size_t)n * lddo + h * 64 + ch * 8), dor);
+  unpack8(*(const u32x4_t*)(q + (size_t)n * ldq + h * 64 + ch * 8), qr);
+  const bf16_t* kbase = kv + (size_t)n * S * ldkv + h * 64 + ch * 8;
+  bf16_t* dkbase = dkv + (size_t)n * S * lddkv + h * 64 + ch * 8;
   const float* prow = probs + (size_t)item * S;
-  float p[4], dpv[4], delta = 0.f;
+  const int ngroups = (S + 7) / 8;
+  // pass 1 over V: dp_j, delta = sum_j p_j dp_j, dv_j = p_j do
+  float delta = 0.f;
+  for (int g0 = 0; g0 < ngroups; g0 += CLS_UNROLL) {
+    u32x4_t w[CLS_UNROLL];
+    float pj[CLS_UNROLL];
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = jj * 64 + lane;
-    p[jj] = 0.f; dpv[jj] = 0.f;
-    if (j < S) { p[jj] = prow[j]; dpv[jj] = dot_row64(kbase + D + (size_t)j * ldkv, dor); delta = fmaf(p[jj], dpv[jj], delta); }
+    for (int u = 0; u < CLS_UNROLL; ++u) {
+      const int j = (g0 + u) * 8 + r8;
+      w[u] = (u32x4_t){0u, 0u, 0u, 0u}; pj[u] = 0.f;
+      if (j < S) { w[u] = *(const u32x4_t*)(kbase + D + (size_t)j * ldkv); pj[u] = prow[j]; }
+    }
+#pragma unroll
+    for (int u = 0; u < CLS_UNROLL; ++u) {
+      const int j = (g0 + u) * 8 + r8;
+      const float dpj = row8_sum(dot8(w[u], dor));
+      if (j < S) {
+        if (ch == 0) { PP[wave][j] = pj[u]; DP[wave][j] = dpj; delta = fmaf(pj[u], dpj, delta); }
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2bf(pj[u] * dor[2 * e], pj[u] * dor[2 * e + 1]);
+        *(u32x4_t*)(dkbase + D + (size_t)j * lddkv) = o;
+      }
+    }
   }
   delta = wave_sum(delta);
-  // dv_j = p_j * do (this lane's keys, whole 64-wide rows from registers)
-  bf16_t* dkbase = dkv + (size_t)n * S * lddkv + h * 64;
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = jj * 64 + lane;
-    if (j < S) {
-      bf16_t* row = dkbase + D + (size_t)j * lddkv;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        u32x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = pack2bf(p[jj] * dor[c * 8 + 2 * e], p[jj] * dor[c * 8 + 2 * e + 1]);
-        *(u32x4_t*)(row + c * 8) = o;
-      }
-    }
-  }
-  float ds[4];
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = jj * 64 + lane;
-    ds[jj] = p[jj] * (dpv[jj] - delta) * scale;
-    if (j < S) DS[wave][j] = ds[jj];
-  }
-  // dk_j = scale ds_j q: reuse the register row for q
-  load_row64(q + (size_t)n * ldq + h * 64, dor);
-#pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = jj * 64 + lane;
-    if (j < S) {
-      bf16_t* row = dkbase + (size_t)j * lddkv;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        u32x4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = pack2bf(ds[jj] * dor[c * 8 + 2 * e], ds[jj] * dor[c * 8 + 2 * e + 1]);
-        *(u32x4_t*)(row + c * 8) = o;
-      }
-    }
-  }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // dq[d] = sum_j (scale ds_j) k[j][d]
-  const int dp = lane & 31, par = lane >> 5;
-  const bf16_t* kcol = kbase + dp * 2;
-  float a0 = 0.f, a1 = 0.f;
-  for (int j = par; j < S; j += 2) {
-    const uint32_t w = *(const uint32_t*)(kcol + (size_t)j * ldkv);
-    const float d = DS[wave][j];
-    a0 = fmaf(d, bflo(w), a0); a1 = fmaf(d, bfhi(w), a1);
+  // pass 2 over K: ds_j = scale p_j (dp_j - delta), dq = sum_j ds_j k_j, dk_j = ds_j q
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int g0 = 0; g0 < ngroups; g0 += CLS_UNROLL) {
+    u32x4_t w[CLS_UNROLL];
+    float ds[CLS_UNROLL];
+#pragma unroll
+    for (int u = 0; u < CLS_UNROLL; ++u) {
+      const int j = (g0 + u) * 8 + r8;
+      w[u] = (u32x4_t){0u, 0u, 0u, 0u}; ds[u] = 0.f;
+      if (j < S) { w[u] = *(const u32x4_t*)(kbase + (size_t)j * ldkv); ds[u] = PP[wave][j] * (DP[wave][j] - delta) * scale; }
+    }
+#pragma unroll
+    for (int u = 0; u < CLS_UNROLL; ++u) {
+      const int j = (g0 + u) * 8 + r8;
+      float k8[8];
+      unpack8(w[u], k8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(ds[u], k8[e], acc[e]);
+      if (j < S) {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack2bf(ds[u] * qr[2 * e], ds[u] * qr[2 * e + 1]);
+        *(u32x4_t*)(dkbase + (size_t)j * lddkv) = o;
+      }
+    }
   }
-  a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
-  if (par == 0) *(uint32_t*)(dq + (size_t)n * lddq + h * 64 + dp * 2) = pack2bf(a0, a1);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = col8_sum(acc[e]);
+  if (r8 == 0) {
+    u32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = pack2bf(acc[2 * e], acc[2 * e + 1]);
+    *(u32x4_t*)(dq + (size_t)n * lddq + h * 64 + ch * 8) = o;
+  }
 }
 
 // ---- KV-cache decode attention: one new token per clip ------------------------------------------------------------------
@@ -222,7 +264,7 @@ extern "C" int avt_cls_attn_fwd(const void* q, int ldq, const void* kv, int ldkv
   AVT_CHECK(q && kv && out && probs, "avt_cls_attn_fwd: null argument");
   AVT_CHECK(head_dim == 64, "avt_cls_attn_fwd: head_dim must be 64 (got %d)", head_dim);
   AVT_CHECK(frames > 0 && H > 0 && S > 0 && S <= CLS_SMAX, "avt_cls_attn_fwd: need 0 < S <= %d (got %d)", CLS_SMAX, S);
-  AVT_CHECK(ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 2 == 0 && aligned16(q) && aligned16(kv), "avt_cls_attn_fwd: 16-byte aligned rows required");
+  AVT_CHECK(ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0 && aligned16(q) && aligned16(kv) && aligned16(out), "avt_cls_attn_fwd: 16-byte aligned rows required");
   const int items = frames * H;
   hipLaunchKernelGGL(cls_attn_fwd_kernel, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,
                      (const bf16_t*)kv, ldkv, (bf16_t*)out, ldo, probs, S, H, scale, items);
@@ -236,8 +278,8 @@ extern "C" int avt_cls_attn_bwd(const void* q, int ldq, const void* kv, int ldkv
   AVT_CHECK(q && kv && probs && dout && dq && dkv, "avt_cls_attn_bwd: null argument");
   AVT_CHECK(head_dim == 64, "avt_cls_attn_bwd: head_dim must be 64 (got %d)", head_dim);
   AVT_CHECK(frames > 0 && H > 0 && S > 0 && S <= CLS_SMAX, "avt_cls_attn_bwd: need 0 < S <= %d (got %d)", CLS_SMAX, S);
-  AVT_CHECK(ldq % 8 == 0 && ldkv % 8 == 0 && lddo % 8 == 0 && lddkv % 8 == 0 && lddq % 2 == 0 && aligned16(q) && aligned16(kv) &&
-            aligned16(dout) && aligned16(dkv), "avt_cls_attn_bwd: 16-byte aligned rows required");
+  AVT_CHECK(ldq % 8 == 0 && ldkv % 8 == 0 && lddo % 8 == 0 && lddkv % 8 == 0 && lddq % 8 == 0 && aligned16(q) && aligned16(kv) &&
+            aligned16(dout) && aligned16(dkv) && aligned16(dq), "avt_cls_attn_bwd: 16-byte aligned rows required");
   const int items = frames * H;
   hipLaunchKernelGGL(cls_attn_bwd_kernel, dim3((items + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,
                      (const bf16_t*)kv, ldkv, probs, (const bf16_t*)dout, lddo, (bf16_t*)dq, lddq, (bf16_t*)dkv, lddkv, S, H, scale, items);

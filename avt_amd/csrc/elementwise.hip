@@ -256,6 +256,48 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     if (c0 + c < cols && r0 + r < rows) dst[(size_t)(c0 + c) * ldd + r0 + r] = tile[r][c];
   }
 }
+// the same for a whole table of matrices in ONE launch (blockIdx.y = matrix, blockIdx.x = 64x64 tile of it): the ~40 transposed
+// weight shadows of a ViT are refreshed after every optimizer step, and forty 10-us launches of a few hundred workgroups each
+// cost more than the 340 MB they move.  16-byte global loads and stores when the shapes allow it.
+struct TransposeJob { const bf16_t* src; bf16_t* dst; long ld_src, ld_dst; int rows, cols; };
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const TransposeJob* __restrict__ jobs) {
+  __shared__ bf16_t tile[64][66];                    // row pitch 132 B: rows 8 apart land 8 banks apart (2-way conflicts on the column reads)
+  const TransposeJob jb = jobs[blockIdx.y];
+  const int tc = (jb.cols + 63) / 64, tr = (jb.rows + 63) / 64;
+  if ((int)blockIdx.x >= tc * tr) return;
+  const int r0 = (blockIdx.x / tc) * 64, c0 = (blockIdx.x % tc) * 64;
+  const bool vec = (jb.rows % 8 == 0) && (jb.cols % 8 == 0) && (jb.ld_src % 8 == 0) && (jb.ld_dst % 8 == 0) &&
+                   ((((uintptr_t)jb.src) | ((uintptr_t)jb.dst)) & 15u) == 0;
+  if (vec) {
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {            // 8 chunks of 8 columns per row
+      const int r = i >> 3, c = (i & 7) * 8;
+      u32x4_t w = {0u, 0u, 0u, 0u};
+      if (r0 + r < jb.rows && c0 + c < jb.cols) w = *(const u32x4_t*)(jb.src + (size_t)(r0 + r) * jb.ld_src + c0 + c);
+      uint32_t* t32 = (uint32_t*)&tile[r][c];
+      t32[0] = w[0]; t32[1] = w[1]; t32[2] = w[2]; t32[3] = w[3];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) {            // output row = source column c, 8 source rows per chunk
+      const int c = i >> 3, r = (i & 7) * 8;
+      if (c0 + c < jb.cols && r0 + r < jb.rows) {
+        u32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (uint32_t)tile[r + 2 * e][c] | ((uint32_t)tile[r + 2 * e + 1][c] << 16);
+        *(u32x4_t*)(jb.dst + (size_t)(c0 + c) * jb.ld_dst + r0 + r) = o;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      tile[r][c] = (r0 + r < jb.rows && c0 + c < jb.cols) ? jb.src[(size_t)(r0 + r) * jb.ld_src + c0 + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int c = i >> 6, r = i & 63;
+      if (c0 + c < jb.cols && r0 + r < jb.rows) jb.dst[(size_t)(c0 + c) * jb.ld_dst + r0 + r] = tile[r][c];
+    }
+  }
+}
 // dst[r, :] += src[r, :] for strided bf16 rows (the CLS rows of a [frames*S, D] tensor: ldd = S*D)
 __global__ __launch_bounds__(256) void add_rows_kernel(bf16_t* __restrict__ dst, long ldd, const bf16_t* __restrict__ src, long lds,
                                                        int rows, int D) {
@@ -419,6 +461,13 @@ extern "C" int avt_relu_bf16(const void* x, void* y, void* mask, long n, void* s
   AVT_CHECK(x && y && mask && n > 0 && n % 8 == 0, "avt_relu_bf16: n must be a positive multiple of 8");
   AVT_CHECK(aligned16(x) && aligned16(y) && aligned16(mask), "avt_relu_bf16: 16-byte alignment required");
   hipLaunchKernelGGL(relu_kernel, dim3(GRID_FOR(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, (bf16_t*)mask, n / 8);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int avt_transpose_batch_bf16(const void* jobs, int njobs, int max_tiles, void* stream) {
+  AVT_CHECK(jobs && njobs > 0 && njobs <= 65535 && max_tiles > 0, "avt_transpose_batch_bf16: bad argument");
+  AVT_CHECK((((uintptr_t)jobs) & 7u) == 0, "avt_transpose_batch_bf16: the job table must be 8-byte aligned");
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(max_tiles, njobs), dim3(256), 0, (hipStream_t)stream, (const TransposeJob*)jobs);
   AVT_LAUNCH_CHECK();
   return 0;
 }

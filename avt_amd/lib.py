@@ -37,6 +37,7 @@ SIGNATURES = {
     'avt_dropout_bf16': [_P, _P, _L, _F, _U64, _P],
     'avt_embed_pos_fwd': [_P, _P, _P, _I, _I, _I, _F, _U64, _P],
     'avt_embed_pos_bwd': [_P, _P, _P, _I, _I, _I, _F, _U64, _P],
+    'avt_transpose_batch_bf16': [_P, _I, _I, _P],
     'avt_colsum_bf16': [_P, _I, _P, _I, _I, _P, _SZ, _P],
     'avt_mse_shift_fwd': [_P, _P, _P, _I, _I, _I, _P],
     'avt_mse_shift_bwd': [_P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -273,6 +273,26 @@ def transpose_into(src, dst):
     _lib.call('avt_transpose_bf16', _p(src), _ld(src), _p(dst), _ld(dst), src.size(0), src.size(1), _stream())
 
 
+def transpose_jobs(pairs):
+    """Device job table for ``transpose_batch``: [(src, dst)] 2-D bf16 views with unit inner stride, dst = src^T.
+    Returns (table tensor, njobs, max_tiles); valid while the tensors stay where they are."""
+    import struct
+    buf, max_tiles = b'', 0
+    for src, dst in pairs:
+        _chk(src, BF16, 'src'); _chk(dst, BF16, 'dst')
+        assert dst.shape == (src.size(1), src.size(0))
+        r, c = src.size(0), src.size(1)
+        buf += struct.pack('<QQqqii', src.data_ptr(), dst.data_ptr(), _ld(src), _ld(dst), r, c)
+        max_tiles = max(max_tiles, ((r + 63) // 64) * ((c + 63) // 64))
+    table = torch.frombuffer(bytearray(buf), dtype=torch.uint8).to(pairs[0][0].device)
+    return table, len(pairs), max_tiles
+
+
+def transpose_batch(jobs):
+    table, n, max_tiles = jobs
+    _lib.call('avt_transpose_batch_bf16', _p(table), n, max_tiles, _stream())
+
+
 def relu(x):
     """(max(x, 0), mask) with mask = bf16 1/0 = the derivative, consumed by gemm(act=ACT_MUL_AUX) in backward."""
     _chk(x, BF16, 'x')

@@ -161,6 +161,10 @@ int avt_add_rows_bf16(void* dst, long ldd, const void* src, long lds, int rows, 
 /* dst[c][r] = src[r][c] (bf16): transposed shadow of a Linear weight (out,in) -> (in,out), so that the data gradient
  * dx = dy W of torch.nn.Linear's backward is a k-major x k-major GEMM like the forward (5-9 % faster for K or N >= 2304). */
 int avt_transpose_bf16(const void* src, long ld_src, void* dst, long ld_dst, int rows, int cols, void* stream);
+/* The same for `njobs` matrices in one launch.  jobs: DEVICE memory, njobs records of 40 bytes
+ * { const void* src; void* dst; int64 ld_src; int64 ld_dst; int32 rows; int32 cols; } (the caller builds the table once: the
+ * arena's weights do not move); max_tiles >= ceil(rows/64) * ceil(cols/64) of every job. */
+int avt_transpose_batch_bf16(const void* jobs, int njobs, int max_tiles, void* stream);
 /* ReLU + derivative mask (bf16 0/1) -- nn.TransformerEncoderLayer's activation (models/temporal_aggregation.py:87). */
 int avt_relu_bf16(const void* x, void* y, void* mask, long n, void* stream);
 

@@ -622,3 +622,11 @@ def test_transpose_bf16(ops):
     ops.transpose_into(big[10:138, 5:69], dst)                                     # strided source view
     torch.cuda.synchronize()
     assert torch.equal(dst, big[10:138, 5:69].t().contiguous())
+    # batched: one launch over a device table of (source, destination) records, mixed shapes incl. a non-vectorisable one
+    srcs = [rnd(sh, 1.0, 98 + i) for i, sh in enumerate([(768, 2304), (100, 37), (3072, 768), (64, 64), (136, 72)])] + [big[8:136, 8:72]]
+    dsts = [torch.zeros((x.size(1), x.size(0)), device='cuda', dtype=torch.bfloat16) for x in srcs]
+    jobs = ops.transpose_jobs(list(zip(srcs, dsts)))
+    ops.transpose_batch(jobs)
+    torch.cuda.synchronize()
+    for x, d in zip(srcs, dsts):
+        assert torch.equal(d, x.t().contiguous()), x.shape
