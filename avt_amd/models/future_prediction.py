@@ -132,7 +132,9 @@ class AVTh(nn.Module):
         keep = torch.is_grad_enabled()
         if keep:
             self._fwd_calls = getattr(self, '_fwd_calls', 0) + 1
-        seed = (next(AVTh._seed_counter) * 1000003) if self.training else 0
+        # dropout masks are a pure function of (seed, element index): the seed mixes the process's torch seed (torch.manual_seed)
+        # with a call counter, so a seeded run repeats and differently seeded runs differ
+        seed = ((next(AVTh._seed_counter) * 1000003 + torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF) if self.training else 0
         return _HeadFn.apply(self, arena, keep, self.training, seed, feats, self.encoder.weight)
 
     def _rollout(self, feats, output_len):

@@ -113,7 +113,7 @@ class Transformer(nn.Module):
         arena.refresh_shadow()
         if torch.is_grad_enabled():
             arena.attach_grads()
-        seed = (next(Transformer._seed_counter) * 1000033) if self.training else 0
+        seed = ((next(Transformer._seed_counter) * 1000033 + torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF) if self.training else 0
         enc = _TxFn.apply(self, arena, torch.is_grad_enabled(), self.training, seed, feats, self.downproject.weight)
         return (enc.mean(dim=1) if self.agg_style == 'mean' else enc[:, -1]), {}
 
