@@ -9,7 +9,7 @@ B, T, S, D, H = int(os.environ.get('KB_BATCH', 128)), 10, int(os.environ.get('KB
 N = B * T
 M = N * S
 ops.DETERMINISTIC_WGRAD = os.environ.get('KB_DET', '1') == '1'
-want = set(sys.argv[1:]) or {'ln', 'attn', 'cls', 'gemm', 'wgrad', 'sgd', 'preproc'}
+want = set(sys.argv[1:]) or {'ln', 'attn', 'cls', 'gemm', 'wgrad', 'sgd', 'preproc'}      # + 'blas': library GEMMs next to this repo's
 r = lambda *s: (torch.rand(s, device='cuda') * 2 - 1).to(torch.bfloat16)
 
 
@@ -118,3 +118,32 @@ if 'sgd' in want:
     p_, g_, m_ = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
     sh = torch.zeros(n, device='cuda', dtype=torch.bfloat16)
     timeit('sgd 396M', lambda: ops.sgd_step(p_, g_, m_, sh, 1e-4, 0.9, 1e-6), bytes_=n * 26)
+if 'blas' in want:
+    # library reference: torch.matmul (hipBLASLt / rocBLAS heuristics) on the step's plain GEMM shapes, next to this repo's kernels
+    import torch.nn.functional as F
+    x768, x2304, x3072 = r(M, D), r(M, 3 * D), r(M, 4 * D)
+    wq, w1, wp = r(3 * D, D), r(4 * D, D), r(D, D)
+    bq = torch.rand(3 * D, device='cuda').to(torch.bfloat16)
+    for name, fn, fl in [
+        ('lib qkv fwd  x[M,768] Wq^T + b', lambda: F.linear(x768, wq, bq), 2.0 * M * D * 3 * D),
+        ('lib fc1 dgrad dh[M,3072] W1', lambda: torch.matmul(x3072, w1), 2.0 * M * D * 4 * D),
+        ('lib qkv dgrad dqkv[M,2304] Wq', lambda: torch.matmul(x2304, wq), 2.0 * M * D * 3 * D),
+        ('lib proj dgrad dy[M,768] Wp', lambda: torch.matmul(x768, wp), 2.0 * M * D * D),
+        ('lib fc1 wgrad dh^T x (bf16 out)', lambda: torch.matmul(x3072.t(), x768), 2.0 * M * D * 4 * D),
+        ('lib qkv wgrad dqkv^T x (bf16 out)', lambda: torch.matmul(x2304.t(), x768), 2.0 * M * D * 3 * D),
+        ('lib proj wgrad dy^T x (bf16 out)', lambda: torch.matmul(x768.t(), x768), 2.0 * M * D * D),
+    ]:
+        timeit(name, fn, flops=fl, iters=10)
+    bq32 = bq.float()
+    wT1, wTq = w1.t().contiguous(), wq.t().contiguous()
+    g1, gq, gp = (torch.zeros(s, device='cuda') for s in [(4 * D, D), (3 * D, D), (D, D)])
+    for name, fn, fl in [
+        ('own qkv fwd', lambda: ops.linear_fwd(x768, wq, bias=bq32), 2.0 * M * D * 3 * D),
+        ('own fc1 dgrad (W^T shadow, NT)', lambda: ops.linear_fwd(x3072, wT1), 2.0 * M * D * 4 * D),
+        ('own qkv dgrad (W^T shadow, NT)', lambda: ops.linear_fwd(x2304, wTq), 2.0 * M * D * 3 * D),
+        ('own proj dgrad (NN)', lambda: ops.linear_dgrad(x768, wp), 2.0 * M * D * D),
+        ('own fc1 wgrad (fp32 accumulate)', lambda: ops.linear_wgrad(x3072, x768, g1), 2.0 * M * D * 4 * D),
+        ('own qkv wgrad (fp32 accumulate)', lambda: ops.linear_wgrad(x2304, x768, gq), 2.0 * M * D * 3 * D),
+        ('own proj wgrad (fp32 accumulate)', lambda: ops.linear_wgrad(x768, x768, gp), 2.0 * M * D * D),
+    ]:
+        timeit(name, fn, flops=fl, iters=10)
