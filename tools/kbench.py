@@ -1,5 +1,5 @@
 """Per-kernel timing on the bench shapes (HIP events, many launches): python tools/kbench.py [names...]
-names: ln attn cls gemm wgrad sgd   (default: all).  Prints microseconds per launch and the achieved TB/s or TFLOP/s."""
+names: ln attn cls gemm wgrad sgd preproc (default: all of these); blas / sdpa time the vendor libraries on the same shapes.  Prints microseconds per launch and the achieved TB/s or TFLOP/s."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -147,3 +147,17 @@ if 'blas' in want:
         ('own proj wgrad (fp32 accumulate)', lambda: ops.linear_wgrad(x768, x768, gp), 2.0 * M * D * D),
     ]:
         timeit(name, fn, flops=fl, iters=10)
+if 'sdpa' in want:
+    # library reference for the ViT attention core: torch scaled_dot_product_attention (ROCm flash / mem-efficient backends)
+    import torch.nn.functional as F
+    qkv = r(M, 3 * D)
+    q, k, v = (qkv.view(N, S, 3, H, 64)[:, :, i].permute(0, 2, 1, 3).contiguous().requires_grad_() for i in range(3))
+    fl = 4.0 * N * H * S * S * 64
+    timeit('lib sdpa fwd', lambda: F.scaled_dot_product_attention(q, k, v), flops=fl, iters=10)
+    o = F.scaled_dot_product_attention(q, k, v)
+    do = torch.randn_like(o)
+    timeit('lib sdpa bwd', lambda: torch.autograd.grad(o, (q, k, v), do, retain_graph=True), flops=2.5 * fl, iters=10)
+    o2, l2 = ops.vit_attn_fwd(qkv, N, S, H)
+    timeit('own vit_attn_fwd', lambda: ops.vit_attn_fwd(qkv, N, S, H), flops=fl, iters=10)
+    db = torch.zeros(3 * D, device='cuda')
+    timeit('own vit_attn_bwd (+dbias)', lambda: ops.vit_attn_bwd(qkv, o2, o2, l2, N, S, H, dbias=db), flops=2.5 * fl, iters=10)
