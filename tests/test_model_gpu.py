@@ -658,3 +658,48 @@ def test_twenty_step_loss_trajectory_matches_the_oracle():
     assert o_losses[-1] < 0.8 * o_losses[0], o_losses                          # the run actually learns
     for i, (a, b) in enumerate(zip(h_losses, o_losses)):
         assert abs(a - b) / abs(b) < 3e-2, (i, a, b)
+
+
+def test_step_is_faster_than_the_eager_pytorch_restatement_on_the_same_gpu():
+    """Context for the bench line (no published MI355X number exists): the fp32 restatement of the reference's model
+    (timm-style explicit attention, HF GPT-2 head, torch.optim.SGD) run EAGERLY on this GPU -- fp32 as the reference trains, and
+    under bf16 autocast -- against the HIP path on the same 32-clip batch of config 2.  Prints clips/s for the three; the HIP
+    step must be at least 2x the autocast one."""
+    import time
+    torch.manual_seed(5)
+    vitc, B, T, C = (768, 12, 12, 224), 32, 10, 3806
+    g = torch.Generator().manual_seed(12)
+    video = (torch.rand((B, T, 3, 1, 224, 224), generator=g) * 2 - 1).cuda()
+    target, sub = torch.randint(0, C, (B,), generator=g).cuda(), torch.randint(-1, C, (B, T, 1), generator=g).cuda()
+
+    def timed(step, n=3):
+        step(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return B * n / (time.perf_counter() - t0)
+
+    orc = build_oracle_model('vit', 768, 2048, 6, 4, C, vit=vitc).cuda()
+    opt = torch.optim.SGD(orc.parameters(), lr=1e-4, momentum=0.9, nesterov=True, weight_decay=1e-5)
+
+    def eager(autocast):
+        def step():
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+                oracle_step(orc, video, target, sub)
+            opt.step()
+        return step
+    r_fp32 = timed(eager(False))
+    r_amp = timed(eager(True))
+    del orc, opt
+    torch.cuda.empty_cache()
+    from avt_amd.optim import FusedSGD
+    model = build_hip_model('vit', 768, 2048, 6, 4, C, vit=vitc)
+    hopt = FusedSGD(model.parameters(), lr=1e-4, momentum=0.9, nesterov=True, weight_decay=1e-5, arena=model.arena)
+
+    def hip():
+        hip_step(model, video, target, sub)
+        hopt.step()
+    r_hip = timed(hip)
+    print(f'clips/s at {B} clips x {T} frames: eager fp32 {r_fp32:.1f}, eager bf16 autocast {r_amp:.1f}, HIP path {r_hip:.1f}')
+    assert r_hip > 2.0 * r_amp and r_hip > 2.0 * r_fp32, (r_fp32, r_amp, r_hip)
