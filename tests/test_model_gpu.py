@@ -703,3 +703,43 @@ def test_step_is_faster_than_the_eager_pytorch_restatement_on_the_same_gpu():
     r_hip = timed(hip)
     print(f'clips/s at {B} clips x {T} frames: eager fp32 {r_fp32:.1f}, eager bf16 autocast {r_amp:.1f}, HIP path {r_hip:.1f}')
     assert r_hip > 2.0 * r_amp and r_hip > 2.0 * r_fp32, (r_fp32, r_amp, r_hip)
+
+
+def test_bench_size_batch_matches_two_clips_tiled():
+    """The bench's own size (config 2, 256 clips x 10 frames = 504 320 token rows per GEMM, ~150 GB of saved activations) through a
+    size-independent property: a batch made of two distinct clips repeated 128 times gives every clip the logits of the 2-clip
+    run (row position in a 256x256 tile, XCD tile order and persistent attention scheduling must not matter), the same mean
+    losses, and -- the losses being batch means -- the same parameter gradients up to fp32 summation order."""
+    torch.cuda.empty_cache()
+    torch.manual_seed(7)
+    vitc, T, C, REP = (768, 12, 12, 224), 10, 3806, 128
+    model = build_hip_model('vit', 768, 2048, 6, 4, C, vit=vitc)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.03)
+    g = torch.Generator().manual_seed(13)
+    v2 = (torch.rand((2, T, 3, 1, 224, 224), generator=g) * 2 - 1).cuda()
+    t2, s2 = torch.randint(0, C, (2,), generator=g).cuda(), torch.randint(-1, C, (2, T, 1), generator=g).cuda()
+    names = ['classifiers.action.weight', 'future_predictor.decoder.weight', 'future_predictor.gpt_model.h.2.mlp.c_fc.weight',
+             'backbone.model.norm.weight', 'backbone.model.blocks.11.attn.qkv.weight', 'backbone.model.blocks.6.mlp.fc1.weight',
+             'backbone.model.blocks.6.mlp.fc1.bias', 'backbone.model.blocks.3.attn.qkv.bias', 'backbone.model.blocks.0.norm1.weight',
+             'backbone.model.blocks.0.attn.proj.weight', 'backbone.model.patch_embed.proj.weight', 'backbone.model.pos_embed']
+    params = dict(model.named_parameters())
+    out2, losses2, _, tot2 = hip_step(model, v2, t2, s2)
+    ref_logits = out2['logits/action'].float().clone()
+    ref_past = out2['logits/action_past'].float().clone() if 'logits/action_past' in out2 else None
+    ref_grads = {n: params[n].grad.detach().clone() for n in names}
+    ref_tot = float(tot2.detach())
+    del out2, losses2, tot2
+    vb, tb, sb = v2.repeat(REP, 1, 1, 1, 1, 1), t2.repeat(REP), s2.repeat(REP, 1, 1)
+    out, losses, _, tot = hip_step(model, vb, tb, sb)
+    assert vb.size(0) == 256 and torch.cuda.max_memory_allocated() > 100e9          # the bench's footprint was really exercised
+    lg = out['logits/action'].float()
+    assert torch.equal(lg.view(REP, 2, -1), ref_logits.unsqueeze(0).expand(REP, -1, -1))
+    if ref_past is not None:
+        assert torch.equal(out['logits/action_past'].float().view(REP, *ref_past.shape), ref_past.unsqueeze(0).expand(REP, *ref_past.shape))
+    assert abs(float(tot) - ref_tot) / abs(ref_tot) < 1e-5
+    for n in names:
+        e = rel(params[n].grad, ref_grads[n])
+        assert e < 2e-3, (n, e)
