@@ -705,15 +705,18 @@ def test_step_is_faster_than_the_eager_pytorch_restatement_on_the_same_gpu():
     assert r_hip > 2.0 * r_amp and r_hip > 2.0 * r_fp32, (r_fp32, r_amp, r_hip)
 
 
-def test_bench_size_batch_matches_two_clips_tiled():
-    """The bench's own size (config 2, 256 clips x 10 frames = 504 320 token rows per GEMM, ~150 GB of saved activations) through a
+@pytest.mark.parametrize('vitc,T,REP', [((768, 12, 12, 224), 10, 128), ((768, 12, 12, 224), 15, 64), ((1024, 24, 16, 224), 10, 48)],
+                         ids=['config2_256clips', 'config4_T15_128clips', 'config5_vitl_96clips'])
+def test_bench_size_batch_matches_two_clips_tiled(vitc, T, REP):
+    """The bench's own sizes (config 2: 256 clips x 10 frames = 504 320 token rows per GEMM, ~150 GB of saved activations; config 4:
+    128 clips x 15 frames; config 5: ViT-L/16, 96 clips) through a
     size-independent property: a batch made of two distinct clips repeated 128 times gives every clip the logits of the 2-clip
     run (row position in a 256x256 tile, XCD tile order and persistent attention scheduling must not matter), the same mean
     losses, and -- the losses being batch means -- the same parameter gradients up to fp32 summation order."""
     torch.cuda.empty_cache()
     torch.manual_seed(7)
-    vitc, T, C, REP = (768, 12, 12, 224), 10, 3806, 128
-    model = build_hip_model('vit', 768, 2048, 6, 4, C, vit=vitc)
+    C, last = 3806, vitc[1] - 1
+    model = build_hip_model('vit', vitc[0], 2048, 6, 4, C, vit=vitc)
     with torch.no_grad():
         for n, p in model.named_parameters():
             if p.ndim >= 2:
@@ -722,7 +725,7 @@ def test_bench_size_batch_matches_two_clips_tiled():
     v2 = (torch.rand((2, T, 3, 1, 224, 224), generator=g) * 2 - 1).cuda()
     t2, s2 = torch.randint(0, C, (2,), generator=g).cuda(), torch.randint(-1, C, (2, T, 1), generator=g).cuda()
     names = ['classifiers.action.weight', 'future_predictor.decoder.weight', 'future_predictor.gpt_model.h.2.mlp.c_fc.weight',
-             'backbone.model.norm.weight', 'backbone.model.blocks.11.attn.qkv.weight', 'backbone.model.blocks.6.mlp.fc1.weight',
+             'backbone.model.norm.weight', f'backbone.model.blocks.{last}.attn.qkv.weight', 'backbone.model.blocks.6.mlp.fc1.weight',
              'backbone.model.blocks.6.mlp.fc1.bias', 'backbone.model.blocks.3.attn.qkv.bias', 'backbone.model.blocks.0.norm1.weight',
              'backbone.model.blocks.0.attn.proj.weight', 'backbone.model.patch_embed.proj.weight', 'backbone.model.pos_embed']
     params = dict(model.named_parameters())
@@ -734,12 +737,16 @@ def test_bench_size_batch_matches_two_clips_tiled():
     del out2, losses2, tot2
     vb, tb, sb = v2.repeat(REP, 1, 1, 1, 1, 1), t2.repeat(REP), s2.repeat(REP, 1, 1)
     out, losses, _, tot = hip_step(model, vb, tb, sb)
-    assert vb.size(0) == 256 and torch.cuda.max_memory_allocated() > 100e9          # the bench's footprint was really exercised
+    assert vb.size(0) == 2 * REP and torch.cuda.max_memory_allocated() > 100e9      # the bench's footprint was really exercised
     lg = out['logits/action'].float()
     assert torch.equal(lg.view(REP, 2, -1), ref_logits.unsqueeze(0).expand(REP, -1, -1))
     if ref_past is not None:
         assert torch.equal(out['logits/action_past'].float().view(REP, *ref_past.shape), ref_past.unsqueeze(0).expand(REP, *ref_past.shape))
-    assert abs(float(tot) - ref_tot) / abs(ref_tot) < 1e-5
+    assert abs(float(tot.detach()) - ref_tot) / abs(ref_tot) < 1e-5
+    # 1/B is folded into the bf16 loss gradient: exact for B = 256 / 128 (powers of two), one more bf16 rounding for B = 96
+    # (every later bf16 rounding of the backward then falls differently: independent bf16 noise, within the stated 4e-2 gradient tolerance)
+    from helpers import cosine
+    tol = 2e-3 if (2 * REP) & (2 * REP - 1) == 0 else 3e-2      # 24 layers deep: 2.1e-2 measured on blocks.0.norm1, cosine 0.9998
     for n in names:
         e = rel(params[n].grad, ref_grads[n])
-        assert e < 2e-3, (n, e)
+        assert e < tol and cosine(params[n].grad, ref_grads[n]) > 0.9995, (n, e, cosine(params[n].grad, ref_grads[n]))
