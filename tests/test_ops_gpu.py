@@ -630,3 +630,72 @@ def test_transpose_bf16(ops):
     torch.cuda.synchronize()
     for x, d in zip(srcs, dsts):
         assert torch.equal(d, x.t().contiguous()), x.shape
+
+
+def test_bench_size_kernels_on_sampled_rows(ops):
+    """The dominant kernels at the bench's own shapes (256 clips x 10 frames: M = 504 320 token rows, 2560 frames x 12 heads),
+    checked against fp32 torch on SAMPLED rows / frames so the reference stays small: the 8-phase GEMM with its four epilogues
+    (5910 / 17730 / 23640 tiles), the weight-gradient accumulate over the full M-deep reduction, LayerNorm forward / backward, and
+    the attention kernels over all 30 720 (frame, head) items."""
+    frames, S, H, D = 2560, 197, 12, 768
+    M = frames * S
+    g = torch.Generator(device='cuda').manual_seed(5)
+    rows = torch.randint(0, M, (4096,), device='cuda', generator=g)
+    rows[:3] = torch.tensor([0, M - 1, M - 257], device='cuda')
+    x = rnd((M, D), 1.0, 101)
+    # fc1 forward: bias + GELU + saved derivative (23640 tiles)
+    w1, b1 = rnd((4 * D, D), 0.05, 102), torch.randn(4 * D, device='cuda') * 0.1
+    act, dact = torch.empty((M, 4 * D), device='cuda', dtype=torch.bfloat16), torch.empty((M, 4 * D), device='cuda', dtype=torch.bfloat16)
+    ops.linear_fwd(x, w1, bias=b1, act=ops.ACT_GELU_ERF, c2=dact, out=act)
+    h = (x[rows].float() @ w1.float().t() + b1).requires_grad_()
+    ref = torch.nn.functional.gelu(h)
+    ref.sum().backward()
+    assert relerr(act[rows], ref) < 1e-2 and relerr(dact[rows], h.grad) < 1e-2
+    # fc2 forward: bias + residual (5910 tiles, K = 3072); qkv-shaped output (17730 tiles); data gradient x saved derivative + colsum
+    w2, b2 = rnd((D, 4 * D), 0.05, 103), torch.randn(D, device='cuda') * 0.1
+    y = ops.linear_fwd(act, w2, bias=b2, res=x)
+    assert relerr(y[rows], act[rows].float() @ w2.float().t() + b2 + x[rows].float()) < 1e-2
+    wq = rnd((3 * D, D), 0.05, 104)
+    qkv = ops.linear_fwd(x, wq)
+    assert relerr(qkv[rows], x[rows].float() @ wq.float().t()) < 1e-2
+    cs = torch.zeros(4 * D, device='cuda')
+    dh = ops.linear_dgrad(x, w2, act=ops.ACT_MUL_AUX, aux=dact, colsum=cs)
+    assert relerr(dh[rows], (x[rows].float() @ w2.float()) * dact[rows].float()) < 1e-2
+    assert relerr(cs, dh.float().sum(0)) < 1e-3
+    del y
+    # weight gradient: the full 504 320-deep reduction, fp32 accumulate into a non-zero buffer
+    dw = torch.full((4 * D, D), 0.5, device='cuda')
+    ops.linear_wgrad(dh, x, dw)
+    ref_dw = torch.zeros((4 * D, D), device='cuda')
+    for c0 in range(0, M, 65536):
+        ref_dw += dh[c0:c0 + 65536].float().t() @ x[c0:c0 + 65536].float()
+    assert relerr(dw - 0.5, ref_dw) < 2e-3
+    del dw, ref_dw, dh, act, dact
+    # LayerNorm forward / backward
+    gam, bet = torch.rand(D, device='cuda') + 0.5, torch.randn(D, device='cuda') * 0.1
+    ln, mean, rstd = ops.layernorm_fwd(x, gam, bet, 1e-6)
+    xr = x[rows].float().requires_grad_()
+    lref = torch.nn.functional.layer_norm(xr, (D,), gam, bet, 1e-6)
+    assert relerr(ln[rows], lref) < 1e-2
+    dy, dres = rnd((M, D), 1.0, 105), rnd((M, D), 1.0, 106)
+    dg, db = torch.zeros(D, device='cuda'), torch.zeros(D, device='cuda')
+    dx = ops.layernorm_bwd(dy, x, mean, rstd, gam, dg, db, dres=dres)
+    lref.backward(dy[rows].float())
+    assert relerr(dx[rows], xr.grad + dres[rows].float()) < 1e-2
+    assert relerr(db, dy.float().sum(0)) < 1e-3
+    del ln, dx, dy, dres
+    # attention over all (frame, head) items; reference on sampled frames
+    out, lse = ops.vit_attn_fwd(qkv, frames, S, H)
+    do = rnd((M, D), 1.0, 107)
+    dbias = torch.zeros(3 * D, device='cuda')
+    dqkv = ops.vit_attn_bwd(qkv, out, do, lse, frames, S, H, dbias=dbias)
+    torch.cuda.synchronize()
+    for f in [0, 1, 255, 256, 1279, 2047, 2559]:
+        sl = slice(f * S, (f + 1) * S)
+        t = qkv[sl].float().view(S, 3, H, 64).permute(1, 2, 0, 3).contiguous().requires_grad_()
+        att = ((t[0] @ t[1].transpose(-2, -1)) * 0.125).softmax(-1)
+        r = (att @ t[2]).transpose(0, 1).reshape(S, D)
+        r.backward(do[sl].float())
+        assert relerr(out[sl], r) < 1e-2, f
+        assert relerr(dqkv[sl], t.grad.permute(2, 0, 1, 3).reshape(S, 3 * D)) < 2e-2, f
+    assert relerr(dbias, dqkv.float().sum(0)) < 5e-3
