@@ -238,7 +238,9 @@ def main(argv=None):
                 'traffic': None if pmc is None else pmc['hbm_bytes_per_step'],
                 'traffic_source': None if pmc is None else pmc.get('source'),
                 'algorithmic_bytes_per_step': algorithmic_bytes_per_step(D, L, args.frames, args.batch),
-                'hbm_time_floor_ms_at_6p3TBs': round(algorithmic_bytes_per_step(D, L, args.frames, args.batch) / 6.3e12 * 1e3, 2)}
+                'hbm_time_floor_ms_at_6p3TBs': round(algorithmic_bytes_per_step(D, L, args.frames, args.batch) / 6.3e12 * 1e3, 2),
+                'peak_note': 'peak = dense bf16 MFMA at the nominal clock (MI355X_MICROARCH.md); a bare MFMA loop on pseudo-random bf16 '
+                             'operands sustains 1.79-1.97 PFLOP/s on this part (power-limited clock, profiles/r02_mfma_feed_lab.txt)'}
         if tm > 0:
             ach = fl / tm / 1e12
             roof['dominant_kernel'] = {
