@@ -15,7 +15,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // NW waves; wave tile = TM x TN 32x32 blocks; per 16-deep k-step a wave reads TM + TN fragments and issues TM*TN MFMAs.
 // READS: fragments come from LDS (else stay in registers).  DMA: the wave issues its share of the 64 one-KB LDS-DMA per K step,
 // spread between the MFMAs of the first three k-steps.  BAR: one s_barrier (+ counted vmcnt) per K step.
-template <int NW, int TM, int TN, bool READS, bool DMA, int BAR>      // BAR: barriers per K step (0, 1, 4 or 8)
+template <int NW, int TM, int TN, bool READS, bool DMA, int BAR, bool ILV = false>      // BAR: barriers per K step (0, 1, 4 or 8); ILV: one fragment read after every other MFMA instead of a burst
 __global__ __launch_bounds__(64 * NW) void feed_kernel(const char* src, float* out, long long* cyc, int ksteps, int random_bits) {
   extern __shared__ __attribute__((aligned(16))) char lds[];        // 128 KB: two 64 KB stages
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,8 +57,8 @@ __global__ __launch_bounds__(64 * NW) void feed_kernel(const char* src, float* o
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int cur = ks & 1, nxt = cur ^ 1;
-      if (READS) {                                                   // fragments of the next k-step (of the next stage's first at ks = 3)
-        const char* s2 = (ks < 3) ? stage + (ks + 1) * 8192 : fill;
+      const char* s2 = (ks < 3) ? stage + (ks + 1) * 8192 : fill;
+      if (READS && !ILV) {                                           // fragments of the next k-step (of the next stage's first at ks = 3)
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[nxt][i] = *(const bf16x8*)(s2 + (wm * TM + i) * 1024 + lane * 16);
 #pragma unroll
@@ -71,6 +71,17 @@ __global__ __launch_bounds__(64 * NW) void feed_kernel(const char* src, float* o
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+          if (READS && ILV) {                                        // spread: fragment (i*TN+j)/2 after every second MFMA
+            constexpr int NF = TM + TN;
+            const int m = i * TN + j;
+            if (m % 2 == 1 && m / 2 < NF) {
+              __builtin_amdgcn_sched_barrier(0);
+              const int f = m / 2;
+              if (f < TM) fa[nxt][f] = *(const bf16x8*)(s2 + (wm * TM + f) * 1024 + lane * 16);
+              else fb[nxt][f - TM] = *(const bf16x8*)(s2 + 32768 + (wn * TN + (f - TM)) * 1024 + lane * 16);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
           if (BAR >= 8 && i * TN + j == TM * TN / 2 - 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
           constexpr int STRIDE = (TM * TN) / PER > 0 ? (TM * TN) / PER : 1;
           if (DMA && ks < 3 && (i * TN + j) % STRIDE == 0 && in_ks < PER && dma_done < NDMA) {     // spread between the MFMAs
@@ -100,15 +111,15 @@ __global__ __launch_bounds__(64 * NW) void feed_kernel(const char* src, float* o
   if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
 }
 
-template <int NW, int TM, int TN, bool READS, bool DMA, int BAR>
+template <int NW, int TM, int TN, bool READS, bool DMA, int BAR, bool ILV = false>
 void run(const char* name, const char* src, float* out, long long* cyc, int random_bits) {
   const int ksteps = 2000, nblk = 256;
-  CK(hipFuncSetAttribute((const void*)feed_kernel<NW, TM, TN, READS, DMA, BAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  CK(hipFuncSetAttribute((const void*)feed_kernel<NW, TM, TN, READS, DMA, BAR, ILV>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((feed_kernel<NW, TM, TN, READS, DMA, BAR>), dim3(nblk), dim3(64 * NW), 131072, 0, src, out, cyc, ksteps, random_bits);
+  hipLaunchKernelGGL((feed_kernel<NW, TM, TN, READS, DMA, BAR, ILV>), dim3(nblk), dim3(64 * NW), 131072, 0, src, out, cyc, ksteps, random_bits);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL((feed_kernel<NW, TM, TN, READS, DMA, BAR>), dim3(nblk), dim3(64 * NW), 131072, 0, src, out, cyc, ksteps, random_bits);
+  hipLaunchKernelGGL((feed_kernel<NW, TM, TN, READS, DMA, BAR, ILV>), dim3(nblk), dim3(64 * NW), 131072, 0, src, out, cyc, ksteps, random_bits);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   long long c; CK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
@@ -138,6 +149,8 @@ int main() {
   run<4, 4, 4, true, false, 1>("4 waves 128x128: + reads + barrier", src, out, cyc, random_bits);
   run<4, 4, 4, false, true, 1>("4 waves 128x128: + LDS-DMA (16 / wave) + barrier", src, out, cyc, random_bits);
   run<4, 4, 4, true, true, 1>("4 waves 128x128: + reads + LDS-DMA + barrier", src, out, cyc, random_bits);
+  run<4, 4, 4, true, false, 0, true>("4 waves 128x128: + reads spread between the MFMAs", src, out, cyc, random_bits);
+  run<4, 4, 4, true, true, 1, true>("4 waves 128x128: + spread reads + LDS-DMA + barrier", src, out, cyc, random_bits);
   }
   return 0;
 }
