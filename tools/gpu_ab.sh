@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B session: a few parity tests, then bench lines under different settings.  usage: tools/gpu_ab.sh TAG
+# A/B session: a few parity tests, then bench lines for the product library and for other builds of it.  usage: tools/gpu_ab.sh TAG [lib.so ...]
 TAG=${1:-ab}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -15,7 +15,11 @@ except Exception as e:
     print(sys.argv[1], 'FAILED', e)
 PY
 }
-run base128 python bench.py $B
-run base133 python bench.py $B --batch 133
-export AVT_HIP_LIB=$GRAFT_REPO_ROOT/avt_amd/libavt_hip_lab.so
-for st in 0 3 4 6; do AVT_GEMM_STRIP=$st run lab_strip$st python bench.py $B; done
+# the product library, then every extra library given on the command line (e.g. a lab build with a variant compiled in):
+#   tools/gpu_ab.sh TAG avt_amd/libavt_hip_lab.so avt_amd/libavt_variant.so
+run product python bench.py $B
+shift
+for lib in "$@"; do
+  AVT_HIP_LIB=$GRAFT_REPO_ROOT/$lib run $(basename $lib .so) python bench.py $B
+done
+run product_again python bench.py $B
