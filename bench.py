@@ -240,7 +240,8 @@ def main(argv=None):
                 'algorithmic_bytes_per_step': algorithmic_bytes_per_step(D, L, args.frames, args.batch),
                 'hbm_time_floor_ms_at_6p3TBs': round(algorithmic_bytes_per_step(D, L, args.frames, args.batch) / 6.3e12 * 1e3, 2),
                 'peak_note': 'peak = dense bf16 MFMA at the nominal clock (MI355X_MICROARCH.md); a bare MFMA loop on pseudo-random bf16 '
-                             'operands sustains 1.79-1.97 PFLOP/s on this part (power-limited clock, profiles/r02_mfma_feed_lab.txt)'}
+                             'operands sustains 1.79-1.97 PFLOP/s on this part (power-limited clock, profiles/r02_mfma_feed_lab.txt); this bench '
+                             'draws 1.35-1.37 kW of the 1.4 kW package cap at 1.84-1.89 GHz (profiles/r02_power_clock_under_bench.txt)'}
         if tm > 0:
             ach = fl / tm / 1e12
             roof['dominant_kernel'] = {
