@@ -56,6 +56,7 @@ class ParamArena:
                 p.grad = self.grad[o:o + k].view(p.shape)
                 self.params[n] = p
                 self.name_of[id(p)] = n
+        self._plist = [self.params[n] for n in self.names]
         self._version = None
         self._transposed = {}            # name -> bf16 (in, out) copy of a Linear weight's shadow (see transposed_of)
         self._transpose_jobs = None      # device job table of refresh_transposed
@@ -134,10 +135,15 @@ class ParamArena:
         ops.transpose_batch(self._transpose_jobs)
 
     def grads_attached(self):
-        """Cheap check (first / last parameter): ``zero_grad(set_to_none=True)`` drops every ``.grad`` or none."""
+        """True when every parameter still has a ``.grad`` (a torch optimizer's ``zero_grad(set_to_none=True)`` drops the
+        gradients of ITS OWN groups only -- possibly a middle slice of the arena, e.g. the future predictor alone with the
+        backbone frozen -- so every parameter is looked at; the look is one attribute read each) and the first / last one
+        still alias the flat buffer (re-allocation, e.g. ``model.to()``, moves all of them together)."""
+        for p in self._plist:
+            if p.grad is None:
+                return False
         for n in (self.names[0], self.names[-1]):
-            p = self.params[n]
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self.offsets[n]:
+            if self.params[n].grad.data_ptr() != self.grad.data_ptr() + 4 * self.offsets[n]:
                 return False
         return True
 

@@ -1,26 +1,13 @@
-"""Helpers mirrored from the reference's common/utils.py: top-k accuracy (:17-44) and distributed init (:106-150)."""
+"""Host helpers of the path: top-k accuracy from the fused cross-entropy kernel's target ranks (the numbers of the reference's
+common/utils.py:17-44 ``accuracy``) and one-process-per-GPU distributed init (:106-150)."""
 import os
 
 import torch
 import torch.distributed as dist
 
 
-def accuracy(output, target, topk=(1,)):
-    """Top-k accuracy in percent over all rows (ignored targets < 0 count as misses); all-ignored batch -> zeros."""
-    if torch.all(target < 0):
-        return [torch.zeros([], device=output.device) for _ in range(len(topk))]
-    with torch.no_grad():
-        output = output.flatten(0, -2)
-        target = target.flatten()
-        maxk = max(topk)
-        batch_size = target.size(0)
-        _, pred = output.topk(maxk, 1, True, True)
-        correct = pred.t().eq(target[None])
-        return [correct[:k].flatten().sum(dtype=torch.float32) * (100.0 / batch_size) for k in topk]
-
-
 def accuracy_from_rank(rank, target, topk=(1,)):
-    """Same numbers as ``accuracy`` from the target-rank vector the fused cross-entropy kernel emits (rank = number of logits
+    """The reference's top-k accuracy (percent over ALL rows) from the target-rank vector the fused cross-entropy kernel emits (rank = number of logits
     strictly above the target's, -1 for ignored rows): a row is a top-k hit iff 0 <= rank < k.  Rows with ignored targets
     count as misses and an all-ignored batch gives zeros, as in the reference (common/utils.py:17-44)."""
     with torch.no_grad():

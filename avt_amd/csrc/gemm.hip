@@ -189,6 +189,20 @@ __device__ __forceinline__ void stagger_start(int cycles, int bid) {
   while (__builtin_readcyclecounter() - t0 < target) __builtin_amdgcn_s_sleep(16);
 }
 
+#ifdef AVT_LAB
+// lab: two workgroups share a CU; the one in the odd threadgroup slot of the FIRST dispatch wave starts `cycles` late, so that
+// afterwards one workgroup's epilogue (vector ALU, stores) runs under the other's K loop (matrix pipe) instead of both doing
+// the same thing at the same time.  HW_REG_HW_ID (id 4): TG_ID = bits 19:16.
+__device__ __forceinline__ void stagger_slot(int cycles, int bid, int nfirst) {
+  if (cycles <= 0 || bid >= nfirst) return;
+  uint32_t hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  if (((hw >> 16) & 1u) == 0) return;
+  const long long t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+}
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -727,6 +741,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
   const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
   const int nk = kt_end - kt_begin;
+#ifdef AVT_LAB
+  if (MINW >= 2) stagger_slot(p.stagger, bid, 512); else
+#endif
   stagger_start(AVT_STAGGER(p), bid);
 
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
@@ -1695,6 +1712,11 @@ static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kma
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_8p(p, epi, a_kmajor, b_kmajor, splitk, s);
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
 #ifdef AVT_LAB
+    // two independent 4-wave workgroups per CU (<= 80 KB LDS, <= 256 registers each), optionally started half a tile apart
+    // (AVT_GEMM_STAGGER cycles): while one is in its epilogue the other owns the matrix pipe
+    case 2563: return dispatch_epi<256, 128, 2, 2, 32, 3, true, 0, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
+    case 2562: return dispatch_epi<256, 128, 2, 2, 32, 3, false, 0, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
+    case 1283: return dispatch_epi<128, 256, 1, 4, 32, 3, true, 0, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 258: return dispatch_deepa(p, epi, a_kmajor, b_kmajor, splitk, s);                          // A ring 3 deep, B ring 2 deep
     case 512: return dispatch_pp(p, epi, a_kmajor, b_kmajor, splitk, s);                            // ping-pong 256x256
 #endif

@@ -53,6 +53,7 @@ SIGNATURES = {
 }
 
 _lib = None
+N_CALLS = 0          # C-ABI calls made by this process (bench.py reports calls per step: every call is one or two kernel launches)
 
 
 # workspace-size queries (return size_t, cannot fail)
@@ -98,6 +99,8 @@ def load():
 
 
 def call(name, *args):
+    global N_CALLS
+    N_CALLS += 1
     lib = load()
     rc = getattr(lib, name)(*args)
     if rc != 0:

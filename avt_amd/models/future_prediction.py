@@ -130,8 +130,6 @@ class AVTh(nn.Module):
         if torch.is_grad_enabled():
             arena.attach_grads()
         keep = torch.is_grad_enabled()
-        if keep:
-            self._fwd_calls = getattr(self, '_fwd_calls', 0) + 1
         # dropout masks are a pure function of (seed, element index): the seed mixes the process's torch seed (torch.manual_seed)
         # with a call counter, so a seeded run repeats and differently seeded runs differ
         seed = ((next(AVTh._seed_counter) * 1000003 + torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF) if self.training else 0

@@ -85,8 +85,6 @@ class HipViT(nn.Module):
         if torch.is_grad_enabled():
             arena.attach_grads()
         keep = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if keep:
-            self._fwd_calls = getattr(self, '_fwd_calls', 0) + 1
         return _ViTFn.apply(self, arena, keep, frames, self.cls_token)   # one parameter stands in for all of them
 
 

@@ -44,6 +44,15 @@ def flops_per_clip(D, L, T, Dh=2048, Lh=6, C=NUM_CLASSES, S=197):
     return 3 * (T * f_v + f_h) - T * patch
 
 
+def flops_skipped_per_clip(D, T, S=197):
+    """Work of the LAST ViT block that the CLS-only evaluation never executes (timm consumes x[:, 0] only):
+    the full block minus {k|v projection on all tokens, q / proj / MLP on one token, single-query attention}; x3 for
+    forward + backward.  ``flops_per_clip`` (SURVEY 8d's numerator) still counts it; ``executed_frac`` does not."""
+    full = 2 * S * D * 3 * D + 4 * S * S * D + 2 * S * D * D + 4 * S * D * 4 * D
+    done = 2 * S * D * 2 * D + 2 * D * D + 4 * S * D + 2 * D * D + 4 * D * 4 * D
+    return 3 * T * (full - done)
+
+
 def algorithmic_bytes_per_step(D, L, T, B, Dh=2048, Lh=6, S=197):
     """HBM bytes per step per GPU of the implemented dataflow if every tensor crossed HBM exactly as often as the kernel
     sequence consumes / produces it (DESIGN.md section 4 lists the per-kernel terms).  Unit u = one [tokens, D] bf16 tensor.
@@ -84,7 +93,8 @@ def build(args, device, world):
     opt = FusedSGD(model.parameters(), lr=1e-4 * world, momentum=0.9, nesterov=True, weight_decay=1e-6, arena=model.arena)
     op = Basic(model, device, None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
     trainer = Trainer(model, op, opt, None, {'cls_action': 1.0, 'past_cls_action': 1.0, 'feat': 1.0}, distributed=world > 1,
-                      bucket_bytes=args.bucket_mb << 20, reduce_mode=args.reduce_mode)
+                      bucket_bytes=args.bucket_mb << 20, reduce_mode=args.reduce_mode,
+                      wire_dtype=torch.bfloat16 if args.wire_dtype == 'bf16' else torch.float32)
     rank = int(os.environ.get('RANK', 0))
     data = synthetic_batch(args.batch, args.frames, NUM_CLASSES, device, seed=42 + rank)
     return trainer, data
@@ -93,7 +103,7 @@ def build(args, device, world):
 def cpu_baseline(args):
     """fp32 CPU oracle, fwd + bwd + SGD-nesterov, B = 1 clip (bounded sample of the same workload)."""
     from oracle import avt_oracle as O
-    cores = min(os.cpu_count() or 1, 64)
+    cores = os.cpu_count() or 1                 # BASELINE.md section 3: every host core, count reported
     torch.set_num_threads(cores)
     D, L, H = VIT[args.model]
     orc = O.OracleBaseModel(O.OracleTIMMModel(vit=O.OracleViT(D, L, H)),
@@ -169,6 +179,7 @@ def main(argv=None):
     ap.add_argument('--model', default='vit_base_patch16_224', choices=list(VIT))
     ap.add_argument('--bucket-mb', type=int, default=64)
     ap.add_argument('--reduce-mode', default='all_reduce', choices=['all_reduce', 'rs_ag'], help='gradient exchange per bucket: RCCL all-reduce, or reduce-scatter + all-gather')
+    ap.add_argument('--wire-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (bf16 halves the xGMI bytes; the sum then keeps 8 mantissa bits)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="'gloo' lets several ranks share one GPU (a functional check of the N > 1 path on a 1-GPU box; never a measurement)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-trace', action='store_true')
@@ -201,11 +212,20 @@ def main(argv=None):
     sync()
     trace = None if args.no_gemm_trace else []
     ops.GEMM_TRACE = trace
+    from avt_amd import lib as _abi
+    calls0 = _abi.N_CALLS
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _, _, _ = trainer.step(data)
+    host_enqueue = time.perf_counter() - t0          # the Python side is done enqueuing; the GPU may still be running
     sync()
     elapsed_local = time.perf_counter() - t0
+    abi_calls = _abi.N_CALLS - calls0
+    comm = trainer.reducer.stats(last=args.steps) if trainer.reducer is not None else None
+    comm_all = [comm]
+    if dist_on:
+        comm_all = [None] * world
+        dist.all_gather_object(comm_all, comm)
     ops.GEMM_TRACE = None
     t = torch.tensor([elapsed_local], device=device, dtype=torch.float64)
     per_rank = [t.clone() for _ in range(world)]
@@ -235,6 +255,8 @@ def main(argv=None):
         roof = {'bound': 'mfma', 'scope': 'whole training step (fwd + bwd + SGD) per GPU: clips/s/GPU x algorithmic GFLOP/clip (SURVEY 8d)',
                 'achieved': round(step_tf, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(step_tf / MFMA_PEAK_TFLOPS, 4),
+                'frac_counts': 'algorithmic FLOPs (SURVEY 8d), including the part of the last ViT block that the CLS-only evaluation skips',
+                'executed_frac': round(clips / world * (fclip - flops_skipped_per_clip(D, args.frames)) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                 'traffic': None if pmc is None else pmc['hbm_bytes_per_step'],
                 'traffic_source': None if pmc is None else pmc.get('source'),
                 'algorithmic_bytes_per_step': algorithmic_bytes_per_step(D, L, args.frames, args.batch),
@@ -260,7 +282,11 @@ def main(argv=None):
                           'clips_per_gpu': args.batch, 'global_batch': args.batch * world, 'frames': args.frames,
                           'parallelism': f'dp{world}', 'gflop_per_clip': round(fclip / 1e9, 2), 'final_loss': round(loss_val, 4)},
                'per_rank_clips_per_s': [round(args.batch * args.steps / float(x), 2) for x in per_rank],
+               'host': {'abi_calls_per_step': round(abi_calls / args.steps, 1), 'enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 2),
+                        'note': 'rank 0: C-ABI calls (1-2 kernel launches each) and Python time to enqueue one step; enqueue >= ms_per_step means the step is host-bound'},
                'roofline': roof}
+        if comm_all[0] is not None:
+            out['comm'] = {'per_rank': comm_all, 'note': 'comm_exposed_ms = time the optimizer waited for the gradient exchange after backward had finished'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

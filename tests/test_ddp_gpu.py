@@ -93,7 +93,8 @@ torch.manual_seed(0)
 model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
 opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, arena=model.arena)
 op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
-tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=True, bucket_bytes=64 << 10, force_reducer=True, reduce_mode=os.environ.get('AVT_TEST_REDUCE_MODE', 'all_reduce'))
+tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=True, bucket_bytes=64 << 10, force_reducer=True, reduce_mode=os.environ.get('AVT_TEST_REDUCE_MODE', 'all_reduce'),
+             wire_dtype=torch.bfloat16 if os.environ.get('AVT_TEST_WIRE') == 'bf16' else torch.float32)
 assert tr.reducer is not None
 g = torch.Generator().manual_seed(9)
 data = {'video': (torch.rand((2, 4, 3, 1, 32, 32), generator=g) * 2 - 1).cuda(), 'target': {'action': torch.randint(0, 17, (2,), generator=g).cuda()},
@@ -104,13 +105,16 @@ for _ in range(2):
 torch.cuda.synchronize()
 assert tr.reducer.launched > 2, tr.reducer.launched          # bucketed RCCL all-reduces really ran, on the side stream
 assert not torch.equal(before, model.classifiers.action.weight) and float(loss) == float(loss)
+st = tr.reducer.stats()
+assert st['buckets_per_step'] == tr.reducer.launched and st['comm_exposed_ms'] >= 0.0 and st['mode'] == os.environ.get('AVT_TEST_REDUCE_MODE', 'all_reduce'), st
+assert st['bytes_per_step'] == model.arena.total * (2 if os.environ.get('AVT_TEST_WIRE') == 'bf16' else 4), st
 dist.barrier(); dist.destroy_process_group()
 print('OK nccl', tr.reducer.launched)
 '''
 
 
-@pytest.mark.parametrize('mode', ['all_reduce', 'rs_ag'])
-def test_rccl_executes_the_bucketed_allreduce_on_one_gpu(tmp_path, mode):
+@pytest.mark.parametrize('mode,wire', [('all_reduce', 'fp32'), ('rs_ag', 'fp32'), ('all_reduce', 'bf16'), ('rs_ag', 'bf16')])
+def test_rccl_executes_the_bucketed_allreduce_on_one_gpu(tmp_path, mode, wire):
     """backend='nccl' (= RCCL) with world_size 1: init_process_group, rank-0 broadcast, the bucketed all_reduce launched from
     the backward segment hooks on the side stream, finish() -- the same code path the 8-GPU run takes, on the box we have."""
     if not torch.cuda.is_available():
@@ -118,7 +122,7 @@ def test_rccl_executes_the_bucketed_allreduce_on_one_gpu(tmp_path, mode):
     script = tmp_path / 'nccl_worker.py'
     script.write_text(NCCL_WORKER)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29561', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0',
-               HSA_ENABLE_IPC_MODE_LEGACY='0', AVT_TEST_REDUCE_MODE=mode)
+               HSA_ENABLE_IPC_MODE_LEGACY='0', AVT_TEST_REDUCE_MODE=mode, AVT_TEST_WIRE=wire)
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and 'OK nccl' in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
 
@@ -146,3 +150,5 @@ def test_bench_two_ranks_end_to_end_over_gloo():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2' and len(d['per_rank_clips_per_s']) == 2
     assert d['value'] > 0 and 'cpu_baseline' not in d
+    assert len(d['comm']['per_rank']) == 2 and all(c['buckets_per_step'] >= 1 and 'comm_exposed_ms' in c for c in d['comm']['per_rank'])
+    assert d['host']['abi_calls_per_step'] > 100 and d['roofline']['executed_frac'] < d['roofline']['frac']

@@ -96,6 +96,23 @@ def test_g2b_full_head_T15(golden_dir):
     assert float(wpe[15:].abs().max()) == 0.0                      # only positions 0..14 are touched at T = 15
 
 
+@pytest.mark.parametrize('tag,H', [('h2', 2), ('h8', 8)])
+def test_g8b_real_width_heads(golden_dir, tag, H):
+    """SURVEY 8f-4 at real widths (inter_dim 2048, 8 layers, head_dim 1024 / 256): the oracle against the reference-generated golden."""
+    g = load_golden(os.path.join(golden_dir, f'g8b_head_2048x8_{tag}.npz'))
+    from oracle.make_golden import synth_batch
+    orc = build_oracle_model('feat', 768, 2048, 8, H, 3806)
+    O.closed_form_fill_(list(orc.named_parameters()))
+    video, target, sub = synth_batch(2, 10, 3806, (768, 1, 1, 1), seed=31)
+    out, losses, accs, tot = oracle_step(orc, video, target, sub)
+    assert rel(out['logits/action'], g['out/logits/action']) < 1e-4
+    assert rel(out['past'], g['out/past']) < 1e-4
+    assert abs(float(tot) - float(g['total_loss'])) / abs(float(g['total_loss'])) < 1e-5
+    for n, p in orc.named_parameters():
+        assert abs(float(p.grad.norm()) - float(g[f'gradnorm/{n}'])) / (float(g[f'gradnorm/{n}']) + 1e-12) < 1e-3, n
+    assert rel(orc.future_predictor.gpt_model.h[0].attn.c_attn.bias.grad, g['grad/future_predictor.gpt_model.h.0.attn.c_attn.bias']) < 1e-4
+
+
 def test_g6_eval_rollout_and_multicrop(golden_dir):
     """Eval path: multi-crop averaging + roll-out, oracle vs the reference's BaseModel / AVTh (HF KV cache)."""
     g = load_golden(os.path.join(golden_dir, 'g6a_rollout_multicrop_tiny.npz'))
