@@ -916,12 +916,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   if (AVT_DBG(p)) t_loop = __builtin_readcyclecounter();
 
   gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
-  if (AVT_DBG(p) && tid == 0) {
+#ifdef AVT_LAB
+  if (p.dbg && tid == 0) {
+    const long long t_math = __builtin_readcyclecounter();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    long long t_end = __builtin_readcyclecounter();
-    long long* d_ = AVT_DBG(p);
-    d_[bid * 4 + 0] = t_start; d_[bid * 4 + 1] = t_loop; d_[bid * 4 + 2] = t_end; d_[bid * 4 + 3] = nk;
+    const long long t_end = __builtin_readcyclecounter();
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    long long* d_ = p.dbg + (size_t)bid * 16;            // same record stride as the 8-phase kernel (two groups x 8)
+    d_[0] = t_start; d_[1] = t_loop; d_[2] = t_math; d_[3] = t_end; d_[4] = hw; d_[5] = xcc; d_[6] = nk; d_[7] = bid;
   }
+#endif
 }
 
 // Second pass of the deterministic split-K accumulate: one wave per 1-KB chunk (producing wave w, block (i, j), register
@@ -1406,6 +1412,10 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
   const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
   const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
   const int nk = kt_end - kt_begin;
+#ifdef AVT_LAB
+  long long t8_start = 0, t8_loop = 0;
+  if (p.dbg) t8_start = __builtin_readcyclecounter();
+#endif
 
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
@@ -1570,7 +1580,22 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
   P8_BARRIER();                                          // every LDS-DMA has landed and every fragment read retired: LDS is free
   int lane_e = lane, m0_e = tm0 + grp * WM, n0_e = tn0 + wn * WN;
   asm volatile("" : "+v"(lane_e), "+s"(m0_e), "+s"(n0_e));   // keep the epilogue's address arithmetic out of the K loop's register budget
+#ifdef AVT_LAB
+  if (p.dbg) t8_loop = __builtin_readcyclecounter();
+#endif
   gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane_e, m0_e, n0_e);
+#ifdef AVT_LAB
+  if (p.dbg && (tid == 0 || tid == 256)) {            // first wave of each group: start, end of K loop, arithmetic done, stores drained, placement
+    const long long t_math = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t_end = __builtin_readcyclecounter();
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    long long* d_ = p.dbg + ((size_t)bid * 2 + grp) * 8;
+    d_[0] = t8_start; d_[1] = t8_loop; d_[2] = t_math; d_[3] = t_end; d_[4] = hw; d_[5] = xcc; d_[6] = nk; d_[7] = bid;
+  }
+#endif
 #undef P8_PIN
 #undef P8_MFMA
 #undef P8_BARRIER
