@@ -39,6 +39,7 @@ struct GemmParams {
   int out_f32;
   int splitk;
   int tiles_m, tiles_n;
+  int strip_w;                   // 8-phase kernel, activation epilogue: walk the tiles in column strips of this many tiles (0 = row-major)
   size_t ws_bytes;
   float* ws;                     // EPI 2: split-K partial slabs, [splitk * tiles][BM * BN] fp32 in accumulator order
   uint32_t a_bytes, b_bytes;     // buffer-descriptor bounds
@@ -1406,8 +1407,20 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
   const int lb = xcd_remap(bid, ntile * p.splitk);          // an XCD owns a contiguous range of (split, tile): see xcd_remap
   const int split = lb / ntile;
   const int t_ = lb - split * ntile;
-  const int tm0 = (t_ / p.tiles_n) * BM;
-  const int tn0 = (t_ % p.tiles_n) * BN;
+  // tile order inside the XCD's contiguous range.  Row-major: the ~32 tiles an XCD has in flight cover all column tiles, so
+  // the whole B operand cycles through its 4-MB L2; when B is larger than that (N = 3072, K = 768: 4.7 MB) every tile re-fetches
+  // its B block from the Infinity Cache (measured 6.2 GB of fabric reads for 0.78 GB of operands, profiles/r03_strip_order.txt).
+  // Column strips: all row panels for strip_w column tiles, then the next strip -- the strip of B stays L2-resident and A is
+  // streamed once per strip.
+  int tm_i, tn_i;
+  if (p.strip_w > 0) {
+    const int per = p.tiles_m * p.strip_w;
+    const int strip = t_ / per, r_ = t_ - strip * per;
+    const int w_ = min(p.strip_w, p.tiles_n - strip * p.strip_w);
+    tm_i = r_ / w_; tn_i = strip * p.strip_w + (r_ - tm_i * w_);
+  } else { tm_i = t_ / p.tiles_n; tn_i = t_ - tm_i * p.tiles_n; }
+  const int tm0 = tm_i * BM;
+  const int tn0 = tn_i * BN;
   const int nk_total = (p.K + BK - 1) / BK;
   const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
   const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
@@ -1625,6 +1638,22 @@ int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
   }
   if (splitk > nk) splitk = nk;
   p.splitk = splitk;
+  p.strip_w = 0;
+  if (epi == 0 && p.tiles_m >= 64) {
+    // column strips when the B operand does not fit next to the A working set in an XCD's 4-MB L2: as many column tiles per
+    // strip as keep the strip of B under ~2.5 MB (the last strip takes the remainder: when the remainder is narrow -- a
+    // column strip narrower than 3 tiles re-reads A too often -- the strips are evened out)
+    const size_t b_bytes = (size_t)p.N * p.K * 2;
+    if (b_bytes > (size_t)4 << 20) {       // (3.5 MB -- the qkv weight -- still lives in L2: strips cost +3 % there)
+      int w = (int)(((size_t)5 << 19) / ((size_t)256 * p.K * 2)); if (w < 1) w = 1;
+      const int nstrip = (p.tiles_n + w - 1) / w;
+      w = (p.tiles_n + nstrip - 1) / nstrip;
+      if (w >= 3 && w < p.tiles_n) p.strip_w = w;
+    }
+  }
+#ifdef AVT_LAB
+  { static const char* e = getenv("AVT_GEMM_STRIP"); if (e) p.strip_w = (epi == 0 && atoi(e) < p.tiles_n) ? atoi(e) : 0; }
+#endif
   if (epi == 2) {
     if (a_kmajor || b_kmajor) { avt_set_error("avt_gemm_accum_bf16: operands must both be stored reduction-index-major"); return -1; }
     if ((size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4); return -2; }
@@ -1641,6 +1670,176 @@ int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
   if (a_kmajor && !b_kmajor) return launch_8p<true, false, 1>(p, s);
   if (!a_kmajor && !b_kmajor) return launch_8p<false, false, 1>(p, s);
   return launch_8p<false, true, 1>(p, s);
+}
+
+// ---- 4-wave kernel: 256x128x32 tile, TWO workgroups per CU, so that one's epilogue runs under the other's K loop ------------
+// Measured on gfx950 (tools/lab/coissue_lab.hip, coissue2_lab.hip, valu_rate_lab.hip; profiles/r03_issue_rules.txt):
+//   * a wave's vector-ALU instructions never overlap its OWN MFMAs (8 MFMA + k packed FMAs = 8 x 32 + 4.7 k cycles), but the
+//     vector ALU of ANOTHER wave on the same SIMD does run under them (the MFMA wave keeps 32.1 cycles per MFMA; the other
+//     wave's packed FMAs slow from one per 9.5 to one per 17.5 cycles);
+//   * a wave's own ds_read_b128 and LDS-DMA issue DO overlap its MFMAs (8 MFMA + 6 reads = 257 cycles, + 2 LDS-DMA = 281).
+// In the 8-phase kernel all eight waves of the CU reach the epilogue together: for a GELU (+ GELU') tile that is 22 k cycles of
+// vector-ALU work next to a 32 k-cycle K loop with the matrix pipe idle (tools/gemm_timeline.py).  Here a workgroup is four
+// waves (one per SIMD, wave tile 128x64 as in the 8-phase kernel, so the epilogue code is shared) on a 256x128 tile with a
+// 72-KB ring (3 stages of 32 k), and two workgroups share the CU: while one converts and stores its tile, the other owns the
+// matrix pipe.  The K loop therefore has to keep the pipe busy from ONE wave per SIMD: it contains no vector-ALU instruction at
+// all (per-lane offsets are computed once, the K advance goes through the scalar offset of the buffer instruction, stages past
+// the end read through a zero-length descriptor), fragments of the next k-step are requested before the MFMAs of the current
+// one, and the six LDS-DMA instructions of a stage are spread between the MFMAs.
+//   stage s (slot s % 3):  wait own DMA of stage s (vmcnt 6), lgkmcnt(0), s_barrier
+//                          read fragments (s, k-step 0) | 8 MFMA of (s-1, k-step 1) with 3 DMA of stage s+2 between them
+//                          read fragments (s, k-step 1) | 8 MFMA of (s,   k-step 0) with 3 DMA of stage s+2 between them
+// The barrier of stage s also tells that every wave has its (s-1, k-step 1) fragments in registers, so slot (s+2) % 3 = (s-1) % 3 is free.
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256, 2) void gemm_4w_kernel(GemmParams p) {
+  static_assert(A_KMAJOR && B_KMAJOR, "4-wave kernel: k-major operands only");
+  constexpr int BM = 256, BN = 128, BK = 32, WM = 128, WN = 64, TM = 4, TN = 2;
+  constexpr int A_ST = BM * BK * 2, STAGE = (BM + BN) * BK * 2;      // 16 KB + 8 KB
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int t_ = xcd_remap(blockIdx.x, ntile);
+  const int tm0 = (t_ / p.tiles_n) * BM;
+  const int tn0 = (t_ % p.tiles_n) * BN;
+  const int nk = p.K / BK;                                           // host-checked: K % 32 == 0
+#ifdef AVT_LAB
+  long long t4_start = 0, t4_loop = 0;
+  if (p.dbg) t4_start = __builtin_readcyclecounter();
+#endif
+
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t ra_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0, 0x00020000);
+
+  // LDS-DMA: one instruction = 16 rows x 64 B; wave w stages rows j*64 + w*16 .. +15 of A (j = 0..3) and of B (j = 0, 1).
+  // Rows past the matrix edge lie past the descriptor's range and arrive as zeros.
+  uint32_t voffA[4], voffB[2];
+  {
+    const int rl = wave * 16 + (lane >> 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = j * 64 + rl;
+      const int c = (lane & 3) ^ kmajor_swz<BK>(r);
+      voffA[j] = (uint32_t)(((size_t)(tm0 + r) * (size_t)p.lda + (size_t)c * 8) * 2);
+      if (j < 2) voffB[j] = (uint32_t)(((size_t)(tn0 + r) * (size_t)p.ldb + (size_t)c * 8) * 2);
+    }
+  }
+  char* const dst = lds + wave * 16 * (BK * 2);                       // wave-uniform part of the destination
+  auto dma = [&](int q, int st) __attribute__((always_inline)) {      // q = 0..3: A rows, 4..5: B rows; st = stage to fetch
+    const uint32_t kadv = (uint32_t)st * (BK * 2);                    // scalar: k advance in bytes
+    char* d = dst + (st % 3) * STAGE;
+    if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(st < nk ? ra : ra_null, AVT_LDS_PTR(d + q * 64 * (BK * 2)), 16, voffA[q], kadv, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(st < nk ? rb : rb_null, AVT_LDS_PTR(d + A_ST + (q - 4) * 64 * (BK * 2)), 16, voffB[q - 4], kadv, 0, 0);
+  };
+  // fragment addresses: lane (i = l & 31, h = l >> 5) reads row (block*32 + i), 16-B chunk (ks*2 + h) ^ ((i >> 2) & 3); the
+  // row-block, the k-step (chunk ^ 2) and the slot are immediates of the ds_read
+  const int ch0 = (lane >> 5) ^ (((lane & 31) >> 2) & 3);
+  const char* const fa0 = lds + (wm * 128 + (lane & 31)) * (BK * 2) + ch0 * 16;
+  const char* const fa1 = lds + (wm * 128 + (lane & 31)) * (BK * 2) + (ch0 ^ 2) * 16;
+  const char* const fb0 = lds + A_ST + (wn * 64 + (lane & 31)) * (BK * 2) + ch0 * 16;
+  const char* const fb1 = lds + A_ST + (wn * 64 + (lane & 31)) * (BK * 2) + (ch0 ^ 2) * 16;
+  bf16x8_t af[2][TM], bfr[2][TN];
+  auto rdf = [&](int ks, int slot) __attribute__((always_inline)) {
+    const char* a = (ks ? fa1 : fa0) + slot * STAGE;
+    const char* b = (ks ? fb1 : fb0) + slot * STAGE;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[ks][i] = *(const bf16x8_t*)(a + i * 32 * (BK * 2));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bfr[ks][j] = *(const bf16x8_t*)(b + j * 32 * (BK * 2));
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
+  // 8 MFMAs of k-step KS with the DMA instructions Q0 .. Q0+2 of stage ST after the 1st, 3rd and 5th of them
+#define W4_MFMA(KS, Q0, ST)                                                                              \
+  do {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                       \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
+        acc[i][j] = mma<0>(af[KS][i], bfr[KS][j], acc[i][j]);                                            \
+        if (j == 0 && i < 3) { W4_PIN(); dma((Q0) + i, (ST)); W4_PIN(); }                               \
+      }                                                                                                  \
+  } while (0)
+  // one stage: S = stage index (runtime), SLOT = S % 3 (compile time)
+#define W4_STAGE(S, SLOT, FIRST)                                                                         \
+  do {                                                                                                   \
+    wait_vmcnt<6>();                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+    W4_PIN(); asm volatile("s_barrier" ::: "memory"); W4_PIN();                                          \
+    rdf(0, SLOT); W4_PIN();                                                                              \
+    if (!(FIRST)) { W4_MFMA(1, 0, (S) + 2); } else { dma(0, (S) + 2); dma(1, (S) + 2); dma(2, (S) + 2); } \
+    W4_PIN(); rdf(1, SLOT); W4_PIN();                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");       /* the six k-step-0 fragments are older than the six just requested */ \
+    W4_PIN(); W4_MFMA(0, 3, (S) + 2); W4_PIN();                                                          \
+  } while (0)
+
+  // prologue: stages 0 and 1
+#pragma unroll
+  for (int q = 0; q < 6; ++q) dma(q, 0);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) dma(q, 1);
+  W4_STAGE(0, 0, true);
+  int s = 1;
+  for (; s + 2 < nk; s += 3) {            // slots 1, 2, 0
+    W4_STAGE(s, 1, false);
+    W4_STAGE(s + 1, 2, false);
+    W4_STAGE(s + 2, 0, false);
+  }
+  if (s < nk) { W4_STAGE(s, 1, false); ++s; }
+  if (s < nk) { W4_STAGE(s, 2, false); ++s; }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  W4_PIN();
+#pragma unroll
+  for (int i = 0; i < TM; ++i)            // k-step 1 of the last stage
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = mma<0>(af[1][i], bfr[1][j], acc[i][j]);
+  wait_vmcnt<0>();                        // the zero-length fetches past the end
+  W4_PIN(); asm volatile("s_barrier" ::: "memory"); W4_PIN();       // every wave is done with the ring: the epilogue reuses it
+#undef W4_STAGE
+#undef W4_MFMA
+#undef W4_PIN
+  int lane_e = lane, m0_e = tm0 + wm * WM, n0_e = tn0 + wn * WN;
+  asm volatile("" : "+v"(lane_e), "+s"(m0_e), "+s"(n0_e));
+#ifdef AVT_LAB
+  if (p.dbg) t4_loop = __builtin_readcyclecounter();
+#endif
+  gemm_epilogue<TM, TN, WM, WN, 0>(p, acc, lds, wave, lane_e, m0_e, n0_e);
+#ifdef AVT_LAB
+  if (p.dbg && tid == 0) {
+    const long long t_math = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t_end = __builtin_readcyclecounter();
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    long long* d_ = p.dbg + (size_t)blockIdx.x * 16;
+    d_[0] = t4_start; d_[1] = t4_loop; d_[2] = t_math; d_[3] = t_end; d_[4] = hw; d_[5] = xcc; d_[6] = nk; d_[7] = blockIdx.x;
+  }
+#endif
+}
+
+int dispatch_4w(GemmParams& p, int epi, int a_kmajor, int b_kmajor, hipStream_t s) {
+  if (epi != 0 || !a_kmajor || !b_kmajor || p.K % 32 != 0) { avt_set_error("avt_gemm_bf16: tile 2564 (4-wave, two workgroups per CU) needs the activation epilogue, k-major operands and K %% 32 == 0"); return -1; }
+  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 127) / 128; p.splitk = 1;
+  constexpr int ring = 3 * (256 + 128) * 32 * 2, patch = 4 * epi_wave_lds<64>();
+  constexpr int smem = ring > patch ? ring : patch;
+  static_assert(2 * smem <= 160 * 1024, "two workgroups must fit one CU's LDS");
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_4w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
+  hipLaunchKernelGGL((gemm_4w_kernel<true, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), smem, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
 }
 
 }  // namespace
@@ -1733,6 +1932,7 @@ static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kma
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_epi<256, 256, 2, 4, 64, 2, true, 0, 1, 4>(p, epi, a_kmajor, b_kmajor, splitk, s);
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 2568: return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);       // all 8 waves issue LDS-DMA
+    case 2564: return dispatch_4w(p, epi, a_kmajor, b_kmajor, s);                                  // 4 waves, 256x128x32, two workgroups per CU
     case 808:                                                                                     // 8-phase schedule (needs K % 64 == 0 for k-major operands)
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_8p(p, epi, a_kmajor, b_kmajor, splitk, s);
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);

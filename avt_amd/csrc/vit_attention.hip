@@ -22,8 +22,14 @@ __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// row-major [R][64] bf16 tile, 128-B rows, 16-B chunk c of row r stored at c ^ ((r>>1)&7)
-__device__ __forceinline__ int rm_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+// row-major [R][64] bf16 tile, 128-B rows, 16-B chunk c of row r stored at c ^ swz8(r).  Two access patterns read these tiles:
+//   * ds_read_b128 row fragments (16 rows x one chunk): conflict-free when the 8 row pairs of a 16-row group get 8 different
+//     chunk positions (even / odd rows already sit in different 128-B halves of the 256-B bank row): any bijection of (r >> 1) & 7;
+//   * ds_read_b64_tr_b16 transposing reads (8 rows x 32 B per half wave): the 4 row pairs of 8 consecutive rows must land on 4
+//     different 32-B slots.  With the plain c ^ ((r >> 1) & 7) they shared two (rows r and r + 2 on the same banks: 25 % of the
+//     backward's LDS cycles were bank-conflict cycles, profiles/r03a_pmc_sq.txt); p -> ((p & 3) << 1) | (p >> 2) satisfies both.
+__device__ __forceinline__ int swz8(int r) { const int p = (r >> 1) & 7; return ((p & 3) << 1) | (p >> 2); }
+__device__ __forceinline__ int rm_off(int r, int c) { return r * 128 + ((c ^ swz8(r)) << 4); }
 
 // Stage S rows x 64 columns (global row stride ld) into a swizzled row-major tile of RP rows (zero padded) and/or
 // a transposed tile [64][TS] (element (d, r) at d*TS + r), zero padded to TP rows.
@@ -53,7 +59,7 @@ __device__ __forceinline__ void stage_head_dma(const bf16_t* src, int ld, int S,
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 0x7FFFFFF0u, 0x00020000);
   for (int j = wave; j < RP / 8; j += nwaves) {
     const int r = j * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int c = (lane & 7) ^ swz8(r);
     uint32_t off = (uint32_t)(((size_t)r * (size_t)ld + (size_t)c * 8) * 2);
     if (r >= S) off = 0xFFFFFFF0u;
     char* dst = rm + __builtin_amdgcn_readfirstlane(j) * 1024;

@@ -37,7 +37,9 @@ def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile):
             bm = 808
         if bm == 64 and epi == 0 and a_kmajor and b_kmajor:
             bm = 643
-    shape = {64: '64,64,2,2,64,2,0', 128: '128,128,2,2,64,2,0', 256: '256,256,2,4,64,2,1', 512: 'pp', 258: 'deepa', 2568: '256,256,2,4,64,2,1,l8', 808: '8p', 643: '64,64,2,2,64,3,0'}[bm]
+    shape = {2564: '4w', 64: '64,64,2,2,64,2,0', 128: '128,128,2,2,64,2,0', 256: '256,256,2,4,64,2,1', 512: 'pp', 258: 'deepa', 2568: '256,256,2,4,64,2,1,l8', 808: '8p', 643: '64,64,2,2,64,3,0'}[bm]
+    if bm == 2564:
+        return f'gemm_4w_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))}>'
     if bm == 808:
         return f'gemm_8p_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
     if bm == 258:

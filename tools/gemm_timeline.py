@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 os.environ.setdefault('AVT_HIP_LIB', os.path.join(ROOT, 'avt_amd', 'libavt_hip_lab.so'))
-NB = 60000
+NB = 100000
 dbg = torch.zeros(16 * NB, device='cuda', dtype=torch.int64)
 os.environ['AVT_GEMM_DBG_PTR'] = hex(dbg.data_ptr())
 from avt_amd import ops
@@ -18,6 +18,8 @@ x, w1 = r(M, 768), r(3072, 768)
 b3 = torch.rand(3072, device='cuda')
 pre = torch.empty((M, 3072), device='cuda', dtype=torch.bfloat16); act = torch.empty_like(pre)
 cases = {'fc1 gelu+c2': dict(bias=b3, act=ops.ACT_GELU_ERF, c2=pre), 'fc1 plain': dict()}
+if os.environ.get('TL_CASES'):
+    cases = {k: v for k, v in cases.items() if k in os.environ['TL_CASES'].split(',')}
 for tile in [int(t) for t in sys.argv[1:]] or [808]:
     for name, kw in cases.items():
         for _ in range(2):

@@ -14,7 +14,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob('gpurun_out/pmc_$TAG/*/*counter_collection.csv'):
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name'][:60]
-        if 'gemm_kernel' not in k and 'gemm_8p' not in k: continue
+        if 'gemm' not in k: continue
         tot[k][row['Counter_Name']] += float(row['Counter_Value'])
         cnt[(k, row['Counter_Name'])] += 1
 for k, d in tot.items():
