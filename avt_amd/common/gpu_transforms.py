@@ -32,7 +32,7 @@ class GpuClipTransform:
         self.flip_p = flip_p if train else 0.0
         self.scale_pix_val, self.reverse_channels, self.train = scale_pix_val, reverse_channels, train
         if eval_num_crops not in (1, 3):
-            raise NotImplementedError('Not supported')               # common/transforms.py:271
+            raise NotImplementedError(f'eval_num_crops = {eval_num_crops}: MultiCropVideo defines 1 or 3 crops (common/transforms.py:254-296)')
         self.num_crops, self.flip_crops = (1, False) if train else (eval_num_crops, bool(eval_flip_crops))
         self.quantize_u8 = bool(train)              # ColorJitterVideo is in transform_train only (func/train.py:554-557)
 
@@ -87,7 +87,11 @@ class GpuClipTransform:
             else:
                 params = [tuple(self.draw(H, W)) + (b,) for b in range(B)]
         else:
-            params = [tuple(q) + ((b,) if len(q) == 5 else ()) for b, q in enumerate(params)]
+            params = [tuple(int(v) for v in q) + ((b,) if len(q) == 5 else ()) for b, q in enumerate(params)]
+        th, tw = self.crop
+        for new_h, new_w, flip, ci, cj, src in params:          # the kernel trusts these: an out-of-range row would read past a frame
+            if not (0 <= src < B and new_h > 0 and new_w > 0 and flip in (0, 1) and 0 <= ci and ci + th <= new_h and 0 <= cj and cj + tw <= new_w):
+                raise ValueError(f'bad preprocessing parameters {(new_h, new_w, flip, ci, cj, src)} for {B} clips and a {th}x{tw} crop')
         p = torch.tensor(params, dtype=torch.int32).to(clips_u8.device, non_blocking=True)
         out = ops.video_preproc(clips_u8.contiguous(), p, self.crop, self.scale_pix_val, self.mean, self.std, self.reverse_channels,
                                 quantize_u8=self.quantize_u8)

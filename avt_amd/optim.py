@@ -106,7 +106,7 @@ class FusedSGD:
         for g in self.param_groups:
             ids = []
             for p in g['params']:
-                if self.steps > 0:
+                if self.steps > 0 and g['momentum'] != 0:            # torch keeps no buffer for momentum-free groups
                     n = a.name_of[id(p)]
                     o = a.offsets[n]
                     state[idx] = {'momentum_buffer': self.momentum_buf[o:o + p.numel()].view(p.shape).clone()}
@@ -120,7 +120,7 @@ class FusedSGD:
             d.setdefault('fused', None)
             d['params'] = ids
             groups.append(d)
-        return {'state': state, 'param_groups': groups}
+        return {'state': state, 'param_groups': groups, 'avt_steps': self.steps}      # extra key: ignored by torch.optim.SGD.load_state_dict
 
     def load_state_dict(self, sd):
         a = self.arena
@@ -146,7 +146,8 @@ class FusedSGD:
                 o = a.offsets[n]
                 self.momentum_buf[o:o + p.numel()].copy_(st['momentum_buffer'].reshape(-1).to(self.momentum_buf.device, torch.float32))
                 loaded += 1
-        self.steps = 1 if loaded else 0          # torch initialises the buffer with the first gradient; after that it is live
+        # torch initialises the buffer with the first gradient and after that it is live; a torch-written file has no step count
+        self.steps = int(sd.get('avt_steps', 1 if loaded else 0))
         for g, sg in zip(self.param_groups, saved_groups):
             g.update({k: v for k, v in sg.items() if k != 'params'})
         self._ranges = None

@@ -103,7 +103,10 @@ def build(args, device, world):
 def cpu_baseline(args):
     """fp32 CPU oracle, fwd + bwd + SGD-nesterov, B = 1 clip (bounded sample of the same workload)."""
     from oracle import avt_oracle as O
-    cores = os.cpu_count() or 1                 # BASELINE.md section 3: every host core, count reported
+    # threads actually used (reported as `cores`).  Not every hardware thread: with all 256 of the GPU box's the fp32 oracle runs
+    # 70x SLOWER (0.0051 clips/s, 13 minutes for the four sample steps -- oversubscribed small ops) than with 64 (0.34-0.37 clips/s)
+    host_threads = os.cpu_count() or 1
+    cores = min(host_threads, 64)
     torch.set_num_threads(cores)
     D, L, H = VIT[args.model]
     orc = O.OracleBaseModel(O.OracleTIMMModel(vit=O.OracleViT(D, L, H)),
@@ -129,7 +132,7 @@ def cpu_baseline(args):
         times.append(time.time() - t0)
     timed = times[1:]
     t = sum(timed) / len(timed)
-    return {'value': round(B / t, 4), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+    return {'value': round(B / t, 4), 'unit': 'clips/s', 'cores': cores, 'host_threads': host_threads, 'kind': 'port',
             'min': round(B / max(timed), 4), 'max': round(B / min(timed), 4),
             'sample': f'B={B} clip x {args.frames} frames, 1 warm-up + {len(timed)} timed fwd+bwd+SGD steps of the fp32 oracle '
                       f'(mean {t:.2f} s/step, range {min(timed):.2f}-{max(timed):.2f} s, '

@@ -88,3 +88,43 @@ def cosine(a, b):
 def rel(a, b):
     a, b = a.detach().float().cpu(), b.detach().float().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+# ---- the product's dropout masks, restated on the host -----------------------------------------------------------------------
+def rng_keep_mask(seed, numel, p):
+    """keep[i] of the HIP kernels' counter-based dropout (avt_amd/csrc/common.hpp: rng_u32 / drop_keep): a splitmix64-style hash
+    of (seed, element index), kept when its bits 16..47 are >= p * 2^32.  uint64 arithmetic wraps, as on the device."""
+    with np.errstate(over='ignore'):
+        idx = np.arange(numel, dtype=np.uint64)
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+        u = (z >> np.uint64(16)) & np.uint64(0xFFFFFFFF)
+    thresh = min(max(int(float(np.float32(p)) * 4294967296.0), 0), 4294967295)
+    return torch.from_numpy((u >= np.uint64(thresh)).astype(np.float32))
+
+
+class FixedMaskDropout(torch.nn.Module):
+    """nn.Dropout with the mask a HIP kernel would draw for (seed, flat element index)."""
+    def __init__(self, p, seed):
+        super().__init__()
+        self.p, self.seed = p, seed
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        keep = rng_keep_mask(self.seed, x.numel(), self.p).view(x.shape)
+        return x * keep * float(np.float32(1.0) / (np.float32(1.0) - np.float32(self.p)))
+
+
+def give_oracle_the_hip_masks(orc, seed, p):
+    """Replace the oracle head's dropouts by the masks the HIP head draws from `seed` (avt_amd/models/future_prediction.py:
+    embedding dropout = seed; layer l: attention probabilities seed + 16 (l + 1) + 1, the two residual dropouts + 2 / + 3)."""
+    g = orc.future_predictor.gpt_model
+    g.drop = FixedMaskDropout(p, seed)
+    for li, blk in enumerate(g.h):
+        s0 = seed + 16 * (li + 1)
+        blk.attn.attn_dropout = FixedMaskDropout(p, s0 + 1)
+        blk.attn.resid_dropout = FixedMaskDropout(p, s0 + 2)
+        blk.mlp.dropout = FixedMaskDropout(p, s0 + 3)

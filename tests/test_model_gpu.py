@@ -376,6 +376,50 @@ def test_config5_vitl_full_depth_backward_vs_oracle():
     assert not bad, bad[:10]
 
 
+def test_dropout_on_training_step_matches_the_oracle_given_the_same_masks():
+    """The step the bench times has dropout ON (GPT-2 head: embedding, attention-probability and two residual dropouts per layer,
+    p = 0.1).  The HIP kernels draw their masks from a counter-based hash of (seed, element index); tests/helpers.py restates
+    that hash on the host and hands the SAME masks to the fp32 oracle, so the whole training step -- outputs, the three losses
+    and every parameter gradient -- can be compared end to end with dropout active.  (The classifier's nn.Dropout uses torch's
+    own generator and is switched off here; its mask statistics are covered by the per-op tests.)"""
+    import itertools
+    from helpers import give_oracle_the_hip_masks
+    from avt_amd.models.future_prediction import AVTh
+    IN, DH, L, H, C, B, T, P = 64, 128, 3, 4, 17, 3, 6, 0.1
+    torch.manual_seed(1234)
+    orc = build_oracle_model('feat', IN, DH, L, H, C)
+    with torch.no_grad():
+        for n, p in orc.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.15)
+    model = build_hip_model('feat', IN, DH, L, H, C, head_drop=P)
+    model.load_state_dict(orc.state_dict())
+    AVTh._seed_counter = itertools.count(7)                     # the next forward draws seed = 7 * 1000003 + torch.initial_seed()
+    seed = (7 * 1000003 + torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+    give_oracle_the_hip_masks(orc, seed, P)
+    orc.train()
+    g = torch.Generator().manual_seed(5)
+    video = torch.rand((B, T, IN, 1, 1, 1), generator=g) * 2 - 1
+    target = torch.randint(0, C, (B,), generator=g)
+    sub = torch.randint(-1, C, (B, T, 1), generator=g)
+    o_out, o_losses, _, o_tot = oracle_step(orc, video, target, sub)
+    out, losses, _, tot = hip_step(model, video.cuda(), target.cuda(), sub.cuda())
+    # the masks bite: the same oracle without them is far away
+    orc_nodrop = build_oracle_model('feat', IN, DH, L, H, C)
+    orc_nodrop.load_state_dict(orc.state_dict(), strict=False)
+    n_out, _, _, _ = oracle_step(orc_nodrop, video, target, sub)
+    assert rel(n_out['logits/action'], o_out['logits/action']) > 5e-2
+    assert rel(out['logits/action'], o_out['logits/action']) < TOL_OUT
+    assert rel(out['past_logits/action'], o_out['past_logits/action']) < TOL_OUT
+    for k in ['cls_action', 'past_cls_action', 'feat']:
+        assert rel(losses[k], o_losses[k]) < 3e-2, k
+    assert abs(float(tot) - float(o_tot)) / abs(float(o_tot)) < 3e-2
+    rows = _grad_report(model, orc)
+    assert len(rows) > 30
+    bad = [r for r in rows if r[1] > 4e-2 or r[2] > 3e-2 or r[3] < 0.999]
+    assert not bad, bad[:10]
+
+
 # ---- round 2: eval path (SURVEY 8f-1) ----------------------------------------------------------------------------------------
 def test_g6a_multicrop_rollout_tiny_vit_vs_reference_golden(golden_dir):
     """7-D multi-crop video (3 crops averaged, models/base_model.py:251-273) + KV-cache roll-out (output_len_eval = 3,
@@ -448,6 +492,39 @@ def test_cls_only_last_block_equals_all_token_path():
             assert float(a.abs().max()) < 1e-3, n
             continue
         assert rel(a, b) < 2.5e-2, (n, rel(a, b))
+
+
+def test_torch_optimizer_over_a_middle_slice_of_the_arena_still_gets_its_gradients():
+    """A torch optimizer that owns only the future predictor (a MIDDLE slice of the flat arena: backbone before it, classifier after
+    it) drops only its own .grad views in zero_grad(set_to_none=True); the first and last parameters of the arena keep theirs.
+    The fused backward must notice and re-attach them, otherwise optimizer.step() silently updates nothing (round-2 advisor finding)."""
+    from avt_amd.config import Cfg
+    from avt_amd.func.train import Trainer
+    from avt_amd.func.train_eval_ops import Basic
+    g = torch.Generator().manual_seed(9)
+    data = {'video': (torch.rand((2, 4, 3, 1, 32, 32), generator=g) * 2 - 1).cuda(), 'target': {'action': torch.randint(0, 17, (2,), generator=g).cuda()},
+            'target_subclips': {'action': torch.randint(-1, 17, (2, 4, 1), generator=g).cuda()}}
+    torch.manual_seed(0)
+    model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.1)
+    for mod in (model.backbone, model.classifiers):
+        for p in mod.parameters():
+            p.requires_grad = False
+    head = list(model.future_predictor.parameters())
+    opt = torch.optim.AdamW(head, lr=1e-2)
+    before = [p.detach().clone() for p in head]
+    tr = Trainer(model, Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy')), opt, None, LOSS_WTS)
+    for _ in range(2):
+        tr.step(data)
+        assert all(p.grad is not None for p in head)
+        a = model.arena
+        assert all(p.grad.data_ptr() == a.grad.data_ptr() + 4 * a.offsets[a.name_of[id(p)]] for p in head)
+    torch.cuda.synchronize()
+    moved = sum(not torch.equal(b, p.detach()) for b, p in zip(before, head))
+    assert moved > 0.9 * len(head), (moved, len(head))
 
 
 def test_reference_loop_order_with_a_torch_optimizer_trains():
