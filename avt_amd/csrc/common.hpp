@@ -123,6 +123,19 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// ---- transposing LDS read issued through inline assembly -------------------------------------------------------------------
+// hipcc cannot tell that __builtin_amdgcn_ds_read_tr16_b64 does not alias LDS-DMA (buffer_load ... lds) transfers still in flight
+// and puts s_waitcnt vmcnt(0) in front of it; kernels that prefetch by LDS-DMA and place their own waits use this form instead.
+// `addr` = the lane's LDS byte address, OFF = compile-time offset.  The result may only be used after an explicit s_waitcnt lgkmcnt.
+template <int OFF>
+__device__ __forceinline__ s16x4_t ds_read_tr_na(uint32_t addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read immediate offset");
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ uint32_t lds_addr32(const char* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+
 // ---- host-side error channel -------------------------------------------------------------------------
 void avt_set_error(const char* fmt, ...);
 #define AVT_CHECK(cond, ...) do { if (!(cond)) { avt_set_error(__VA_ARGS__); return -1; } } while (0)

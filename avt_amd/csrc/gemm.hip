@@ -180,6 +180,51 @@ __device__ __forceinline__ bf16x8_t frag_kstrided(const char* lds_tile, int tile
   return u.v;
 }
 
+// frag_kstrided through inline assembly (see ds_read_tr_na in common.hpp): no compiler-placed s_waitcnt vmcnt(0); the caller
+// waits (frag_wait) before the first MFMA that consumes the fragment.  Rows r and r + 4 share the swizzle: one address, two immediates.
+template <int BR>
+__device__ __forceinline__ bf16x8_t frag_kstrided_na(const char* lds_tile, int tile, int ks, int lane) {
+  const int g = lane >> 4, i16 = lane & 15;
+  const int col = tile * 32 + (g & 1) * 16 + (i16 & 3) * 4;
+  const int r = ks * 16 + (g >> 1) * 8 + (i16 >> 2);
+  const int c = (col >> 3) ^ kstrided_swz<BR>(r);
+  const uint32_t a = lds_addr32(lds_tile + r * (BR * 2) + c * 16 + (col & 7) * 2);
+  union { bf16x8_t v; s16x4_t h[2]; } u;
+  u.h[0] = ds_read_tr_na<0>(a);
+  u.h[1] = ds_read_tr_na<4 * BR * 2>(a);
+  return u.v;
+}
+// wait until at most N of this wave's LDS operations are outstanding, then pass the fragments through an empty statement so
+// that no MFMA reading them can be scheduled above the wait
+template <int N, int TM, int TN>
+__device__ __forceinline__ void frag_wait(bf16x8_t (&a)[TM], bf16x8_t (&b)[TN]) {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+#pragma unroll
+  for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(a[i]));
+#pragma unroll
+  for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(b[j]));
+}
+// The same transposing read issued through inline assembly, for kernels that place their own s_waitcnt.  hipcc cannot tell that
+// a __builtin_amdgcn_ds_read_tr16_b64 does not alias the LDS-DMA (buffer_load ... lds) transfers still in flight and puts an
+// s_waitcnt vmcnt(0) in front of every group of them: the whole ring drains before each fragment read and the 1.5-K-tile
+// prefetch of the 8-phase kernel degenerates to none (found in round 3: every k-strided operand -- all weight gradients, the
+// proj data gradient -- had been running like that; plain ds_read_b128 loads are not affected).  `addr` = the lane's LDS byte
+// address, OFF = compile-time offset (slot, k-step, half).  The result may only be used after an explicit s_waitcnt lgkmcnt.
+// the four k-steps of one 32-column block of a [64][128] k-strided half-tile (256-B rows): f[ks] = rows ks*16 .. +15
+template <int OFF>
+__device__ __forceinline__ void frag4_tr_na(bf16x8_t (&f)[4], uint32_t addr) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    union { bf16x8_t v; s16x4_t h[2]; } u;
+    switch (ks) {             // compile-time immediates
+      case 0: u.h[0] = ds_read_tr_na<OFF>(addr); u.h[1] = ds_read_tr_na<OFF + 4 * 256>(addr); break;
+      case 1: u.h[0] = ds_read_tr_na<OFF + 16 * 256>(addr); u.h[1] = ds_read_tr_na<OFF + 20 * 256>(addr); break;
+      case 2: u.h[0] = ds_read_tr_na<OFF + 32 * 256>(addr); u.h[1] = ds_read_tr_na<OFF + 36 * 256>(addr); break;
+      default: u.h[0] = ds_read_tr_na<OFF + 48 * 256>(addr); u.h[1] = ds_read_tr_na<OFF + 52 * 256>(addr); break;
+    }
+    f[ks] = u.v;
+  }
+}
 // De-synchronise the chip: all CUs start together and would otherwise hit their output-store tails together (a burst at
 // the HBM write rate while the MFMA pipes idle).  The workgroups of the FIRST dispatch wave start spread over
 // `cycles`; every CU keeps its offset afterwards because it picks up its next tile when it finishes the previous one.
@@ -834,10 +879,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
         bf16x8_t af[TM], bfr[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          af[i] = A_KMAJOR ? frag_kmajor<BK>(la, wm * TM + i, ks, lane) : frag_kstrided<BM>(la, wm * TM + i, ks, lane);
+          af[i] = A_KMAJOR ? frag_kmajor<BK>(la, wm * TM + i, ks, lane) : frag_kstrided_na<BM>(la, wm * TM + i, ks, lane);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          bfr[j] = B_KMAJOR ? frag_kmajor<BK>(lb, wn * TN + j, ks, lane) : frag_kstrided<BN>(lb, wn * TN + j, ks, lane);
+          bfr[j] = B_KMAJOR ? frag_kmajor<BK>(lb, wn * TN + j, ks, lane) : frag_kstrided_na<BN>(lb, wn * TN + j, ks, lane);
+        if (!A_KMAJOR || !B_KMAJOR) frag_wait<0>(af, bfr);          // inline-assembly reads: the compiler does not wait for them
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -874,17 +920,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
       auto ldf = [&](int ks, int b) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          af[b][i] = A_KMAJOR ? frag_kmajor<BK>(la, wm * TM + i, ks, lane) : frag_kstrided<BM>(la, wm * TM + i, ks, lane);
+          af[b][i] = A_KMAJOR ? frag_kmajor<BK>(la, wm * TM + i, ks, lane) : frag_kstrided_na<BM>(la, wm * TM + i, ks, lane);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          bfr[b][j] = B_KMAJOR ? frag_kmajor<BK>(lb, wn * TN + j, ks, lane) : frag_kstrided<BN>(lb, wn * TN + j, ks, lane);
+          bfr[b][j] = B_KMAJOR ? frag_kmajor<BK>(lb, wn * TN + j, ks, lane) : frag_kstrided_na<BN>(lb, wn * TN + j, ks, lane);
       };
       constexpr int NPART = RA + RB;
       constexpr int PER = (NPART + KS - 2) / (KS - 1);        // parts per k-step over the first KS-1 steps
+      constexpr int NRD = (A_KMAJOR ? TM : 2 * TM) + (B_KMAJOR ? TN : 2 * TN);     // LDS reads of one k-step's fragments
+      static_assert(NRD <= 15, "lgkmcnt is a 4-bit counter");
       ldf(0, 0);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (ks + 1 < KS) ldf(ks + 1, (ks + 1) & 1);
+        if (!A_KMAJOR || !B_KMAJOR) {                          // fragments of step ks: older than the NRD reads just requested
+          if (ks + 1 < KS) frag_wait<NRD>(af[ks & 1], bfr[ks & 1]); else frag_wait<0>(af[ks & 1], bfr[ks & 1]);
+        }
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
           const int part = ks * PER + q;
@@ -1496,19 +1547,55 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
   };
 
   bf16x8_t fa[2][4], fb0[4], fb1[4];
+  // k-strided operands: per-lane LDS addresses of the lane's element in k row (g>>1)*8 + (i>>2) of the 32-column blocks it reads
+  // (see frag_kstrided: chunk = ((block ^ (i>>2)) << 2) | (g&1)*2 | ((i&3)>>1)); the slot, the k-step and the half are
+  // immediates of the (inline-assembly) reads; slots 4-7 go through a second base 64 KB further
+  uint32_t trA[2][2] = {{0u, 0u}, {0u, 0u}}, trB[2] = {0u, 0u};
+  {
+    const int g = lane >> 4, i16 = lane & 15;
+    const int lane_off = ((g >> 1) * 8 + (i16 >> 2)) * 256 + (i16 & 1) * 8;
+    const int x = (g & 1) * 2 + ((i16 & 3) >> 1);
+    if (!A_KMAJOR) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        trA[0][i] = lds_addr32(lds) + (uint32_t)(lane_off + (((((grp * 2 + i) ^ (i16 >> 2)) & 3) << 2) | x) * 16);
+        trA[1][i] = trA[0][i] + 65536u;
+      }
+    }
+    if (!B_KMAJOR) {
+      trB[0] = lds_addr32(lds) + (uint32_t)(lane_off + ((((wn ^ (i16 >> 2)) & 3) << 2) | x) * 16);
+      trB[1] = trB[0] + 65536u;
+    }
+  }
   auto read_a = [&](bf16x8_t (&f)[2][4], int h, int par) __attribute__((always_inline)) {
-    const char* slot = lds + ((h ? 3 : 0) * 2 + par) * HALF;
+    if (A_KMAJOR) {
+      const char* slot = lds + ((h ? 3 : 0) * 2 + par) * HALF;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        f[i][ks] = A_KMAJOR ? frag_kmajor<BK>(slot + grp * 64 * (BK * 2), i, ks, lane) : frag_kstrided<128>(slot, grp * 2 + i, ks, lane);
+        for (int ks = 0; ks < 4; ++ks) f[i][ks] = frag_kmajor<BK>(slot + grp * 64 * (BK * 2), i, ks, lane);
+    } else {
+      switch ((h ? 3 : 0) * 2 + par) {          // slots 0, 1, 6, 7 (h and par are literals at every call site)
+        case 0: frag4_tr_na<0>(f[0], trA[0][0]); frag4_tr_na<0>(f[1], trA[0][1]); break;
+        case 1: frag4_tr_na<HALF>(f[0], trA[0][0]); frag4_tr_na<HALF>(f[1], trA[0][1]); break;
+        case 6: frag4_tr_na<6 * HALF - 65536>(f[0], trA[1][0]); frag4_tr_na<6 * HALF - 65536>(f[1], trA[1][1]); break;
+        default: frag4_tr_na<7 * HALF - 65536>(f[0], trA[1][0]); frag4_tr_na<7 * HALF - 65536>(f[1], trA[1][1]); break;
+      }
+    }
   };
   auto read_b = [&](bf16x8_t (&f)[4], int h, int par) __attribute__((always_inline)) {
-    const char* slot = lds + ((h ? 2 : 1) * 2 + par) * HALF;
+    if (B_KMAJOR) {
+      const char* slot = lds + ((h ? 2 : 1) * 2 + par) * HALF;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      f[ks] = B_KMAJOR ? frag_kmajor<BK>(slot + wn * 32 * (BK * 2), 0, ks, lane) : frag_kstrided<128>(slot, wn, ks, lane);
+      for (int ks = 0; ks < 4; ++ks) f[ks] = frag_kmajor<BK>(slot + wn * 32 * (BK * 2), 0, ks, lane);
+    } else {
+      switch ((h ? 2 : 1) * 2 + par) {          // slots 2, 3, 4, 5
+        case 2: frag4_tr_na<2 * HALF>(f, trB[0]); break;
+        case 3: frag4_tr_na<3 * HALF>(f, trB[0]); break;
+        case 4: frag4_tr_na<4 * HALF - 65536>(f, trB[1]); break;
+        default: frag4_tr_na<5 * HALF - 65536>(f, trB[1]); break;
+      }
+    }
   };
 
   f32x16_t acc[TM][TN];
@@ -1828,6 +1915,209 @@ __global__ __launch_bounds__(256, 2) void gemm_4w_kernel(GemmParams p) {
 #endif
 }
 
+// ---- 4-wave weight-gradient kernel: 256x256x32 tile, wave tile 128x128, accumulators in the AGPR half of the file ----------
+// C[m, n] += sum_k A[k, m] B[k, n], both operands stored reduction-index-major (dy^T x), split-K slabs (EPI 2).
+// The 8-phase kernel spends 24 KB of transposing LDS reads per wave and K tile (wave tile 128x64: 4 + 2 fragments per 8 MFMAs)
+// and its matrix pipe is busy 0.48-0.51 of the time on these launches (profiles/r03a_pmc_sq.txt) although neither LDS nor HBM
+// is near a limit: the L phases (twice the LDS instructions of a k-major operand) are longer than the partner's M phases.
+// With one wave per SIMD (4 waves, 512 registers each: 256 accumulators as AGPRs) the wave tile is 128x128 -- 4 + 4 fragments per
+// 16 MFMAs, a third fewer LDS bytes per flop -- and, since a wave's own LDS reads and LDS-DMA issue overlap its MFMAs
+// (profiles/r03_issue_rules.txt), no second wave is needed to keep the pipe fed as long as the K loop holds no vector-ALU work:
+// fragment addresses and DMA offsets are per-lane constants, the K advance lives in the scalar buffer descriptor.
+// Ring: 5 stages of [32 k][256 + 256] bf16 = 160 KB (the whole LDS; this epilogue needs none), 4 stages in flight.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
+  static_assert(EPI == 2, "4-wave weight-gradient kernel: split-K slab epilogue only");
+  constexpr int BM = 256, BN = 256, BK = 32, NST = 5, WM = 128, WN = 128, TM = 4, TN = 4;
+  constexpr int ROWB = 512;                                  // bytes of one k row of a [32][256] operand tile
+  constexpr int OP_T = BK * ROWB, STAGE = 2 * OP_T;          // 16 KB + 16 KB
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int lb = xcd_remap(blockIdx.x, ntile * p.splitk);
+  const int split = lb / ntile;
+  const int t_ = lb - split * ntile;
+  const int tm0 = (t_ / p.tiles_n) * BM;
+  const int tn0 = (t_ % p.tiles_n) * BN;
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
+  const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
+  const int nk = kt_end - kt_begin;
+
+  // LDS-DMA: one instruction = 2 k rows x 512 B; wave w stages rows q*8 + w*2 .. +1 (q = 0..3) of A and of B.  A column
+  // chunk that lies entirely past the matrix edge is clamped to the last chunk holding a valid column (never stored).
+  uint32_t voffA[4], voffB[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = q * 8 + wave * 2 + (lane >> 5);
+    const int c = (lane & 31) ^ kstrided_swz<256>(r);
+    int ca = tm0 + c * 8, cb = tn0 + c * 8;
+    if (ca >= p.M) ca = (p.M - 1) & ~7;
+    if (cb >= p.N) cb = (p.N - 1) & ~7;
+    voffA[q] = (uint32_t)(((size_t)r * (size_t)p.lda + (size_t)ca) * 2);
+    voffB[q] = (uint32_t)(((size_t)r * (size_t)p.ldb + (size_t)cb) * 2);
+  }
+  char* const dst = lds + wave * 2 * ROWB;
+  // K advance through the descriptor (scalar arithmetic only): a running base pointer and a running byte bound per operand, moved
+  // one stage forward after each stage's eight DMA instructions; rows past the end of the reduction -- and whole stages past
+  // this split's range -- read as zeros (bound 0)
+  // (everything here is wave-uniform; readfirstlane makes that provable, otherwise the descriptors end up in vector registers
+  // and every LDS-DMA instruction turns into a waterfall loop)
+  auto sgpr = [](uint32_t v) __attribute__((always_inline)) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+  const uint32_t stepA = sgpr((uint32_t)BK * (uint32_t)p.lda * 2u), stepB = sgpr((uint32_t)BK * (uint32_t)p.ldb * 2u);
+  const uint64_t pa0 = (uint64_t)(uintptr_t)p.A + (uint64_t)kt_begin * stepA, pb0 = (uint64_t)(uintptr_t)p.B + (uint64_t)kt_begin * stepB;
+  uint32_t pa_lo = sgpr((uint32_t)pa0), pa_hi = sgpr((uint32_t)(pa0 >> 32)), pb_lo = sgpr((uint32_t)pb0), pb_hi = sgpr((uint32_t)(pb0 >> 32));
+  uint32_t remA = sgpr((uint64_t)kt_begin * stepA < p.a_bytes ? (uint32_t)(p.a_bytes - (uint64_t)kt_begin * stepA) : 0u);
+  uint32_t remB = sgpr((uint64_t)kt_begin * stepB < p.b_bytes ? (uint32_t)(p.b_bytes - (uint64_t)kt_begin * stepB) : 0u);
+  int left = __builtin_amdgcn_readfirstlane(nk);                      // stages of this split not yet handed to the DMA
+  __amdgpu_buffer_rsrc_t ra_t, rb_t;
+  auto next_stage = [&]() __attribute__((always_inline)) {            // descriptors of the next stage to fetch, then advance
+    const bool live = left > 0;                                       // a live stage starts inside the operand: no underflow below
+    ra_t = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)sgpr(pa_hi) << 32) | sgpr(pa_lo)), 0, sgpr(live ? remA : 0u), 0x00020000);
+    rb_t = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)sgpr(pb_hi) << 32) | sgpr(pb_lo)), 0, sgpr(live ? remB : 0u), 0x00020000);
+    const uint32_t na = pa_lo + stepA, nb = pb_lo + stepB;
+    pa_hi += (na < pa_lo) ? 1u : 0u; pb_hi += (nb < pb_lo) ? 1u : 0u; pa_lo = na; pb_lo = nb;
+    remA -= stepA; remB -= stepB;
+    --left;
+  };
+  auto dma = [&](int q, int slot) __attribute__((always_inline)) {    // q = 0..3: A, 4..7: B, of the stage next_stage() prepared
+    char* d = dst + slot * STAGE;
+    if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_t, AVT_LDS_PTR(d + q * 8 * ROWB), 16, voffA[q], 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_t, AVT_LDS_PTR(d + OP_T + (q - 4) * 8 * ROWB), 16, voffB[q - 4], 0, 0, 0);
+  };
+  // transposing fragment reads (frag_kstrided<256>): lane (g = l >> 4, i = l & 15) reads k rows ks*16 + (g>>1)*8 + (i>>2) + 4h
+  // (h = 0, 1), columns tile*32 + (g&1)*16 + (i&3)*4 .. +3; the 16-B chunk index is swizzled with (row & 3) << 2 = (i>>2) << 2,
+  // i.e. chunk = ((tile ^ (i>>2)) << 2) | (g&1)*2 | ((i&3)>>1): one per-lane address per 32-column block, rows as immediates.
+  // Slots 0-1, 2-3 and 4 get their own base registers (the ds_read immediate reaches 64 KB).  The addresses are made opaque
+  // so that they stay in registers instead of being re-added inside the loop (a vector-ALU instruction there costs MFMA time).
+  uint32_t adA[3][TM], adB[3][TN];
+  {
+    const int g = lane >> 4, i16 = lane & 15;
+    const int rsub = (g >> 1) * 8 + (i16 >> 2);
+    const int x = (g & 1) * 2 + ((i16 & 3) >> 1);
+    const int lane_off = rsub * ROWB + (i16 & 1) * 8;
+    const uint32_t base = lds_addr32(lds);
+#pragma unroll
+    for (int b_ = 0; b_ < 3; ++b_)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ta = wm * 4 + t, tb = wn * 4 + t;
+        uint32_t oa = base + (uint32_t)(b_ * 2 * STAGE + lane_off + (((ta ^ (i16 >> 2)) << 2) | x) * 16);
+        uint32_t ob = base + (uint32_t)(b_ * 2 * STAGE + OP_T + lane_off + (((tb ^ (i16 >> 2)) << 2) | x) * 16);
+        asm volatile("" : "+v"(oa), "+v"(ob));
+        adA[b_][t] = oa; adB[b_][t] = ob;
+      }
+  }
+  bf16x8_t af[2][TM], bfr[2][TN];
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
+  // fragment f of the next k-step: f = 0: A0, 1..4: B0..B3, 5..7: A1..A3 (the order the MFMAs need them)
+#define W4_RDF(NB, SLOT, KS, F)                                                                                       \
+  do {                                                                                                                \
+    constexpr int imm_ = ((SLOT) & 1) * STAGE + (KS) * 16 * ROWB;                                                     \
+    union { bf16x8_t v; s16x4_t h[2]; } u_;                                                                           \
+    const uint32_t a_ = ((F) == 0) ? adA[(SLOT) >> 1][0] : ((F) <= 4 ? adB[(SLOT) >> 1][(F) - 1] : adA[(SLOT) >> 1][(F) - 4]);  \
+    u_.h[0] = ds_read_tr_na<imm_>(a_); u_.h[1] = ds_read_tr_na<imm_ + 4 * ROWB>(a_);     /* inline asm: no compiler-placed vmcnt(0) */ \
+    if ((F) == 0) af[NB][0] = u_.v; else if ((F) <= 4) bfr[NB][(F) - 1] = u_.v; else af[NB][(F) - 4] = u_.v;          \
+  } while (0)
+  // 16 MFMAs of buffer CB; between them the 8 fragments of (SLOT, KS) into buffer NB and the DMA instructions Q0..Q0+3 of stage ST
+#define W4_STEP(CB, NB, SLOT, KS, Q0, ST, READ)                                                                       \
+  do {                                                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      /* buffer CB's fragments (inline-assembly reads) have landed */ \
+    W4_PIN();                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                    \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                                \
+        acc[i][j] = mma<EPI>(af[CB][i], bfr[CB][j], acc[i][j]);                                                       \
+        W4_PIN();                                                                                                     \
+        if (READ) {                                                                                                   \
+          if (i * 4 + j == 0) W4_RDF(NB, SLOT, KS, 0);  if (i * 4 + j == 1) W4_RDF(NB, SLOT, KS, 1);                  \
+          if (i * 4 + j == 2) W4_RDF(NB, SLOT, KS, 2);  if (i * 4 + j == 3) W4_RDF(NB, SLOT, KS, 3);                  \
+          if (i * 4 + j == 4) W4_RDF(NB, SLOT, KS, 4);  if (i * 4 + j == 6) W4_RDF(NB, SLOT, KS, 5);                  \
+          if (i * 4 + j == 8) W4_RDF(NB, SLOT, KS, 6);  if (i * 4 + j == 10) W4_RDF(NB, SLOT, KS, 7);                 \
+        }                                                                                                             \
+        if ((i * 4 + j) % 4 == 1 && (Q0) >= 0) dma((Q0) + (i * 4 + j) / 4, (ST));            /* ST = destination slot */   \
+        W4_PIN();                                                                                                     \
+      }                                                                                                               \
+  } while (0)
+  // stage S in slot SLOT: wait for its DMA (3 younger stages = 24 instructions stay in flight), barrier, then
+  //   fragments (S, k-step 0) under the MFMAs of (S-1, k-step 1), fragments (S, k-step 1) under the MFMAs of (S, k-step 0);
+  //   the 8 DMA instructions of stage S+4 (slot of stage S-1, free since the barrier) are spread over both halves
+#define W4_STAGE(S, SLOT)                                                                                             \
+  do {                                                                                                                \
+    wait_vmcnt<24>();                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                \
+    W4_PIN(); asm volatile("s_barrier" ::: "memory"); W4_PIN();                                                       \
+    next_stage();                                                                                                     \
+    W4_STEP(1, 0, SLOT, 0, 0, ((SLOT) + 4) % NST, true);                                                              \
+    W4_STEP(0, 1, SLOT, 1, 4, ((SLOT) + 4) % NST, true);                                                              \
+  } while (0)
+
+  // prologue: stages 0..3 in flight; the first stage has no previous k-step to multiply: its k-step 0 fragments are read plainly
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    next_stage();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dma(q, st);
+  }
+  wait_vmcnt<24>();
+  W4_PIN(); asm volatile("s_barrier" ::: "memory"); W4_PIN();
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    if (f == 0) W4_RDF(0, 0, 0, 0); if (f == 1) W4_RDF(0, 0, 0, 1); if (f == 2) W4_RDF(0, 0, 0, 2); if (f == 3) W4_RDF(0, 0, 0, 3);
+    if (f == 4) W4_RDF(0, 0, 0, 4); if (f == 5) W4_RDF(0, 0, 0, 5); if (f == 6) W4_RDF(0, 0, 0, 6); if (f == 7) W4_RDF(0, 0, 0, 7);
+  }
+  next_stage();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma(q, 4);
+  W4_PIN();
+  W4_STEP(0, 1, 0, 1, 4, 4, true);                        // MFMAs of (0, k-step 0), fragments of (0, k-step 1), second half of stage 4's DMA
+  int s = 1;
+  for (; s + 4 < nk; s += 5) {                            // slots 1, 2, 3, 4, 0
+    W4_STAGE(s, 1); W4_STAGE(s + 1, 2); W4_STAGE(s + 2, 3); W4_STAGE(s + 3, 4); W4_STAGE(s + 4, 0);
+  }
+  if (s < nk) { W4_STAGE(s, 1); ++s; }
+  if (s < nk) { W4_STAGE(s, 2); ++s; }
+  if (s < nk) { W4_STAGE(s, 3); ++s; }
+  if (s < nk) { W4_STAGE(s, 4); ++s; }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  W4_PIN();
+  W4_STEP(1, 0, 0, 0, -1, 0, false);                      // k-step 1 of the last stage
+  wait_vmcnt<0>();
+#undef W4_STAGE
+#undef W4_STEP
+#undef W4_RDF
+#undef W4_PIN
+  gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
+}
+
+int dispatch_w4(GemmParams& p, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
+  if (a_kmajor || b_kmajor) { avt_set_error("avt_gemm_accum_bf16: operands must both be stored reduction-index-major"); return -1; }
+  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
+  const int nk64 = (p.K + 63) / 64;
+  if (splitk <= 0) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk64, 1, 8);      // same choice as the 8-phase kernel: the workspace query mirrors it
+  if (splitk > nk64) splitk = nk64;
+  p.splitk = splitk;
+  if ((size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4); return -2; }
+  constexpr int smem = 5 * 2 * 32 * 512;               // 160 KB
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
+  hipLaunchKernelGGL((gemm_w4_kernel<2>), dim3(p.tiles_m * p.tiles_n * splitk), dim3(256), smem, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return launch_reduce<4, 4, 2, 2>(p, s);
+}
+
 int dispatch_4w(GemmParams& p, int epi, int a_kmajor, int b_kmajor, hipStream_t s) {
   if (epi != 0 || !a_kmajor || !b_kmajor || p.K % 32 != 0) { avt_set_error("avt_gemm_bf16: tile 2564 (4-wave, two workgroups per CU) needs the activation epilogue, k-major operands and K %% 32 == 0"); return -1; }
   p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 127) / 128; p.splitk = 1;
@@ -1899,6 +2189,7 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
     }
   }
   if (tile == 0 && bm == 256 && (K % 64 == 0 || (!a_kmajor && !b_kmajor))) bm = 808;       // default big-tile kernel: the 8-phase schedule
+  if (tile == 0 && bm == 808 && epi == 2) bm = 2565;                                          // weight gradients: 4 waves of 128x128 (+2-3 % over the 8-phase kernel)
   if (tile == 0 && bm == 64 && epi == 0 && a_kmajor && b_kmajor) bm = 643;                   // all-k-major small outputs: 3-deep ring (+15-25 % on the head's data gradients)
   int nslots = 0;
   if (colsum && part) {
@@ -1932,7 +2223,10 @@ static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kma
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_epi<256, 256, 2, 4, 64, 2, true, 0, 1, 4>(p, epi, a_kmajor, b_kmajor, splitk, s);
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 2568: return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);       // all 8 waves issue LDS-DMA
-    case 2564: return dispatch_4w(p, epi, a_kmajor, b_kmajor, s);                                  // 4 waves, 256x128x32, two workgroups per CU
+    case 2564: return dispatch_4w(p, epi, a_kmajor, b_kmajor, s);
+    case 2565:                                                                                    // 4-wave weight-gradient kernel (128x128 wave tiles, AGPR accumulators)
+      if (epi != 2) { avt_set_error("avt_gemm: tile 2565 is the deterministic weight-gradient kernel (avt_gemm_accum_bf16 only)"); return -1; }
+      return dispatch_w4(p, a_kmajor, b_kmajor, splitk, s);                                  // 4 waves, 256x128x32, two workgroups per CU
     case 808:                                                                                     // 8-phase schedule (needs K % 64 == 0 for k-major operands)
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_8p(p, epi, a_kmajor, b_kmajor, splitk, s);
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);

@@ -108,6 +108,44 @@ __device__ __forceinline__ bf16x8_t frag_tr_rm(const char* rm, int dt, int t, in
   }
   return u.v;
 }
+// The same gather through inline assembly, for the K / V / Q / dO tiles that are filled by LDS-DMA: hipcc cannot tell that a
+// __builtin_amdgcn_ds_read_tr16_b64 does not alias the buffer_load ... lds transfers in flight and puts s_waitcnt vmcnt(0) in
+// front of it -- which here meant waiting, in the middle of an item, for the NEXT item's prefetched tiles (found in round 3).
+// The result may only be used after lgkm_wait4() on it.
+// Per-lane byte offsets of the lane's element for the four 16-column blocks dt (row 4g + (i>>2) of a 32-row group): the
+// swizzle depends on the lane only ((row >> 1) & 7 = 2g + (i >> 3) for every t and h), so the tile, t and h are immediates.
+__device__ __forceinline__ void tr_lane_offsets(int lane, uint32_t (&off)[4]) {
+  const int g = lane >> 4, i16 = lane & 15;
+  const int r = 4 * g + (i16 >> 2);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) off[dt] = (uint32_t)(rm_off(r, dt * 2 + ((i16 & 3) >> 1)) + (i16 & 1) * 8);
+}
+// fragment (dt, t) of the tile at byte offset TILE from the address the offsets were added to: rows 32t + 16h + ...
+template <int TILE, int T>
+__device__ __forceinline__ bf16x8_t frag_tr_na(uint32_t addr) {
+  union { bf16x8_t v; s16x4_t h[2]; } u;
+  u.h[0] = ds_read_tr_na<TILE + T * 4096>(addr);
+  u.h[1] = ds_read_tr_na<TILE + T * 4096 + 2048>(addr);
+  return u.v;
+}
+// the four dt fragments of key / query pair t (t is a loop index of an unrolled loop: dispatched to the immediate forms)
+template <int TILE, int NP>
+__device__ __forceinline__ void frag4_tr_na(bf16x8_t (&f)[4], const uint32_t (&addr)[4], int t) {
+  constexpr int T1 = 1 < NP ? 1 : 0, T2 = 2 < NP ? 2 : 0, T3 = 3 < NP ? 3 : 0, T4 = 4 < NP ? 4 : 0, T5 = 5 < NP ? 5 : 0, T6 = 6 < NP ? 6 : 0;   // t < NP always
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    switch (t) {
+      case 0: f[dt] = frag_tr_na<TILE, 0>(addr[dt]); break;   case 1: f[dt] = frag_tr_na<TILE, T1>(addr[dt]); break;
+      case 2: f[dt] = frag_tr_na<TILE, T2>(addr[dt]); break;  case 3: f[dt] = frag_tr_na<TILE, T3>(addr[dt]); break;
+      case 4: f[dt] = frag_tr_na<TILE, T4>(addr[dt]); break;  case 5: f[dt] = frag_tr_na<TILE, T5>(addr[dt]); break;
+      default: f[dt] = frag_tr_na<TILE, T6>(addr[dt]); break;
+    }
+  }
+}
+// wait for every LDS read of this wave; the fragments pass through the statement so that no consumer can be scheduled above it
+__device__ __forceinline__ void lgkm_wait4(bf16x8_t& a, bf16x8_t& b, bf16x8_t& c, bf16x8_t& d) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 __device__ __forceinline__ bf16x8_t pack_pair(f32x4_t a, f32x4_t b) {
   union { bf16x8_t v; uint32_t w[4]; } u;
   u.w[0] = pack2bf(a[0], a[1]); u.w[1] = pack2bf(a[2], a[3]);
@@ -143,6 +181,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   const int q0 = wave * 16, g = lane >> 4;
   int item = blockIdx.x;
   bf16x8_t nq[2];
+  uint32_t troff[4];
+  tr_lane_offsets(lane, troff);
   if (item < items) {
     const bf16_t* base = qkv + (size_t)(item / H) * S * ld + (item % H) * HD;
     stage_head_dma(base + D, ld, S, smem, KP, wv, NKT, lane);
@@ -206,11 +246,20 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
     f32x4_t o[4];
   #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    uint32_t vaddr[4];                         // this item's V tile + the lane's offsets (4 adds per item)
+    {
+      const uint32_t vb = lds_addr32(Vb);
+  #pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vaddr[dt] = vb + troff[dt];
+    }
   #pragma unroll
     for (int t = 0; t < NP; ++t) {
       bf16x8_t pb = pack_pair(st[2 * t], st[2 * t + 1]);
+      bf16x8_t vf[4];
+      frag4_tr_na<0, NP>(vf, vaddr, t);
+      lgkm_wait4(vf[0], vf[1], vf[2], vf[3]);
   #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(frag_tr_rm(Vb, dt, t, lane), pb, o[dt]);
+      for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(vf[dt], pb, o[dt]);
     }
     const int q = q0 + (lane & 15);
     if (q < S) {
@@ -269,6 +318,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
   if (dbias) for (int i = tid; i < H * 192; i += nthr) bias_s[i] = 0.f;
   int item = blockIdx.x;
   const int q0 = wave * 16, q = q0 + (lane & 15);
+  uint32_t tr0[4], tr1[4];                     // LDS addresses of the lane's transposing reads: tiles below / above 64 KB
+  tr_lane_offsets(lane, tr0);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { tr0[dt] += lds_addr32(smem); tr1[dt] = tr0[dt] + 65536u; }
   // this wave's own Q / dO / O strips and lse of the NEXT item are fetched (to registers) at the end of phase B of the current one
   bf16x8_t nq[2], ndo[2], no[2];
   float nlq = 0.f;
@@ -362,8 +415,11 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
           }
         }
         bf16x8_t b = pack_pair(dsv[0], dsv[1]);
+        bf16x8_t kf[4];
+        frag4_tr_na<RM, NP>(kf, tr0, t);                                  // K tile
+        lgkm_wait4(kf[0], kf[1], kf[2], kf[3]);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(frag_tr_rm(Ks, dt, t, lane), b, acc[dt]);
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(kf[dt], b, acc[dt]);
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -434,10 +490,17 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
         }
         bf16x8_t bp = pack_pair(pv2[0], pv2[1]);
         bf16x8_t bd = pack_pair(ds2[0], ds2[1]);
+        {
+          bf16x8_t tf[4];
+          constexpr bool HI = 3 * RM + (NP - 1) * 4096 + 2048 >= 65536;   // dO tile: past the 64-KB reach of the immediate at S > 128
+          frag4_tr_na<HI ? 3 * RM - 65536 : 3 * RM, NP>(tf, HI ? tr1 : tr0, t);
+          lgkm_wait4(tf[0], tf[1], tf[2], tf[3]);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          adv[dt] = mfma16(frag_tr_rm(dOs, dt, t, lane), bp, adv[dt]);
-          adk[dt] = mfma16(frag_tr_rm(Qs, dt, t, lane), bd, adk[dt]);
+          for (int dt = 0; dt < 4; ++dt) adv[dt] = mfma16(tf[dt], bp, adv[dt]);
+          frag4_tr_na<0, NP>(tf, tr0, t);                                 // Q tile
+          lgkm_wait4(tf[0], tf[1], tf[2], tf[3]);
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) adk[dt] = mfma16(tf[dt], bd, adk[dt]);
         }
       }
       // next item's strips: requested here, after the register-hungry loop, and hidden behind the stores and barrier 1

@@ -111,6 +111,7 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
 
 
 # ---- deterministic weight-gradient accumulate ------------------------------------------------------------------------------
+WGRAD_TILE = 0                   # 0 = the library's choice; 2565 = the 4-wave 128x128-wave-tile kernel (A/B and tests)
 DETERMINISTIC_WGRAD = True       # False: fp32 atomics straight into the gradient (out_mode 2), order-dependent in the last bits
 _WGRAD_WS = {}                   # (device index, stream) -> uint8 workspace; GEMMs on one stream are ordered, so they share it
 
@@ -136,10 +137,13 @@ def gemm_accum(A, B, C, M, N, K):
     if trace is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _lib.call('avt_gemm_accum_bf16', _p(A), _ld(A), _p(B), _ld(B), _p(C), _ld(C), M, N, K, 0, 0, _p(ws), ws.numel(), _stream())
+    _lib.call('avt_gemm_accum_bf16', _p(A), _ld(A), _p(B), _ld(B), _p(C), _ld(C), M, N, K, 0, WGRAD_TILE, _p(ws), ws.numel(), _stream())
     if trace is not None:
         ev1.record()
-        trace.append((gemm_variant(M, N, K, False, False, OUT_ACCUM_F32, 0).replace(',1>', ',2>'), 2.0 * M * N * K, ev0, ev1))   # EPI 2 = slabs + ordered reduce
+        name = gemm_variant(M, N, K, False, False, OUT_ACCUM_F32, WGRAD_TILE if WGRAD_TILE != 2565 else 0).replace(',1>', ',2>')   # EPI 2 = slabs + ordered reduce
+        if name.startswith('gemm_8p_kernel') and WGRAD_TILE in (0, 2565):
+            name = 'gemm_w4_kernel<2>'                    # the library's default for 256x256-tile weight gradients
+        trace.append((name, 2.0 * M * N * K, ev0, ev1))
     return C
 
 

@@ -249,7 +249,7 @@ def main(argv=None):
                 d[0] += fl
                 d[1] += e0.elapsed_time(e1) * 1e-3
                 d[2] += 1
-        dom = {k: v for k, v in per_variant.items() if k.startswith(('gemm_kernel<128', 'gemm_kernel<256', 'gemm_8p_kernel'))}
+        dom = {k: v for k, v in per_variant.items() if k.startswith(('gemm_kernel<128', 'gemm_kernel<256', 'gemm_8p_kernel', 'gemm_w4_kernel', 'gemm_4w_kernel'))}
         fl = sum(v[0] for v in dom.values())
         tm = sum(v[1] for v in dom.values())
         n_launch = sum(v[2] for v in dom.values())
@@ -270,7 +270,7 @@ def main(argv=None):
         if tm > 0:
             ach = fl / tm / 1e12
             roof['dominant_kernel'] = {
-                'kernel': 'gemm_8p_kernel<*> (256x256x64, 8-phase) + gemm_kernel<256|128,*> (bf16 MFMA GEMM, all layouts/epilogues)',
+                'kernel': 'gemm_8p_kernel<*> (256x256x64, 8-phase) + gemm_w4_kernel (weight gradients, 4 waves of 128x128) + gemm_kernel<256|128,*> (bf16 MFMA GEMM, all layouts/epilogues)',
                 'achieved': round(ach, 1), 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4),
                 'launches': n_launch, 'avg_launch_us': round(tm / n_launch * 1e6, 2),
                 'avg_launch_gflop': round(fl / n_launch / 1e9, 3), 'share_of_step_time': round(tm / elapsed, 3),
