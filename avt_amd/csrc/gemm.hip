@@ -472,7 +472,7 @@ __device__ __forceinline__ void epi_fast(const GemmParams& p, const f32x16_t (&a
   float* bias_l = (float*)wave_lds;
   char* patch_c = wave_lds + WN * 4;
   char* patch_d = patch_c + 32 * LDB;
-  if (lane < WN) bias_l[lane] = (p.bias && col0 + lane < p.N) ? p.bias[col0 + lane] : 0.f;
+  for (int c_ = lane; c_ < WN; c_ += 64) bias_l[c_] = (p.bias && col0 + c_ < p.N) ? p.bias[col0 + c_] : 0.f;
   if (ACT == 0) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -515,7 +515,7 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
   char* patch_c = wave_lds + WN * 4;
   char* patch_d = patch_c + 32 * LDB;
   char* opbuf = patch_d + 32 * LDB;
-  if (lane < WN) bias_l[lane] = (p.bias && col0 + lane < p.N) ? p.bias[col0 + lane] : 0.f;
+  for (int c_ = lane; c_ < WN; c_ += 64) bias_l[c_] = (p.bias && col0 + c_ < p.N) ? p.bias[col0 + c_] : 0.f;
   const int ml = lane & 31, h = lane >> 5;
   const int rl = lane / LPR, pc = lane % LPR, cl = pc * 8;
   const bf16_t* prim_ptr = (ACT == 3) ? p.aux : p.res;
