@@ -48,7 +48,10 @@ int avt_abi_version(void);
  *     v += res[(res_period ? m % res_period : m), n];  colsum[n] += v (over the bf16-rounded values when C is bf16; see "partials" below);  C[m,n] = v
  * out_mode 2: C (fp32) += acc with atomics, no epilogue; splitk > 1 splits the reduction over workgroups
  *             (splitk <= 0 picks a factor that fills the chip).  Used for weight gradients.
- * tile: 0 = choose; 64 | 128 | 256 | 808 (256x256 tile, 8-phase schedule) force a kernel.  Requirements: 16-B aligned pointers, lda/ldb % 8 == 0,
+ * tile: 0 = choose; 64 | 128 | 256 | 808 (256x256 tile, 8-phase schedule) | 2564 (256x128 tile, 4 waves, two workgroups per CU: k-major
+ * operands, K % 32 == 0; bit-identical to 808, measured slower -- kept for experiments) force a kernel.  The automatic choice walks the
+ * tiles of an activation GEMM whose B operand exceeds an XCD's 4-MB L2 (N*K*2 > 4 MB, e.g. the fc1 weight) in column strips, so that
+ * the strip of B stays L2-resident (results do not depend on the tile order).  Requirements: 16-B aligned pointers, lda/ldb % 8 == 0,
  * K % 8 == 0 when an operand is k-major, N % 4 == 0 and ldc % 4 == 0 for out_mode 0/1. */
 int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,
                   void* C, int ldc, int M, int N, int K,
@@ -71,7 +74,10 @@ size_t avt_gemm_colsum_workspace_bytes(int M, int N, int tile);
  * major (dW = dy^T x of a Linear, x^T dy of an HF Conv1D).  Same kernels as out_mode 2, but every (split, tile) workgroup
  * writes its partial tile to its own slab of `workspace` and a second kernel adds the slabs in split order into C: no atomics,
  * bit-reproducible, and cheaper than the atomics (66 MB of full-line stores + one pass instead of 16 M fp32 atomics for fc1).
- * avt_gemm_accum_workspace_bytes(M, N, K) = bytes the automatic tile / split choice (tile = 0, splitk <= 0) needs. */
+ * avt_gemm_accum_workspace_bytes(M, N, K) = bytes the automatic tile / split choice (tile = 0, splitk <= 0) needs.
+ * tile: 0 = choose (256x256 output tiles: the 4-wave kernel with 128x128 wave tiles and AGPR accumulators, else 128x128 tiles);
+ * 808 = the 8-phase kernel, 2565 = the 4-wave kernel, 128 = small tiles.  Kernels differ in where the reduction is split, so their
+ * results differ in the last bits; each kernel is bit-reproducible. */
 int avt_gemm_accum_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                         int splitk, int tile, void* workspace, size_t workspace_bytes, void* stream);
 size_t avt_gemm_accum_workspace_bytes(int M, int N, int K);
