@@ -68,23 +68,26 @@ __device__ __forceinline__ void gelu_erf_both(float x, float& y, float& dy) {
   y = x * cdf;
   dy = cdf + x * 0.3989422804014327f * ex;
 }
-// two elements at a time with packed fp32 arithmetic (v_pk_mul/fma/add_f32); erf(z) = z * P(z^2) on |z| <= 3 (degree-8
-// near-minimax fit, |error| <= 2.4e-5, i.e. below bf16 resolution of the outputs; |z| > 3 clamps to +-1), one v_exp_f32
-// per element for the density term of the derivative.
+// two elements at a time with packed fp32 arithmetic (v_pk_mul/fma/add_f32).  Phi(x) = 1/2 + x R(x^2) on |x| <= 3 sqrt(2), with
+// R(u) = (1 / (2 sqrt 2)) P(u / 2) from the degree-8 near-minimax fit erf(z) = z P(z^2) on |z| <= 3 (|error| of Phi <= 1.2e-5, far
+// below bf16 resolution of the outputs; beyond the clamp Phi is 0 / 1 to 1e-5 and x phi(x) < 3e-4); one v_exp_f32 per element for
+// the density term of the derivative.  Working in x^2 directly (coefficients rescaled, the 1/sqrt 2 and the 1/2 folded in) takes
+// 8 vector instructions per 4 elements off the round-2 form (z = x / sqrt 2, z^2, z P, * 1/2 + 1/2): the epilogue is bound by
+// the vector-ALU issue rate (profiles/r03_issue_rules.txt), where one exponential costs 1.5 packed FMAs.
 __device__ __forceinline__ void gelu_erf_both2(f32x2_t x, f32x2_t& y, f32x2_t& dy) {
-  f32x2_t z = x * 0.70710678118654752f;
-  z[0] = __builtin_amdgcn_fmed3f(z[0], -3.0f, 3.0f); z[1] = __builtin_amdgcn_fmed3f(z[1], -3.0f, 3.0f);
-  const f32x2_t u = z * z;                                            // = min(x^2 / 2, 9)
-  f32x2_t pl = u * 4.074186322e-08f + -1.944813448e-06f;
-  pl = pl * u + 4.106037522e-05f;
-  pl = pl * u + -5.110356142e-04f;
-  pl = pl * u + 4.235421773e-03f;
-  pl = pl * u + -2.510284632e-02f;
-  pl = pl * u + 1.110793129e-01f;
-  pl = pl * u + -3.753148615e-01f;
-  pl = pl * u + 1.128268480e+00f;
-  const f32x2_t cdf = z * pl * 0.5f + 0.5f;                           // |erf| <= 1 + 2.4e-5 on the clamped range: no second clamp
-  const f32x2_t a = u * -1.4426950408889634f;                         // exp(-x^2/2) = 2^a (x*phi(x) < 3e-4 where the clamp bites)
+  f32x2_t xc;
+  xc[0] = __builtin_amdgcn_fmed3f(x[0], -4.242640687f, 4.242640687f); xc[1] = __builtin_amdgcn_fmed3f(x[1], -4.242640687f, 4.242640687f);
+  const f32x2_t u = xc * xc;                                          // = min(x^2, 18)
+  f32x2_t pl = u * 5.626728078e-11f + -5.371838974e-09f;
+  pl = pl * u + 2.268286700e-07f;
+  pl = pl * u + -5.646199191e-06f;
+  pl = pl * u + 9.359048303e-05f;
+  pl = pl * u + -1.109399554e-03f;
+  pl = pl * u + 9.818116925e-03f;
+  pl = pl * u + -6.634692091e-02f;
+  pl = pl * u + 3.989031466e-01f;
+  const f32x2_t cdf = xc * pl + 0.5f;
+  const f32x2_t a = u * -0.7213475204444817f;                         // exp(-x^2/2) = 2^a
   f32x2_t ex; ex[0] = __builtin_amdgcn_exp2f(a[0]); ex[1] = __builtin_amdgcn_exp2f(a[1]);
   y = x * cdf;
   dy = x * 0.3989422804014327f * ex + cdf;

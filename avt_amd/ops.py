@@ -443,6 +443,35 @@ def xent_bwd(logits, target, lse, gout, C, ldd, ignore_index=-1):
     return dlogits
 
 
+# ---- classifier + softmax cross-entropy as one operator ----------------------------------------------------------------------
+def linear_softmax_xent_fwd(x, w, bias, target, C, ignore_index=-1):
+    """x bf16 [R, K], w bf16 [Cpad, K] (rows >= C zero), bias fp32 [Cpad] | None, target int64 [R] -> (logits fp32 [R, Cpad], loss, lse, rank)."""
+    _chk(x, BF16, 'x'); _chk(w, BF16, 'w')
+    R, K = x.shape
+    Cpad = w.size(0)
+    logits = torch.empty((R, Cpad), device=x.device, dtype=torch.float32)
+    loss = torch.empty(R, device=x.device, dtype=torch.float32)
+    lse = torch.empty(R, device=x.device, dtype=torch.float32)
+    rank = torch.empty(R, device=x.device, dtype=torch.int32)
+    _lib.call('avt_linear_softmax_xent_fwd', _p(x), _ld(x), _p(w), _ld(w), _p(bias), _p(target), _p(logits), _ld(logits), _p(loss), _p(lse),
+              _p(rank), R, C, Cpad, K, ignore_index, _stream())
+    return logits, loss, lse, rank
+
+
+def linear_softmax_xent_bwd(logits, target, lse, gloss, x, w, C, dw=None, dbias=None, want_dx=True, dx_f32=True, ignore_index=-1):
+    """Backward of linear_softmax_xent_fwd: accumulates into dw [Cpad, K] / dbias [Cpad] (fp32) and returns dx [R, K] (or None)."""
+    R, K = x.shape
+    Cpad = w.size(0)
+    dlogits = torch.empty((R, Cpad), device=x.device, dtype=BF16)
+    dx = torch.empty((R, K), device=x.device, dtype=torch.float32 if dx_f32 else BF16) if want_dx else None
+    ws = _wgrad_workspace(x.device, _lib.load().avt_gemm_accum_workspace_bytes(Cpad, K, R)) if dw is not None else None
+    part, part_bytes = _partials(x.device, 'avt_colsum_workspace_bytes', R, Cpad) if dbias is not None else (None, 0)
+    _lib.call('avt_linear_softmax_xent_bwd', _p(logits), _ld(logits), _p(target), _p(lse), _p(gloss), _p(x), _ld(x), _p(w), _ld(w), _p(dlogits),
+              _p(dw), _ld(dw) if dw is not None else 0, _p(dbias), _p(dx), _ld(dx) if dx is not None else 0, int(dx_f32), R, C, Cpad, K,
+              ignore_index, _p(ws), ws.numel() if ws is not None else 0, part, part_bytes, _stream())
+    return dx
+
+
 # ---- optimizer -------------------------------------------------------------------------------------------------------------
 def sgd_step(param, grad, buf, shadow, lr, momentum, weight_decay, grad_scale=1.0, nesterov=True, first_step=False, zero_grad=True):
     _lib.call('avt_sgd_step', _p(param), _p(grad), _p(buf), _p(shadow), param.numel(), float(lr), float(momentum),

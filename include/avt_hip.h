@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 3
+#define AVT_ABI_VERSION 4
 
 const char* avt_last_error(void);
 int avt_abi_version(void);
@@ -196,6 +196,24 @@ int avt_xent_fwd(const float* logits, int ld, const long* target, float* loss, f
                  long ignore_index, void* stream);
 int avt_xent_bwd(const float* logits, int ld, const long* target, const float* lse, const float* gout, void* dlogits,
                  int ldd, int R, int C, long ignore_index, void* stream);
+
+/* ---- classifier + softmax cross-entropy as one operator -------------------------------------------------------
+ * Replaces torch.nn.Linear (models/base_model.py:203-216, conf/model/classifier/linear.yaml:3) followed by MultiDimCrossEntropy
+ * (loss_fn/multidim_xentropy.py:11-25: ignore_index, reduction 'none') and, in backward, their two autograd nodes.
+ * fwd: logits[R, ldl >= Cpad] (fp32) = x[R,K] W[Cpad,K]^T + bias[Cpad];  loss[r] = lse[r] - logits[r, target[r]] (0 where target ==
+ *      ignore_index), lse[r], rank[r] = number of logits above the target's (-1 where ignored; may be NULL).  C valid classes, the
+ *      weight / bias rows C..Cpad-1 are zero padding (Cpad % 8 == 0).
+ * bwd: dlogits = (softmax - onehot) * gloss[r] written ONCE as bf16 [R, Cpad] (caller scratch, zero padding columns) and consumed
+ *      in place by  dw[Cpad,K] (fp32) += dlogits^T x  (deterministic split-K: `workspace` of avt_gemm_accum_workspace_bytes(Cpad,K,R)),
+ *      dbias[Cpad] += column sums (`partials`: see above),  dx[R,K] = dlogits W  (bf16, or fp32 when dx_f32).  dw / dbias / dx may be NULL. */
+int avt_linear_softmax_xent_fwd(const void* x, int ldx, const void* w, int ldw, const float* bias, const long* target,
+                                float* logits, int ldl, float* loss, float* lse, int* rank,
+                                int R, int C, int Cpad, int K, long ignore_index, void* stream);
+int avt_linear_softmax_xent_bwd(const float* logits, int ldl, const long* target, const float* lse, const float* gloss,
+                                const void* x, int ldx, const void* w, int ldw, void* dlogits_bf16,
+                                float* dw, int lddw, float* dbias, void* dx, int lddx, int dx_f32,
+                                int R, int C, int Cpad, int K, long ignore_index,
+                                void* workspace, size_t workspace_bytes, float* partials, size_t partials_bytes, void* stream);
 
 /* ---- optimizer -------------------------------------------------------------------------------------------------------
  * torch.optim.SGD(momentum, nesterov, weight_decay) over a flat fp32 range (func/train.py:233, conf/opt/optimizer/sgd.yaml):

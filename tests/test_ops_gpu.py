@@ -699,3 +699,32 @@ def test_bench_size_kernels_on_sampled_rows(ops):
         assert relerr(out[sl], r) < 1e-2, f
         assert relerr(dqkv[sl], t.grad.permute(2, 0, 1, 3).reshape(S, 3 * D)) < 2e-2, f
     assert relerr(dbias, dqkv.float().sum(0)) < 5e-3
+
+
+def test_linear_cross_entropy_fused_operator_vs_torch():
+    """avt_linear_softmax_xent_fwd / _bwd: logits, un-reduced loss with ignore_index, target rank, and the gradients of the
+    weight, the bias and the input against torch.nn.functional.linear + cross_entropy in fp32 -- at the classifier's real shape
+    ((B*T + B) rows x 768 -> 3806 classes, padded to 3840) and a ragged toy shape."""
+    import torch.nn.functional as F
+    from avt_amd.loss_fn.fused_linear_xent import LinearCrossEntropy
+    for (R, K, C) in [(2816, 768, 3806), (37, 64, 17)]:
+        g = torch.Generator().manual_seed(R)
+        x = (torch.randn((R, K), generator=g) * 0.5).cuda().requires_grad_()
+        target = torch.randint(-1, C, (R,), generator=g).cuda()
+        m = LinearCrossEntropy(K, C).cuda()
+        with torch.no_grad():
+            m.weight.normal_(0, 0.05, generator=torch.Generator(device='cuda').manual_seed(1)); m.bias.uniform_(-0.1, 0.1)
+        loss, rank, logits = m(x, target)
+        w = torch.rand(R, generator=g).cuda()
+        (loss * w).sum().backward()
+        xr = x.detach().clone().requires_grad_(); wr = m.weight.detach().clone().requires_grad_(); br = m.bias.detach().clone().requires_grad_()
+        lg = F.linear(xr, wr, br)
+        ref = F.cross_entropy(lg, target, ignore_index=-1, reduction='none')
+        (ref * w).sum().backward()
+        assert relerr(logits, lg) < 2e-2 and relerr(loss, ref) < 2e-2
+        assert float(loss[target < 0].abs().max() if (target < 0).any() else 0.0) == 0.0
+        ref_rank = (lg > lg.gather(1, target.clamp(min=0)[:, None])).sum(1)
+        ok = target >= 0
+        assert float((rank[ok] - ref_rank[ok]).abs().float().mean()) < 0.5          # bf16 logits may swap near-ties
+        assert bool((rank[~ok] == -1).all())
+        assert relerr(m.weight.grad, wr.grad) < 3e-2 and relerr(m.bias.grad, br.grad) < 3e-2 and relerr(x.grad, xr.grad) < 3e-2
