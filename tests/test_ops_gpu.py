@@ -723,8 +723,10 @@ def test_linear_cross_entropy_fused_operator_vs_torch():
         (ref * w).sum().backward()
         assert relerr(logits, lg) < 2e-2 and relerr(loss, ref) < 2e-2
         assert float(loss[target < 0].abs().max() if (target < 0).any() else 0.0) == 0.0
-        ref_rank = (lg > lg.gather(1, target.clamp(min=0)[:, None])).sum(1)
+        ref_rank = (logits > logits.gather(1, target.clamp(min=0)[:, None])).sum(1)       # of the operator's own logits: exact
         ok = target >= 0
-        assert float((rank[ok] - ref_rank[ok]).abs().float().mean()) < 0.5          # bf16 logits may swap near-ties
+        assert bool((rank[ok] == ref_rank[ok]).all())
+        fp32_rank = (lg > lg.gather(1, target.clamp(min=0)[:, None])).sum(1)
+        assert float((rank[ok] - fp32_rank[ok]).abs().float().mean()) < 0.01 * C           # bf16 operands swap near-ties among thousands of classes
         assert bool((rank[~ok] == -1).all())
         assert relerr(m.weight.grad, wr.grad) < 3e-2 and relerr(m.bias.grad, br.grad) < 3e-2 and relerr(x.grad, xr.grad) < 3e-2
