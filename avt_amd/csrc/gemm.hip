@@ -784,8 +784,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   const int tn0 = (t % p.tiles_n) * BN;
 
   const int nk_total = (p.K + BK - 1) / BK;
-  const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
-  const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
+  // (32-bit arithmetic: nk_total * splitk < 2^31 for every operand below 4 GiB; the 64-bit form expands to ~200 scalar
+  // instructions at the start of every workgroup)
+  const int kt_begin = p.splitk == 1 ? 0 : (int)((unsigned)nk_total * (unsigned)split / (unsigned)p.splitk);
+  const int kt_end = p.splitk == 1 ? nk_total : (int)((unsigned)nk_total * (unsigned)(split + 1) / (unsigned)p.splitk);
   const int nk = kt_end - kt_begin;
 #ifdef AVT_LAB
   if (MINW >= 2) stagger_slot(p.stagger, bid, 512); else
@@ -1124,8 +1126,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
   const int tm0 = (t / p.tiles_n) * BM;
   const int tn0 = (t % p.tiles_n) * BN;
   const int nk_total = (p.K + BK - 1) / BK;
-  const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
-  const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
+  // (32-bit arithmetic: nk_total * splitk < 2^31 for every operand below 4 GiB; the 64-bit form expands to ~200 scalar
+  // instructions at the start of every workgroup)
+  const int kt_begin = p.splitk == 1 ? 0 : (int)((unsigned)nk_total * (unsigned)split / (unsigned)p.splitk);
+  const int kt_end = p.splitk == 1 ? nk_total : (int)((unsigned)nk_total * (unsigned)(split + 1) / (unsigned)p.splitk);
   const int nk = kt_end - kt_begin;
 
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
@@ -1316,8 +1320,10 @@ __global__ __launch_bounds__(512) void gemm_deepa_kernel(GemmParams p) {
   const int tm0 = (t / p.tiles_n) * BM;
   const int tn0 = (t % p.tiles_n) * BN;
   const int nk_total = (p.K + BK - 1) / BK;
-  const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
-  const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
+  // (32-bit arithmetic: nk_total * splitk < 2^31 for every operand below 4 GiB; the 64-bit form expands to ~200 scalar
+  // instructions at the start of every workgroup)
+  const int kt_begin = p.splitk == 1 ? 0 : (int)((unsigned)nk_total * (unsigned)split / (unsigned)p.splitk);
+  const int kt_end = p.splitk == 1 ? nk_total : (int)((unsigned)nk_total * (unsigned)(split + 1) / (unsigned)p.splitk);
   const int nk = kt_end - kt_begin;
 
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
@@ -1473,8 +1479,10 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
   const int tm0 = tm_i * BM;
   const int tn0 = tn_i * BN;
   const int nk_total = (p.K + BK - 1) / BK;
-  const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
-  const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
+  // (32-bit arithmetic: nk_total * splitk < 2^31 for every operand below 4 GiB; the 64-bit form expands to ~200 scalar
+  // instructions at the start of every workgroup)
+  const int kt_begin = p.splitk == 1 ? 0 : (int)((unsigned)nk_total * (unsigned)split / (unsigned)p.splitk);
+  const int kt_end = p.splitk == 1 ? nk_total : (int)((unsigned)nk_total * (unsigned)(split + 1) / (unsigned)p.splitk);
   const int nk = kt_end - kt_begin;
 #ifdef AVT_LAB
   long long t8_start = 0, t8_loop = 0;
@@ -1943,8 +1951,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   const int tm0 = (t_ / p.tiles_n) * BM;
   const int tn0 = (t_ % p.tiles_n) * BN;
   const int nk_total = (p.K + BK - 1) / BK;
-  const int kt_begin = (int)(((long)nk_total * split) / p.splitk);
-  const int kt_end = (int)(((long)nk_total * (split + 1)) / p.splitk);
+  // (32-bit arithmetic: nk_total * splitk < 2^31 for every operand below 4 GiB; the 64-bit form expands to ~200 scalar
+  // instructions at the start of every workgroup)
+  const int kt_begin = p.splitk == 1 ? 0 : (int)((unsigned)nk_total * (unsigned)split / (unsigned)p.splitk);
+  const int kt_end = p.splitk == 1 ? nk_total : (int)((unsigned)nk_total * (unsigned)(split + 1) / (unsigned)p.splitk);
   const int nk = kt_end - kt_begin;
 
   // LDS-DMA: one instruction = 2 k rows x 512 B; wave w stages rows q*8 + w*2 .. +1 (q = 0..3) of A and of B.  A column
