@@ -7,9 +7,13 @@ distributions the reference's transforms use (``random.randint`` for the ``"248-
 RandomCrop.get_params), so a seeded run draws the same sequence.
 
 Configured from the same ``data_train`` / ``data_eval`` keys (conf/data/default.yaml: scale_h, scale_w, crop_size, mean, std, flip_p,
-scale_pix_val, reverse_channels, eval_num_crops, eval_flip_crops).  Colour jitter is 0 in every AVT experiment
-(conf/data/default.yaml:37-40): non-zero strengths raise, and the zero-strength ``ColorJitterVideo`` of the TRAINING chain is reproduced
-for what it still does -- its float -> PIL -> float round trip cuts the resized pixels to 8 bits (``quantize_u8`` of the kernel).
+scale_pix_val, reverse_channels, eval_num_crops, eval_flip_crops, color_jitter_*).  Colour jitter is 0 in every AVT experiment
+(conf/data/default.yaml:37-40): the zero-strength ``ColorJitterVideo`` of the TRAINING chain is reproduced for what it still does -- its
+float -> PIL -> float round trip cuts the resized pixels to 8 bits (``quantize_u8`` of the fused kernel).  With non-zero strengths the
+three-stage kernel chain of ``avt_video_preproc_jitter_u8`` runs instead (resize + flip -> 8-bit clip -> the four Pillow operations of
+torchvision 0.8.2's ColorJitter, bit-exact -> normalise + crop); the draws follow torchvision 0.8.2's ``ColorJitter.forward``:
+``torch.randperm(4)`` for the order, ``torch.tensor(1.0).uniform_(lo, hi)`` per active operation when its turn comes, one draw per clip
+(the reference jitters all frames of a clip as one stacked image, common/transforms.py:399-421).
 """
 import random
 
@@ -22,8 +26,19 @@ class GpuClipTransform:
     def __init__(self, scale_h, scale_w=-1, crop_size=224, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), flip_p=0.5,
                  scale_pix_val=1.0, reverse_channels=False, train=True, eval_num_crops=1, eval_flip_crops=False, color_jitter_brightness=0.0, color_jitter_contrast=0.0,
                  color_jitter_saturation=0.0, color_jitter_hue=0.0, **_unused):
-        if any(v != 0 for v in (color_jitter_brightness, color_jitter_contrast, color_jitter_saturation, color_jitter_hue)):
-            raise NotImplementedError('colour jitter is 0 in the AVT experiments and not part of the fused kernel')
+        # torchvision ColorJitter._check_input: value v -> range [max(0, 1 - v), 1 + v] (hue: [-v, v], v <= 0.5); None when it is a no-op
+        def _rng(v, center=1.0, clip0=True):
+            if isinstance(v, (tuple, list)):
+                lo, hi = float(v[0]), float(v[1])
+            else:
+                lo, hi = center - float(v), center + float(v)
+                if clip0:
+                    lo = max(lo, 0.0)
+            return None if lo == hi == center else (lo, hi)
+        self.jitter = [_rng(color_jitter_brightness), _rng(color_jitter_contrast), _rng(color_jitter_saturation),
+                       _rng(color_jitter_hue, center=0.0, clip0=False)] if train else [None] * 4
+        if self.jitter[3] is not None and not (-0.5 <= self.jitter[3][0] <= self.jitter[3][1] <= 0.5):
+            raise ValueError('hue jitter must lie in [-0.5, 0.5]')
         if crop_size is None:
             raise NotImplementedError('the fused kernel writes a fixed-size batch: crop_size must be set')
         self.scale_h, self.scale_w = scale_h, scale_w
@@ -63,6 +78,16 @@ class GpuClipTransform:
             i, j = int(round((new_h - th) / 2.0)), int(round((new_w - tw) / 2.0))
         return new_h, new_w, flip, i, j
 
+    def draw_jitter(self):
+        """One clip's colour-jitter operations [(op id, factor)] in application order, drawn as torchvision 0.8.2's ColorJitter.forward
+        does: a random permutation of (brightness, contrast, saturation, hue), each active one drawing its factor when its turn comes."""
+        ops = []
+        for fn_id in torch.randperm(4).tolist():
+            r = self.jitter[fn_id]
+            if r is not None:
+                ops.append((fn_id, torch.tensor(1.0).uniform_(r[0], r[1]).item()))
+        return ops
+
     def eval_crops(self, H, W):
         """MultiCropVideo (common/transforms.py:254-296): [(new_h, new_w, flip, i, j)] for the 1 or 3 crops, then their mirror
         images when ``eval_flip_crops`` (a mirrored crop at column j = the crop at new_w - tw - j of the mirrored frame)."""
@@ -74,9 +99,10 @@ class GpuClipTransform:
             out += [(new_h, new_w, 1, i, new_w - tw - j) for i, j in pos]
         return out
 
-    def __call__(self, clips_u8, params=None):
+    def __call__(self, clips_u8, params=None, jitter=None):
         """clips_u8: uint8 (B, T, H, W, 3) on the GPU -> fp32 (B, T, 3, 1, crop_h, crop_w), the ``video`` entry of the sample
-        dict the model consumes.  ``params`` (B x 5 ints) overrides the draws (tests)."""
+        dict the model consumes.  ``params`` (B x 5 ints) overrides the draws (tests); ``jitter`` (per clip a list of
+        (op id | name, factor) in application order) overrides the colour-jitter draws."""
         B, T, H, W, _ = clips_u8.shape
         multi = (not self.train) and (self.num_crops > 1 or self.flip_crops) and params is None
         if params is None:
@@ -93,6 +119,20 @@ class GpuClipTransform:
             if not (0 <= src < B and new_h > 0 and new_w > 0 and flip in (0, 1) and 0 <= ci and ci + th <= new_h and 0 <= cj and cj + tw <= new_w):
                 raise ValueError(f'bad preprocessing parameters {(new_h, new_w, flip, ci, cj, src)} for {B} clips and a {th}x{tw} crop')
         p = torch.tensor(params, dtype=torch.int32).to(clips_u8.device, non_blocking=True)
+        if jitter is None and any(r is not None for r in self.jitter):
+            jitter = [self.draw_jitter() for _ in params]                    # after the geometric draws, as in the transform list's order
+        if jitter is not None and any(len(j) for j in jitter):
+            names = ('brightness', 'contrast', 'saturation', 'hue')
+            op_ids = torch.full((len(params), 4), -1, dtype=torch.int32)
+            fac = torch.zeros((len(params), 4), dtype=torch.float32)
+            for b, ops_b in enumerate(jitter):
+                assert len(ops_b) <= 4
+                for k, (op, f) in enumerate(ops_b):
+                    op = names.index(op) if isinstance(op, str) else int(op)
+                    op_ids[b, k] = op
+                    fac[b, k] = float(int(float(f) * 255) & 255) if op == 3 else float(f)   # hue: np.uint8(hue_factor * 255), the 8-bit shift
+            return ops.video_preproc_jitter(clips_u8.contiguous(), p, op_ids.to(clips_u8.device), fac.to(clips_u8.device), self.crop,
+                                            self.scale_pix_val, self.mean, self.std, self.reverse_channels)
         out = ops.video_preproc(clips_u8.contiguous(), p, self.crop, self.scale_pix_val, self.mean, self.std, self.reverse_channels,
                                 quantize_u8=self.quantize_u8)
         if multi:                                   # (B * crops, T, 3, 1, h, w) -> the model's 7-D (B, #clips, #crops, C, T', H, W)

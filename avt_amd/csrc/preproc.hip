@@ -57,6 +57,197 @@ __global__ __launch_bounds__(256) void video_preproc_kernel(const uint8_t* __res
     }
   }
 }
+// ---- ColorJitterVideo with non-zero strengths (common/transforms.py:399-421) ------------------------------------------------------
+// The reference converts the flipped, resized clip -- all frames stacked into one tall image -- to an 8-bit PIL image, runs
+// torchvision 0.8.2's ColorJitter on it (four Pillow operations in a drawn order with drawn factors) and converts back.  The
+// contrast step blends with the mean grey of the WHOLE stacked image, so the resized clip has to exist: three stages instead of
+// the single fused kernel --
+//   1. resize + flip + floor(v * 255)            -> 8-bit scratch clip [clip][T][new_h][new_w][3] (pitch SH x SW)
+//   2. up to four in-place passes, op and factor per clip: brightness / contrast / saturation = Pillow's Image.blend(degenerate,
+//      image, factor) (Blend.c: float32, truncation inside [0, 1], clipping outside) with degenerate = 0 | round(mean luma of the
+//      clip) | the pixel's luma ((19595 R + 38470 G + 7471 B + 0x8000) >> 16); hue = Pillow's rgb2hsv_row / hsv2rgb_row
+//      (Convert.c) around an 8-bit wrap-around add of (int)(factor * 255) & 255 (handed in as the op's factor).  The clip's luma sum is an
+//      exact 64-bit integer sum.
+//   3. / 255, x scale_pix, (reverse channels), normalise, crop -> fp32.
+// No floating-point contraction from here to the end of the file: a fused multiply-add rounds differently from Pillow's C (hipcc contracts
+// by default, THROUGH the __f*_rn intrinsics as well -- measured: saturation was one level off in 0.1 % of the pixels).
+#pragma clang fp contract(off)
+__device__ __forceinline__ int luma_u8(int r, int g, int b) { return (int)(((unsigned)r * 19595u + (unsigned)g * 38470u + (unsigned)b * 7471u + 0x8000u) >> 16); }
+__device__ __forceinline__ int blend_u8(int d, int im, float f) {
+  const float t = ((float)d + (f * (float)(im - d)));
+  if (f >= 0.f && f <= 1.f) return (int)t;                        // (UINT8) of a value inside [0, 255]
+  return t <= 0.f ? 0 : (t >= 255.f ? 255 : (int)t);
+}
+__device__ __forceinline__ void rgb2hsv_u8(int r, int g, int b, int& uh, int& us, int& uv) {
+  const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+  uv = maxc;
+  if (minc == maxc) { uh = 0; us = 0; return; }
+  const float cr = (float)(maxc - minc);
+  const float s = (cr / (float)maxc);
+  const float rc = ((float)(maxc - r) / cr), gc = ((float)(maxc - g) / cr), bc = ((float)(maxc - b) / cr);
+  float h;
+  if (r == maxc) h = (bc - gc);
+  else if (g == maxc) h = (float)((2.0 + (double)rc) - (double)bc);
+  else h = (float)((4.0 + (double)gc) - (double)rc);
+  h = (float)fmod((((double)h / 6.0) + 1.0), 1.0);
+  uh = min(max((int)((double)h * 255.0), 0), 255);
+  us = min(max((int)((double)s * 255.0), 0), 255);
+}
+__device__ __forceinline__ int round_u8(float x) { return min(max((int)rintf(x), 0), 255); }
+__device__ __forceinline__ void hsv2rgb_u8(int uh, int us, int uv, int& r, int& g, int& b) {
+  if (us == 0) { r = g = b = uv; return; }
+  const float h = (((float)uh * 6.0f) / 255.0f), fs = ((float)us / 255.0f), fv = (float)uv;
+  const int i = (int)floorf(h);
+  const float f = (h - (float)i);
+  const int p = round_u8((fv * (1.f - fs)));
+  const int q = round_u8((fv * (1.f - (fs * f))));
+  const int t = round_u8((fv * (1.f - (fs * (1.f - f)))));
+  switch (i % 6) {
+    case 0: r = uv; g = t; b = p; break;
+    case 1: r = q; g = uv; b = p; break;
+    case 2: r = p; g = uv; b = t; break;
+    case 3: r = p; g = q; b = uv; break;
+    case 4: r = t; g = p; b = uv; break;
+    default: r = uv; g = p; b = q; break;
+  }
+}
+
+__global__ __launch_bounds__(256) void resize_flip_u8_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ scratch,
+                                                             const int* __restrict__ params, int T, int H, int W, int SH, int SW, long total) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int x = (int)(idx % SW);
+    long r = idx / SW;
+    const int y = (int)(r % SH); r /= SH;
+    const int t = (int)(r % T);
+    const int b = (int)(r / T);
+    const int* pp = params + b * 6;
+    const int new_h = pp[0], new_w = pp[1], flip = pp[2], sb = pp[5];
+    if (y >= new_h || x >= new_w) continue;
+    const int xr = flip ? new_w - 1 - x : x;
+    const float sy = fmaxf(((float)H / (float)new_h) * ((float)y + 0.5f) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)W / (float)new_w) * ((float)xr + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const uint8_t* f = src + ((size_t)sb * T + t) * (size_t)H * W * 3;
+    const uint8_t* p00 = f + ((size_t)y0 * W + x0) * 3;
+    const uint8_t* p01 = f + ((size_t)y0 * W + x1) * 3;
+    const uint8_t* p10 = f + ((size_t)y1 * W + x0) * 3;
+    const uint8_t* p11 = f + ((size_t)y1 * W + x1) * 3;
+    uint8_t* o = scratch + ((((size_t)b * T + t) * SH + y) * SW + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      // to_tensor divides by 255 (a true division, not a multiplication by the reciprocal: the 8-bit cut below is sensitive to the last bit)
+      const float v = hy * (hx * ((float)p00[c] / 255.f) + lx * ((float)p01[c] / 255.f)) + ly * (hx * ((float)p10[c] / 255.f) + lx * ((float)p11[c] / 255.f));
+      o[c] = (uint8_t)(int)floorf(v * 255.f);
+    }
+  }
+}
+// exact per-clip sum of the luma of every pixel (for the clips whose op of this slot is contrast)
+__global__ __launch_bounds__(256) void luma_sum_kernel(const uint8_t* __restrict__ scratch, const int* __restrict__ params, const int* __restrict__ ops,
+                                                       int slot, unsigned long long* __restrict__ sums, int T, int SH, int SW, int blocks_per_clip) {
+  const int b = blockIdx.x / blocks_per_clip, part = blockIdx.x % blocks_per_clip;
+  if (ops[b * 4 + slot] != 1) return;
+  const int new_h = params[b * 6], new_w = params[b * 6 + 1];
+  const long n = (long)T * new_h * new_w;
+  unsigned long long acc = 0;
+  for (long i = (long)part * 256 + threadIdx.x; i < n; i += (long)blocks_per_clip * 256) {
+    const int x = (int)(i % new_w);
+    const long r = i / new_w;
+    const int y = (int)(r % new_h), t = (int)(r / new_h);
+    const uint8_t* px = scratch + ((((size_t)b * T + t) * SH + y) * SW + x) * 3;
+    acc += (unsigned long long)luma_u8(px[0], px[1], px[2]);
+  }
+  __shared__ unsigned long long sh[256];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) atomicAdd(&sums[b], sh[0]);               // integer atomics: exact, order-independent
+}
+// op ids: 0 brightness, 1 contrast, 2 saturation, 3 hue, < 0 none
+__global__ __launch_bounds__(256) void jitter_op_kernel(uint8_t* __restrict__ scratch, const int* __restrict__ params, const int* __restrict__ ops,
+                                                        const float* __restrict__ factors, int slot, const unsigned long long* __restrict__ sums,
+                                                        int T, int SH, int SW, long total) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int x = (int)(idx % SW);
+    long r = idx / SW;
+    const int y = (int)(r % SH); r /= SH;
+    const int t = (int)(r % T);
+    const int b = (int)(r / T);
+    const int op = ops[b * 4 + slot];
+    const int new_h = params[b * 6], new_w = params[b * 6 + 1];
+    if (op < 0 || y >= new_h || x >= new_w) continue;
+    const float f = factors[b * 4 + slot];
+    uint8_t* px = scratch + ((((size_t)b * T + t) * SH + y) * SW + x) * 3;
+    int R = px[0], G = px[1], B = px[2];
+    if (op == 0) { R = blend_u8(0, R, f); G = blend_u8(0, G, f); B = blend_u8(0, B, f); }
+    else if (op == 1) {
+      const double n = (double)T * (double)new_h * (double)new_w;
+      const int mean = (int)((double)sums[b] / n + 0.5);
+      R = blend_u8(mean, R, f); G = blend_u8(mean, G, f); B = blend_u8(mean, B, f);
+    } else if (op == 2) {
+      const int l = luma_u8(R, G, B);
+      R = blend_u8(l, R, f); G = blend_u8(l, G, f); B = blend_u8(l, B, f);
+    } else {
+      int uh, us, uv;
+      rgb2hsv_u8(R, G, B, uh, us, uv);
+      uh = (uh + (int)f) & 255;                                    // np_h += np.uint8(hue_factor * 255), 8-bit wrap-around: the caller passes the shift
+      hsv2rgb_u8(uh, us, uv, R, G, B);
+    }
+    px[0] = (uint8_t)R; px[1] = (uint8_t)G; px[2] = (uint8_t)B;
+  }
+}
+__global__ __launch_bounds__(256) void crop_norm_u8_kernel(const uint8_t* __restrict__ scratch, float* __restrict__ dst, const int* __restrict__ params,
+                                                           int T, int SH, int SW, int OH, int OW, float scale_pix, float m0, float m1, float m2,
+                                                           float is0, float is1, float is2, int reverse, long total) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int x = (int)(idx % OW);
+    long r = idx / OW;
+    const int y = (int)(r % OH); r /= OH;
+    const int t = (int)(r % T);
+    const int b = (int)(r / T);
+    const int ci = params[b * 6 + 3], cj = params[b * 6 + 4];
+    const uint8_t* px = scratch + ((((size_t)b * T + t) * SH + (y + ci)) * SW + (x + cj)) * 3;
+    float* o = dst + (((size_t)b * T + t) * 3) * (size_t)OH * OW + (size_t)y * OW + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = (float)px[reverse ? 2 - c : c] / 255.f;
+      const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), is = c == 0 ? is0 : (c == 1 ? is1 : is2);
+      o[(size_t)c * OH * OW] = (v * scale_pix - m) * is;
+    }
+  }
+}
+}  // namespace
+
+extern "C" size_t avt_video_jitter_scratch_bytes(int B, int T, int max_h, int max_w) { return (size_t)B * T * max_h * max_w * 3 + 256; }
+
+extern "C" int avt_video_preproc_jitter_u8(const void* src, float* dst, const int* params, const int* jitter_ops, const float* jitter_factors,
+                                           int B, int T, int H, int W, int OH, int OW, int max_h, int max_w, float scale_pix,
+                                           const float* mean3, const float* std3, int reverse_channels,
+                                           void* scratch, size_t scratch_bytes, unsigned long long* luma_sums, void* stream) {
+  AVT_CHECK(src && dst && params && jitter_ops && jitter_factors && mean3 && std3 && scratch && luma_sums, "avt_video_preproc_jitter_u8: null argument");
+  AVT_CHECK(B > 0 && T > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && max_h >= OH && max_w >= OW, "avt_video_preproc_jitter_u8: bad shape");
+  AVT_CHECK(scratch_bytes >= (size_t)B * T * max_h * max_w * 3, "avt_video_preproc_jitter_u8: scratch too small (%zu bytes needed)", (size_t)B * T * max_h * max_w * 3);
+  AVT_CHECK(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "avt_video_preproc_jitter_u8: zero std");
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)B * T * max_h * max_w;
+  long g = (total + 255) / 256; if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(resize_flip_u8_kernel, dim3((int)g), dim3(256), 0, s, (const uint8_t*)src, (uint8_t*)scratch, params, T, H, W, max_h, max_w, total);
+  for (int slot = 0; slot < 4; ++slot) {
+    (void)hipMemsetAsync(luma_sums, 0, (size_t)B * sizeof(unsigned long long), s);
+    const int bpc = 64;
+    hipLaunchKernelGGL(luma_sum_kernel, dim3(B * bpc), dim3(256), 0, s, (const uint8_t*)scratch, params, jitter_ops, slot, luma_sums, T, max_h, max_w, bpc);
+    hipLaunchKernelGGL(jitter_op_kernel, dim3((int)g), dim3(256), 0, s, (uint8_t*)scratch, params, jitter_ops, jitter_factors, slot, luma_sums, T, max_h, max_w, total);
+  }
+  const long tot_out = (long)B * T * OH * OW;
+  long g2 = (tot_out + 255) / 256; if (g2 > 16384) g2 = 16384;
+  hipLaunchKernelGGL(crop_norm_u8_kernel, dim3((int)g2), dim3(256), 0, s, (const uint8_t*)scratch, dst, params, T, max_h, max_w, OH, OW, scale_pix,
+                     mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2], reverse_channels, tot_out);
+  AVT_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
 }  // namespace
 
 extern "C" int avt_video_preproc_u8(const void* src, float* dst, const int* params, int B, int T, int H, int W, int OH, int OW,

@@ -47,6 +47,7 @@ SIGNATURES = {
     'avt_cls_attn_bwd': [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     'avt_causal_attn_decode': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     'avt_video_preproc_u8': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P],
+    'avt_video_preproc_jitter_u8': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P, _SZ, _P, _P],
     'avt_xent_fwd': [_P, _I, _P, _P, _P, _P, _I, _I, _L, _P],
     'avt_xent_bwd': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _L, _P],
     'avt_sgd_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _I, _I, _P],
@@ -66,6 +67,7 @@ SIZE_QUERIES = {
     'avt_vit_attn_bwd_workspace_bytes': [_I, _I, _I],
     'avt_patch_embed_bwd_reduce_workspace_bytes': [_I, _I, _I],
     'avt_colsum_workspace_bytes': [_I, _I],
+    'avt_video_jitter_scratch_bytes': [_I, _I, _I, _I],
 }
 
 

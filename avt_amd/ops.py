@@ -424,6 +424,29 @@ def video_preproc(src_u8, params, out_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), s
     return out
 
 
+def video_preproc_jitter(src_u8, params, jitter_ops, jitter_factors, out_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5),
+                         reverse_channels=False):
+    """video_preproc with ColorJitterVideo: jitter_ops int32 (Bout, 4) in application order (0 brightness, 1 contrast, 2 saturation, 3 hue,
+    -1 none), jitter_factors fp32 (Bout, 4) (hue: the 8-bit shift).  The resized clips go through an 8-bit scratch buffer."""
+    import ctypes
+    _chk(src_u8, torch.uint8, 'src'); _chk(params, torch.int32, 'params'); _chk(jitter_ops, torch.int32, 'jitter_ops'); _chk(jitter_factors, torch.float32, 'jitter_factors')
+    assert src_u8.dim() == 5 and src_u8.size(-1) == 3 and src_u8.is_contiguous() and params.is_contiguous()
+    _, T, H, W, _ = src_u8.shape
+    OH, OW = out_hw
+    B = params.size(0)
+    assert params.shape == (B, 6) and jitter_ops.shape == (B, 4) and jitter_factors.shape == (B, 4)
+    hw = params[:, :2].max(dim=0).values.tolist()                   # one small device -> host read: the scratch pitch
+    max_h, max_w = int(hw[0]), int(hw[1])
+    scratch = torch.empty(_lib.load().avt_video_jitter_scratch_bytes(B, T, max_h, max_w), device=src_u8.device, dtype=torch.uint8)
+    sums = torch.zeros(B, device=src_u8.device, dtype=torch.int64)
+    out = torch.empty((B, T, 3, 1, OH, OW), device=src_u8.device, dtype=torch.float32)
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    _lib.call('avt_video_preproc_jitter_u8', _p(src_u8), _p(out), _p(params), _p(jitter_ops.contiguous()), _p(jitter_factors.contiguous()), B, T, H, W,
+              OH, OW, max_h, max_w, float(scale_pix), ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p), int(reverse_channels),
+              _p(scratch), scratch.numel(), _p(sums), _stream())
+    return out
+
+
 # ---- cross entropy ---------------------------------------------------------------------------------------------------------
 def xent_fwd(logits, target, C, ignore_index=-1):
     """logits fp32 [R, ld>=C]; returns (loss[R], lse[R], rank[R])."""

@@ -188,6 +188,19 @@ int avt_video_preproc_u8(const void* src, float* dst, const int* params, int B, 
                          float scale_pix, const float* mean3, const float* std3, int reverse_channels, int quantize_u8,
                          void* stream);
 
+/* The same chain with NON-ZERO colour jitter (ColorJitterVideo, common/transforms.py:399-421, around torchvision 0.8.2's ColorJitter on a
+ * PIL image): resize + flip -> 8-bit clip (the wrapper's to_pil_image) -> up to four in-place Pillow operations per clip, in the order
+ * and with the factors the caller drew -> / 255 -> scale -> (reverse) -> normalise -> crop.  jitter_ops: int32 [B][4], application order,
+ * 0 brightness | 1 contrast | 2 saturation (ImageEnhance = Image.blend with black | the clip's mean grey | the pixel's grey) | 3 hue
+ * (8-bit HSV round trip) | -1 none; jitter_factors: fp32 [B][4], the blend factor, or for hue the 8-bit shift (int)(hue_factor * 255) & 255.
+ * max_h / max_w >= every clip's new_h / new_w: pitch of the 8-bit `scratch` (avt_video_jitter_scratch_bytes); luma_sums: B x uint64 scratch.
+ * Bit-exact against Pillow (tests/golden/g11_color_jitter.npz, generated through the reference's own wrapper). */
+int avt_video_preproc_jitter_u8(const void* src, float* dst, const int* params, const int* jitter_ops, const float* jitter_factors,
+                                int B, int T, int H, int W, int OH, int OW, int max_h, int max_w, float scale_pix,
+                                const float* mean3, const float* std3, int reverse_channels,
+                                void* scratch, size_t scratch_bytes, unsigned long long* luma_sums, void* stream);
+size_t avt_video_jitter_scratch_bytes(int B, int T, int max_h, int max_w);
+
 /* ---- softmax cross-entropy -------------------------------------------------------------------------------------------
  * loss_fn/multidim_xentropy.py:11-25 (CrossEntropyLoss(ignore_index=-1, reduction='none')) + common/utils.py:17-44.
  * logits fp32 [R, ld], C valid columns; target int64 [R]; loss/lse fp32 [R]; rank int32 [R] (#logits > target logit,

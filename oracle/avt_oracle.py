@@ -15,6 +15,8 @@ State-dict names and shapes are identical to the reference's (timm naming under 
 HF naming under ``future_predictor.gpt_model.`` with Conv1D weights stored (in, out)).
 """
 import math
+
+import numpy as np
 from typing import Dict, Optional
 
 import torch
@@ -420,8 +422,87 @@ def resize_shape(clip_h, clip_w, target):
     return max(int(clip_h * scale), target), max(int(clip_w * scale), target)
 
 
+# ---- ColorJitterVideo with non-zero strengths (common/transforms.py:399-421) --------------------------------------------------
+# The reference hands the flipped, resized clip -- all frames stacked into ONE tall 8-bit image -- to torchvision's ColorJitter
+# (torchvision 0.8.2, env.yaml:305: absent from /root/reference and from this image).  On a PIL image that class applies, in a random
+# order (``torch.randperm(4)``) and with factors drawn by ``torch.tensor(1.0).uniform_(lo, hi)``, four Pillow operations
+# (torchvision/transforms/functional_pil.py of 0.8.2): ImageEnhance.Brightness / Contrast / Color (= Image.blend(degenerate, image, factor)
+# with degenerate = black | the mean grey of the WHOLE stacked image | the pixel's own grey) and a hue shift on Pillow's 8-bit HSV form.
+# They are restated below on uint8 arrays, following Pillow's C code (Blend.c, Convert.c: rgb2l, rgb2hsv_row, hsv2rgb_row) and pinned
+# against the installed Pillow itself (oracle/make_golden_r3.py: max difference 0 on random images and factors; Pillow 12.2.0).
+JITTER_OPS = ('brightness', 'contrast', 'saturation', 'hue')
+
+
+def pil_luma(rgb):
+    """Pillow RGB -> L (ITU-R 601-2, integer form): (19595 R + 38470 G + 7471 B + 0x8000) >> 16."""
+    r, g, b = (rgb[..., i].astype(np.uint32) for i in range(3))
+    return ((r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16).astype(np.uint8)
+
+
+def pil_blend(degenerate, image, factor):
+    """Image.blend(degenerate, image, factor) (Blend.c): float32 arithmetic; truncation inside [0, 1], clipping outside."""
+    d, im = degenerate.astype(np.int32), image.astype(np.int32)
+    t = (d.astype(np.float32) + np.float32(factor) * (im - d).astype(np.float32)).astype(np.float32)
+    if 0.0 <= factor <= 1.0:
+        return t.astype(np.int32).astype(np.uint8)
+    return np.where(t <= 0, 0, np.where(t >= 255, 255, t.astype(np.int32))).astype(np.uint8)
+
+
+def pil_rgb2hsv(rgb):
+    """Convert.c rgb2hsv_row: float32 ratios, the hue expression in double (its literals are doubles), 8-bit truncation."""
+    r, g, b = (rgb[..., i].astype(np.float32) for i in range(3))
+    maxc, minc = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    cr = maxc - minc
+    with np.errstate(divide='ignore', invalid='ignore'):
+        s = cr / maxc
+        rc, gc, bc = ((maxc - c) / cr for c in (r, g, b))
+        rc64, gc64, bc64 = rc.astype(np.float64), gc.astype(np.float64), bc.astype(np.float64)
+        h = np.where(r == maxc, (bc - gc).astype(np.float64), np.where(g == maxc, 2.0 + rc64 - bc64, 4.0 + gc64 - rc64)).astype(np.float32)
+        h = np.fmod(h.astype(np.float64) / 6.0 + 1.0, 1.0).astype(np.float32)
+        uh = np.clip(np.nan_to_num(h.astype(np.float64) * 255.0).astype(np.int32), 0, 255)
+        us = np.clip(np.nan_to_num(s.astype(np.float64) * 255.0).astype(np.int32), 0, 255)
+    grey = cr == 0
+    return np.stack([np.where(grey, 0, uh), np.where(grey, 0, us), maxc.astype(np.int32)], -1).astype(np.uint8)
+
+
+def pil_hsv2rgb(hsv):
+    """Convert.c hsv2rgb_row: sextant i = floor(6 h / 255), p / q / t rounded to nearest."""
+    h = hsv[..., 0].astype(np.float32) * np.float32(6.0) / np.float32(255.0)
+    fs = hsv[..., 1].astype(np.float32) / np.float32(255.0)
+    v = hsv[..., 2].astype(np.int32)
+    i = np.floor(h).astype(np.int32)
+    f = h - i.astype(np.float32)
+    fv = v.astype(np.float32)
+    rnd = lambda x: np.clip(np.round(x).astype(np.int32), 0, 255)
+    pp, q, t = rnd(fv * (1 - fs)), rnd(fv * (1 - fs * f)), rnd(fv * (1 - fs * (1 - f)))
+    i = i % 6
+    out = np.stack([np.choose(i, [v, q, pp, pp, t, v]), np.choose(i, [t, v, v, q, pp, pp]), np.choose(i, [pp, pp, t, v, v, q])], -1)
+    return np.where((hsv[..., 1] == 0)[..., None], np.repeat(v[..., None], 3, -1), out).astype(np.uint8)
+
+
+def pil_color_jitter(img_u8, ops):
+    """img_u8: uint8 (H, W, 3), the stacked clip; ops: [(name, factor)] in application order (names of JITTER_OPS)."""
+    img = np.ascontiguousarray(img_u8)
+    for name, factor in ops:
+        factor = float(factor)
+        if name == 'brightness':
+            img = pil_blend(np.zeros_like(img), img, factor)
+        elif name == 'contrast':
+            mean = int(pil_luma(img).astype(np.float64).mean() + 0.5)            # ImageStat.Stat(image.convert('L')).mean[0], rounded
+            img = pil_blend(np.full_like(img, mean), img, factor)
+        elif name == 'saturation':
+            img = pil_blend(np.repeat(pil_luma(img)[..., None], 3, -1), img, factor)
+        elif name == 'hue':                                                      # functional_pil.adjust_hue: np_h += np.uint8(hue_factor * 255)
+            hsv = pil_rgb2hsv(img)
+            hsv[..., 0] = (hsv[..., 0].astype(np.int32) + (int(factor * 255) & 255)) & 255
+            img = pil_hsv2rgb(hsv)
+        else:
+            raise ValueError(name)
+    return img
+
+
 def video_preproc(clip_u8, new_hw, flip, crop_ij, crop_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5),
-                  reverse_channels=False, color_jitter_roundtrip=False):
+                  reverse_channels=False, color_jitter_roundtrip=False, color_jitter_ops=None):
     """One clip through the reference's training / eval transform chain with the random draws given explicitly.
     clip_u8: uint8 (T, H, W, 3) -> float (3, T, h, w).
     color_jitter_roundtrip: the training chain's ColorJitterVideo (func/train.py:554-557, common/transforms.py:399-421) with all
@@ -432,7 +513,11 @@ def video_preproc(clip_u8, new_hw, flip, crop_ij, crop_hw, scale_pix=1.0, mean=(
     x = F.interpolate(x, size=tuple(new_hw), mode='bilinear')                    # resize, :60-91 (align_corners = None -> False)
     if flip:
         x = x.flip((-1,))                                                        # hflip, :167-175
-    if color_jitter_roundtrip:
+    if color_jitter_ops:                                                         # ColorJitterVideo, :399-421: frames stacked on the height axis
+        c, t, h, w = x.shape
+        stacked = x.mul(255).byte().permute(1, 2, 3, 0).reshape(t * h, w, c).numpy()          # to_pil_image: mul(255).byte()
+        x = torch.from_numpy(pil_color_jitter(stacked, color_jitter_ops)).view(t, h, w, c).permute(3, 0, 1, 2).float().div(255)
+    elif color_jitter_roundtrip:
         x = x.mul(255).byte().float().div(255)                                   # ColorJitterVideo with zero strengths, :417-421
     x = x * scale_pix                                                            # func/train.py:559-560
     if reverse_channels:

@@ -320,5 +320,18 @@ def test_gpu_clip_transform_draws_follow_the_reference_rules():
     mc = GpuClipTransform(248, -1, 224, train=False, eval_num_crops=3, eval_flip_crops=True).eval_crops(256, 456)
     assert mc == [(248, 441, 0, 0, 0), (248, 441, 0, 12, 108), (248, 441, 0, 24, 217),
                   (248, 441, 1, 0, 217), (248, 441, 1, 12, 109), (248, 441, 1, 24, 0)]
-    with pytest.raises(NotImplementedError):
-        GpuClipTransform(248, color_jitter_hue=0.1)
+    # ColorJitterVideo draws (torchvision 0.8.2 ColorJitter.get_params): a permutation of the active operations, factors in
+    # [max(0, 1 - s), 1 + s] (hue: [-s, s]); inactive operations (strength 0) are left out; evaluation never jitters
+    cj = GpuClipTransform(248, -1, 224, train=True, color_jitter_brightness=0.4, color_jitter_contrast=1.5, color_jitter_hue=0.1)
+    orders = set()
+    for _ in range(40):
+        ops_ = cj.draw_jitter()
+        assert sorted(o for o, _ in ops_) == [0, 1, 3]
+        f = dict(ops_)
+        assert 0.6 <= f[0] <= 1.4 and 0.0 <= f[1] <= 2.5 and -0.1 <= f[3] <= 0.1
+        orders.add(tuple(o for o, _ in ops_))
+    assert len(orders) > 2
+    assert GpuClipTransform(248, -1, 224, train=True).draw_jitter() == []
+    assert GpuClipTransform(248, -1, 224, train=False, color_jitter_hue=0.1).draw_jitter() == []
+    with pytest.raises(ValueError):
+        GpuClipTransform(248, -1, 224, train=True, color_jitter_hue=0.7)

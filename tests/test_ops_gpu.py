@@ -730,3 +730,39 @@ def test_linear_cross_entropy_fused_operator_vs_torch():
         assert float((rank[ok] - fp32_rank[ok]).abs().float().mean()) < 0.01 * C           # bf16 operands swap near-ties among thousands of classes
         assert bool((rank[~ok] == -1).all())
         assert relerr(m.weight.grad, wr.grad) < 3e-2 and relerr(m.bias.grad, br.grad) < 3e-2 and relerr(x.grad, xr.grad) < 3e-2
+
+
+def test_video_preproc_with_color_jitter_vs_reference_golden(golden_dir):
+    """G11: the reference's ColorJitterVideo wrapper (common/transforms.py:399-421) inside its transform chain, with torchvision 0.8.2's
+    ColorJitter executed by the real Pillow (brightness / contrast / saturation / hue in three different orders): the three-stage GPU
+    chain must reproduce the 8-bit operations EXACTLY (the only float work left is / 255, normalise: 1e-6)."""
+    import os
+    import numpy as np
+    from avt_amd.common.gpu_transforms import GpuClipTransform
+    g = np.load(os.path.join(golden_dir, 'g11_color_jitter.npz'))
+    clips = torch.from_numpy(g['clips']).cuda()
+    names = ('brightness', 'contrast', 'saturation', 'hue')
+    tf = GpuClipTransform(56, -1, 48, tuple(g['mean']), tuple(g['std']), train=True)
+    params = [tuple(int(v) for v in row) for row in g['params']]
+    jitter = [[(names[int(i)], float(f)) for i, f in zip(ids, fs) if i >= 0] for ids, fs in zip(g['op_ids'], g['op_factors'])]
+    out = tf(clips, params=params, jitter=jitter)                                   # (B, T, 3, 1, h, w)
+    ref = torch.from_numpy(g['out']).permute(0, 2, 1, 3, 4).unsqueeze(3)            # (B, C, T, h, w) -> (B, T, C, 1, h, w)
+    assert out.shape == ref.shape
+    d = (out.cpu() - ref).abs()
+    # clip 3 has identity geometry (the resize returns the 8-bit pixels themselves): its four Pillow operations must come out EXACTLY
+    assert float(d[3].max()) < 2e-6, float(d[3].max())
+    # clips 0-2 are resized: the bilinear weights are combined in a different association order than torch's CPU kernel, so a pixel within
+    # rounding of an integer level may enter the jitter one 8-bit level off (same caveat as the zero-strength round trip above)
+    lvl = 1.0 / 255 / float(min(g['std']))
+    assert float(d[:3].max()) < 6 * lvl and float((d[:3] > 2e-5).float().mean()) < 2e-3, (float(d[:3].max()), float((d[:3] > 2e-5).float().mean()))
+    # the drawn path: strengths set -> every clip gets between one and four operations, reproducibly under a torch seed
+    tf2 = GpuClipTransform(56, -1, 48, tuple(g['mean']), tuple(g['std']), train=True, color_jitter_brightness=0.4, color_jitter_contrast=0.4,
+                           color_jitter_saturation=0.4, color_jitter_hue=0.1)
+    torch.manual_seed(7); import random; random.seed(7)
+    a = tf2(clips)
+    torch.manual_seed(7); random.seed(7)
+    b = tf2(clips)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    plain = GpuClipTransform(56, -1, 48, tuple(g['mean']), tuple(g['std']), train=True)
+    torch.manual_seed(7); random.seed(7)
+    assert float((plain(clips) - a).abs().max()) > 1e-2                              # the jitter does something

@@ -244,3 +244,16 @@ def test_g10_transformer_aggregator(golden_dir):
     params = dict(orc.named_parameters())
     for k in [k for k in g if k.startswith('grad/') and k != 'grad/feats']:
         assert rel(params[k[5:]].grad, g[k]) < 1e-4, k
+
+
+def test_g11_color_jitter_chain(golden_dir):
+    """The oracle's restatement of ColorJitterVideo + torchvision 0.8.2 ColorJitter on Pillow images (oracle.pil_color_jitter) inside the
+    transform chain, against the golden generated through the reference's own wrapper with the real Pillow: exact."""
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, 'g11_color_jitter.npz'))
+    clips = torch.from_numpy(g['clips'])
+    for b in range(clips.size(0)):
+        nh, nw, flip, ci, cj = (int(v) for v in g['params'][b])
+        ops_b = [(O.JITTER_OPS[int(i)], float(f)) for i, f in zip(g['op_ids'][b], g['op_factors'][b]) if i >= 0]
+        mine = O.video_preproc(clips[b], (nh, nw), flip, (ci, cj), (48, 48), 1.0, tuple(g['mean']), tuple(g['std']), False, color_jitter_ops=ops_b)
+        assert float((mine - torch.from_numpy(g['out'][b])).abs().max()) < 1e-6, b
