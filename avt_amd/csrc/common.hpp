@@ -130,12 +130,21 @@ __device__ __forceinline__ float wave_max(float v) {
 // hipcc cannot tell that __builtin_amdgcn_ds_read_tr16_b64 does not alias LDS-DMA (buffer_load ... lds) transfers still in flight
 // and puts s_waitcnt vmcnt(0) in front of it; kernels that prefetch by LDS-DMA and place their own waits use this form instead.
 // `addr` = the lane's LDS byte address, OFF = compile-time offset.  The result may only be used after an explicit s_waitcnt lgkmcnt.
+// The two registers come back as 32-bit words and a fragment is put together from two reads with 32-bit vector operations only
+// (tr_join: a register sequence, no instruction).  Going through 16-bit element vectors (a union with short4) made hipcc emit one
+// `v_bfi_b32 d, 0xffff, s, s` per register to "merge" the halves -- 32 vector instructions per K-loop trip of the weight-gradient kernel,
+// placed BEFORE the hand-written wait, i.e. reading registers whose LDS data the compiler had no reason to believe outstanding
+// (tools/isa_async_check.py scans the generated ISA for exactly that).
 template <int OFF>
-__device__ __forceinline__ s16x4_t ds_read_tr_na(uint32_t addr) {
+__device__ __forceinline__ u32x2_t ds_read_tr_na(uint32_t addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds_read immediate offset");
-  s16x4_t v;
+  u32x2_t v;
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
+}
+__device__ __forceinline__ bf16x8_t tr_join(u32x2_t lo, u32x2_t hi) {
+  const u32x4_t w = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8_t, w);
 }
 __device__ __forceinline__ uint32_t lds_addr32(const char* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 

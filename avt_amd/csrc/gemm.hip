@@ -189,10 +189,8 @@ __device__ __forceinline__ bf16x8_t frag_kstrided_na(const char* lds_tile, int t
   const int r = ks * 16 + (g >> 1) * 8 + (i16 >> 2);
   const int c = (col >> 3) ^ kstrided_swz<BR>(r);
   const uint32_t a = lds_addr32(lds_tile + r * (BR * 2) + c * 16 + (col & 7) * 2);
-  union { bf16x8_t v; s16x4_t h[2]; } u;
-  u.h[0] = ds_read_tr_na<0>(a);
-  u.h[1] = ds_read_tr_na<4 * BR * 2>(a);
-  return u.v;
+  const u32x2_t lo = ds_read_tr_na<0>(a), hi = ds_read_tr_na<4 * BR * 2>(a);
+  return tr_join(lo, hi);
 }
 // wait until at most N of this wave's LDS operations are outstanding, then pass the fragments through an empty statement so
 // that no MFMA reading them can be scheduled above the wait
@@ -215,14 +213,14 @@ template <int OFF>
 __device__ __forceinline__ void frag4_tr_na(bf16x8_t (&f)[4], uint32_t addr) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    union { bf16x8_t v; s16x4_t h[2]; } u;
+    u32x2_t lo, hi;
     switch (ks) {             // compile-time immediates
-      case 0: u.h[0] = ds_read_tr_na<OFF>(addr); u.h[1] = ds_read_tr_na<OFF + 4 * 256>(addr); break;
-      case 1: u.h[0] = ds_read_tr_na<OFF + 16 * 256>(addr); u.h[1] = ds_read_tr_na<OFF + 20 * 256>(addr); break;
-      case 2: u.h[0] = ds_read_tr_na<OFF + 32 * 256>(addr); u.h[1] = ds_read_tr_na<OFF + 36 * 256>(addr); break;
-      default: u.h[0] = ds_read_tr_na<OFF + 48 * 256>(addr); u.h[1] = ds_read_tr_na<OFF + 52 * 256>(addr); break;
+      case 0: lo = ds_read_tr_na<OFF>(addr); hi = ds_read_tr_na<OFF + 4 * 256>(addr); break;
+      case 1: lo = ds_read_tr_na<OFF + 16 * 256>(addr); hi = ds_read_tr_na<OFF + 20 * 256>(addr); break;
+      case 2: lo = ds_read_tr_na<OFF + 32 * 256>(addr); hi = ds_read_tr_na<OFF + 36 * 256>(addr); break;
+      default: lo = ds_read_tr_na<OFF + 48 * 256>(addr); hi = ds_read_tr_na<OFF + 52 * 256>(addr); break;
     }
-    f[ks] = u.v;
+    f[ks] = tr_join(lo, hi);
   }
 }
 // De-synchronise the chip: all CUs start together and would otherwise hit their output-store tails together (a burst at
@@ -2036,10 +2034,10 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
 #define W4_RDF(NB, SLOT, KS, F)                                                                                       \
   do {                                                                                                                \
     constexpr int imm_ = ((SLOT) & 1) * STAGE + (KS) * 16 * ROWB;                                                     \
-    union { bf16x8_t v; s16x4_t h[2]; } u_;                                                                           \
     const uint32_t a_ = ((F) == 0) ? adA[(SLOT) >> 1][0] : ((F) <= 4 ? adB[(SLOT) >> 1][(F) - 1] : adA[(SLOT) >> 1][(F) - 4]);  \
-    u_.h[0] = ds_read_tr_na<imm_>(a_); u_.h[1] = ds_read_tr_na<imm_ + 4 * ROWB>(a_);     /* inline asm: no compiler-placed vmcnt(0) */ \
-    if ((F) == 0) af[NB][0] = u_.v; else if ((F) <= 4) bfr[NB][(F) - 1] = u_.v; else af[NB][(F) - 4] = u_.v;          \
+    const u32x2_t lo_ = ds_read_tr_na<imm_>(a_), hi_ = ds_read_tr_na<imm_ + 4 * ROWB>(a_);   /* inline asm: no compiler-placed vmcnt(0) */ \
+    const bf16x8_t v_ = tr_join(lo_, hi_);                                                                            \
+    if ((F) == 0) af[NB][0] = v_; else if ((F) <= 4) bfr[NB][(F) - 1] = v_; else af[NB][(F) - 4] = v_;                \
   } while (0)
   // 16 MFMAs of buffer CB; between them the 8 fragments of (SLOT, KS) into buffer NB and the DMA instructions Q0..Q0+3 of stage ST
 #define W4_STEP(CB, NB, SLOT, KS, Q0, ST, READ)                                                                       \

@@ -123,10 +123,8 @@ __device__ __forceinline__ void tr_lane_offsets(int lane, uint32_t (&off)[4]) {
 // fragment (dt, t) of the tile at byte offset TILE from the address the offsets were added to: rows 32t + 16h + ...
 template <int TILE, int T>
 __device__ __forceinline__ bf16x8_t frag_tr_na(uint32_t addr) {
-  union { bf16x8_t v; s16x4_t h[2]; } u;
-  u.h[0] = ds_read_tr_na<TILE + T * 4096>(addr);
-  u.h[1] = ds_read_tr_na<TILE + T * 4096 + 2048>(addr);
-  return u.v;
+  const u32x2_t lo = ds_read_tr_na<TILE + T * 4096>(addr), hi = ds_read_tr_na<TILE + T * 4096 + 2048>(addr);
+  return tr_join(lo, hi);
 }
 // the four dt fragments of key / query pair t (t is a loop index of an unrolled loop: dispatched to the immediate forms)
 template <int TILE, int NP>
@@ -163,6 +161,24 @@ __device__ __forceinline__ float lsum16(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
   return v;
+}
+
+// four such sums at once, written out: hipcc folds the rotate into the add (v_add_f32_dpp) only sometimes, else it emits a DPP move, a
+// zero and an add per step.  The four independent chains also fill the two wait states a DPP read needs after the write of its source.
+__device__ __forceinline__ void lsum16x4(f32x4_t& v) {
+  float a = v[0], b = v[1], c = v[2], d = v[3];
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_ror:2 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 row_ror:1 row_mask:0xf bank_mask:0xf"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  v = (f32x4_t){a, b, c, d};
 }
 
 // Forward: persistent workgroups walking over (frame, head) items with the K / V tiles double-buffered in LDS: the tiles of
@@ -360,8 +376,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
     // a wave may have skipped them and the count would be wrong -> wait for everything)
     if (ALL_LIVE) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // barrier 1
-    if (dbias && prev_head >= 0) {                         // dk | dv sums of the previous item, in wave order
-      for (int c = 64 + tid; c < 192; c += nthr) {
+    if (dbias && prev_head >= 0) {                         // dv sums of the previous item, in wave order (the dk sums are zero)
+      for (int c = 128 + tid; c < 192; c += nthr) {
         float t = bias_s[prev_head * 192 + c];
 #pragma unroll
         for (int w = 0; w < NKT; ++w) t += stage_s[w * 192 + c];
@@ -427,12 +443,16 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
           u32x2_t w; w[0] = pack2bf(acc[dt][0], acc[dt][1]); w[1] = pack2bf(acc[dt][2], acc[dt][3]);
           *(u32x2_t*)(dbase + (size_t)q * ld + dt * 16 + 4 * g) = w;
         }
-        if (dbias) {
+      }
+      if (dbias) {
+        // q part of the qkv-bias gradient: sums over the strip's 16 queries = the 16 lanes of a DPP row (queries past the end of the
+        // sequence have all-zero Q / dO / O strips, hence dS = 0 and dQ = 0 exactly: no mask); one 16-byte store per (dt, g)
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // the accumulators come out of the matrix pipe (the assembly below is opaque to the hazard recogniser)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = lsum16((q < S) ? acc[dt][r] : 0.f);
-            if ((lane & 15) == 0) stage_s[wave * 192 + dt * 16 + 4 * g + r] = v;
-          }
+        for (int dt = 0; dt < 4; ++dt) lsum16x4(acc[dt]);
+        if ((lane & 15) == 0) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) *(f32x4_t*)(stage_s + wave * 192 + dt * 16 + 4 * g) = acc[dt];
         }
       }
     }
@@ -513,13 +533,32 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
           u32x2_t x; x[0] = pack2bf(adv[dt][0], adv[dt][1]); x[1] = pack2bf(adv[dt][2], adv[dt][3]);
           *(u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g) = x;
         }
-        if (dbias) {
+      }
+      // qkv-bias gradient, k and v parts, without the 2 x 64 cross-lane sums per wave the accumulators would need:
+      //   colsum(dK) = sum_q (sum_k dS[q,k]) Q[q] = 0 exactly (every row of dS sums to zero): nothing is added;
+      //   colsum(dV) = sum_k sum_q P[q,k] dO[q] = sum_q dO[q] (every row of P sums to one): wave t < NP takes the 32 queries of pair t
+      //   from the dO tile as one more product with an all-ones B operand (4 MFMAs per item instead of 64 DPP adds per wave).
+      if (dbias) {
+        f32x4_t cs[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float vk = lsum16((key < S) ? adk[dt][r] : 0.f);
-            float vv = lsum16((key < S) ? adv[dt][r] : 0.f);
-            if ((lane & 15) == 0) { stage_s[wave * 192 + 64 + dt * 16 + 4 * g + r] = vk; stage_s[wave * 192 + 128 + dt * 16 + 4 * g + r] = vv; }
-          }
+        for (int dt = 0; dt < 4; ++dt) cs[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (wv < NP) {
+          constexpr bool HI = 3 * RM + (NP - 1) * 4096 + 2048 >= 65536;
+          bf16x8_t tf[4];
+          frag4_tr_na<HI ? 3 * RM - 65536 : 3 * RM, NP>(tf, HI ? tr1 : tr0, wv);
+          lgkm_wait4(tf[0], tf[1], tf[2], tf[3]);
+          union { bf16x8_t v; uint32_t w[4]; } ones;
+          ones.w[0] = ones.w[1] = ones.w[2] = ones.w[3] = 0x3F803F80u;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) cs[dt] = mfma16(tf[dt], ones.v, cs[dt]);
+        }
+        // the sums go from the matrix pipe straight to LDS stores behind a branch: keep the 11 wait states an 8-pass MFMA result
+        // needs before a memory instruction reads it explicit (measured: without them the last block of 16 sums was occasionally garbage
+        // in the 4-wave instantiation, where the sums live in AGPRs)
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]));
+        if ((lane & 15) == 0) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) *(f32x4_t*)(stage_s + wave * 192 + 128 + dt * 16 + 4 * g) = cs[dt];
         }
       }
     }
@@ -529,7 +568,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
   if (dbias) {
     __syncthreads();
     if (prev_head >= 0) {
-      for (int c = 64 + tid; c < 192; c += nthr) {
+      for (int c = 128 + tid; c < 192; c += nthr) {
         float t = bias_s[prev_head * 192 + c];
 #pragma unroll
         for (int w = 0; w < NKT; ++w) t += stage_s[w * 192 + c];
