@@ -74,11 +74,16 @@ __device__ __forceinline__ void gelu_erf_both(float x, float& y, float& dy) {
 // the density term of the derivative.  Working in x^2 directly (coefficients rescaled, the 1/sqrt 2 and the 1/2 folded in) takes
 // 8 vector instructions per 4 elements off the round-2 form (z = x / sqrt 2, z^2, z P, * 1/2 + 1/2): the epilogue is bound by
 // the vector-ALU issue rate (profiles/r03_issue_rules.txt), where one exponential costs 1.5 packed FMAs.
-__device__ __forceinline__ void gelu_erf_both2(f32x2_t x, f32x2_t& y, f32x2_t& dy) {
-  f32x2_t xc;
-  xc[0] = __builtin_amdgcn_fmed3f(x[0], -4.242640687f, 4.242640687f); xc[1] = __builtin_amdgcn_fmed3f(x[1], -4.242640687f, 4.242640687f);
-  const f32x2_t u = xc * xc;                                          // = min(x^2, 18)
-  f32x2_t pl = u * 5.626728078e-11f + -5.371838974e-09f;
+// Two pairs at once, written on 4-vectors: every step becomes two INDEPENDENT packed instructions, so the two Horner chains interleave.
+// With one pair per call hipcc ran the chains one after the other and every v_pk_fma_f32 waited on its predecessor (an `s_nop` between
+// each two: 151 per 32-row block of the epilogue).
+__device__ __forceinline__ void gelu_erf_both4(f32x2_t& x0, f32x2_t& x1, f32x2_t& d0, f32x2_t& d1) {
+  const f32x4_t x = {x0[0], x0[1], x1[0], x1[1]};
+  f32x4_t xc;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) xc[k] = __builtin_amdgcn_fmed3f(x[k], -4.242640687f, 4.242640687f);
+  const f32x4_t u = xc * xc;
+  f32x4_t pl = u * 5.626728078e-11f + -5.371838974e-09f;
   pl = pl * u + 2.268286700e-07f;
   pl = pl * u + -5.646199191e-06f;
   pl = pl * u + 9.359048303e-05f;
@@ -86,11 +91,18 @@ __device__ __forceinline__ void gelu_erf_both2(f32x2_t x, f32x2_t& y, f32x2_t& d
   pl = pl * u + 9.818116925e-03f;
   pl = pl * u + -6.634692091e-02f;
   pl = pl * u + 3.989031466e-01f;
-  const f32x2_t cdf = xc * pl + 0.5f;
-  const f32x2_t a = u * -0.7213475204444817f;                         // exp(-x^2/2) = 2^a
-  f32x2_t ex; ex[0] = __builtin_amdgcn_exp2f(a[0]); ex[1] = __builtin_amdgcn_exp2f(a[1]);
-  y = x * cdf;
-  dy = x * 0.3989422804014327f * ex + cdf;
+  const f32x4_t cdf = xc * pl + 0.5f;
+  f32x2_t kexp = {-0.7213475204444817f, -0.7213475204444817f};          // opaque scalar pairs: with a literal hipcc multiplies element by element
+  f32x2_t kphi = {0.3989422804014327f, 0.3989422804014327f};
+  asm("" : "+s"(kexp), "+s"(kphi));
+  const f32x2_t a0 = (f32x2_t){u[0], u[1]} * kexp, a1 = (f32x2_t){u[2], u[3]} * kexp;     // exp(-x^2/2) = 2^a
+  const f32x4_t a = {a0[0], a0[1], a1[0], a1[1]};
+  f32x4_t ex;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ex[k] = __builtin_amdgcn_exp2f(a[k]);
+  const f32x2_t c0 = {cdf[0], cdf[1]}, c1 = {cdf[2], cdf[3]}, e0 = {ex[0], ex[1]}, e1 = {ex[2], ex[3]};
+  d0 = (x0 * kphi) * e0 + c0; d1 = (x1 * kphi) * e1 + c1;
+  x0 = x0 * c0; x1 = x1 * c1;
 }
 __device__ __forceinline__ void gelu_tanh_both(float x, float& y, float& dy) {
   float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);

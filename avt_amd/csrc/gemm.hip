@@ -435,7 +435,7 @@ __device__ __forceinline__ void epi_fast_block(const GemmParams& p, const EpiBlk
       f32x2_t v1 = (f32x2_t){blk[j][4 * q + 2], blk[j][4 * q + 3]} + (f32x2_t){b[2], b[3]};
       if (ACT != 0) {
         f32x2_t d0, d1;
-        if (ACT == 1) { gelu_erf_both2(v0, v0, d0); gelu_erf_both2(v1, v1, d1); }
+        if (ACT == 1) gelu_erf_both4(v0, v1, d0, d1);
         else {
           float y4[4], d4[4];
           gelu_tanh_both(v0[0], y4[0], d4[0]); gelu_tanh_both(v0[1], y4[1], d4[1]);
@@ -579,7 +579,7 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
         if (ACT == 3) { v0 *= o0; v1 *= o1; }
         if (ACT == 1 || ACT == 2) {
           f32x2_t d0, d1;
-          if (ACT == 1) { gelu_erf_both2(v0, v0, d0); gelu_erf_both2(v1, v1, d1); }
+          if (ACT == 1) gelu_erf_both4(v0, v1, d0, d1);
           else {
             float y4[4], d4[4];
             gelu_tanh_both(v0[0], y4[0], d4[0]); gelu_tanh_both(v0[1], y4[1], d4[1]);
