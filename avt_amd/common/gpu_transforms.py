@@ -126,9 +126,12 @@ class GpuClipTransform:
             op_ids = torch.full((len(params), 4), -1, dtype=torch.int32)
             fac = torch.zeros((len(params), 4), dtype=torch.float32)
             for b, ops_b in enumerate(jitter):
-                assert len(ops_b) <= 4
+                if len(ops_b) > 4:
+                    raise ValueError('at most four colour-jitter operations per clip')
                 for k, (op, f) in enumerate(ops_b):
                     op = names.index(op) if isinstance(op, str) else int(op)
+                    if not 0 <= op <= 3 or (op != 3 and float(f) < 0) or (op == 3 and not -0.5 <= float(f) <= 0.5):
+                        raise ValueError(f'bad colour-jitter operation {(op, f)}: ids 0..3, factors >= 0, hue in [-0.5, 0.5]')
                     op_ids[b, k] = op
                     fac[b, k] = float(int(float(f) * 255) & 255) if op == 3 else float(f)   # hue: np.uint8(hue_factor * 255), the 8-bit shift
             return ops.video_preproc_jitter(clips_u8.contiguous(), p, op_ids.to(clips_u8.device), fac.to(clips_u8.device), self.crop,
