@@ -766,3 +766,35 @@ def test_video_preproc_with_color_jitter_vs_reference_golden(golden_dir):
     plain = GpuClipTransform(56, -1, 48, tuple(g['mean']), tuple(g['std']), train=True)
     torch.manual_seed(7); random.seed(7)
     assert float((plain(clips) - a).abs().max()) > 1e-2                              # the jitter does something
+
+
+@pytest.mark.gpu
+def test_color_jitter_operations_exact_vs_oracle_random_chains(ops):
+    """The four Pillow operations on the device against the oracle's restatement (itself pinned to Pillow on the CPU), identity geometry (so
+    the 8-bit input is the clip itself), random orders / factors incl. the clipping branch of Image.blend, negative hue shifts, grey pixels
+    and max-channel ties, with and without the mirror: every 8-bit level equal."""
+    import random
+    import numpy as np
+    from oracle import avt_oracle as O
+    g = torch.Generator().manual_seed(9)
+    T, H, W = 2, 40, 72
+    names = ('brightness', 'contrast', 'saturation', 'hue')
+    random.seed(9)
+    for trial in range(10):
+        clip = torch.randint(0, 256, (1, T, H, W, 3), generator=g, dtype=torch.uint8)
+        if trial % 2 == 0:
+            clip[:, :, : H // 2] = clip[:, :, : H // 2] // 16 * 16
+            clip[..., :12, 1] = clip[..., :12, 0]; clip[..., :6, 2] = clip[..., :6, 0]
+        order = list(names)
+        random.shuffle(order)
+        chain = [(n, random.uniform(-0.5, 0.5) if n == 'hue' else random.uniform(0.0, 2.2)) for n in order[: 1 + trial % 4]]
+        flip = trial % 2
+        ids = [names.index(n) for n, _ in chain] + [-1] * (4 - len(chain))
+        fs = [float(int(f * 255) & 255) if n == 'hue' else f for n, f in chain] + [0.] * (4 - len(chain))
+        params = torch.tensor([[H, W, flip, 0, 0, 0]], dtype=torch.int32).cuda()
+        out = ops.video_preproc_jitter(clip.cuda(), params, torch.tensor([ids], dtype=torch.int32).cuda(), torch.tensor([fs], dtype=torch.float32).cuda(),
+                                       (H, W), mean=(0, 0, 0), std=(1, 1, 1))
+        dev = (out[0, :, :, 0] * 255).round().cpu()                     # (T, 3, H, W) levels
+        ref = O.video_preproc(clip[0], (H, W), flip, (0, 0), (H, W), mean=(0, 0, 0), std=(1, 1, 1), color_jitter_ops=chain)
+        ref = (ref.permute(1, 0, 2, 3) * 255).round()
+        assert torch.equal(dev, ref), (trial, chain, float((dev - ref).abs().max()))

@@ -257,3 +257,42 @@ def test_g11_color_jitter_chain(golden_dir):
         ops_b = [(O.JITTER_OPS[int(i)], float(f)) for i, f in zip(g['op_ids'][b], g['op_factors'][b]) if i >= 0]
         mine = O.video_preproc(clips[b], (nh, nw), flip, (ci, cj), (48, 48), 1.0, tuple(g['mean']), tuple(g['std']), False, color_jitter_ops=ops_b)
         assert float((mine - torch.from_numpy(g['out'][b])).abs().max()) < 1e-6, b
+
+
+def test_pil_restatement_against_the_pillow_in_this_image():
+    """oracle.pil_color_jitter against the real Pillow (when the image has one), executed the way torchvision 0.8.2's functional_pil does it
+    (ImageEnhance.Brightness / Contrast / Color, adjust_hue through the 8-bit HSV image): random images, orders and factors incl. factors
+    outside [0, 1] (clipping branch of Image.blend) and negative hue shifts: exact."""
+    Image = pytest.importorskip('PIL.Image')
+    from PIL import ImageEnhance
+    import numpy as np
+    import random
+
+    def tv_adjust(img, name, f):
+        if name == 'brightness':
+            return ImageEnhance.Brightness(img).enhance(f)
+        if name == 'contrast':
+            return ImageEnhance.Contrast(img).enhance(f)
+        if name == 'saturation':
+            return ImageEnhance.Color(img).enhance(f)
+        h, s, v = img.convert('HSV').split()                                   # functional_pil.adjust_hue
+        np_h = np.array(h, dtype=np.uint8)
+        with np.errstate(over='ignore'):
+            np_h = (np_h.astype(np.int32) + (int(f * 255) & 255)).astype(np.uint8)         # np_h += np.uint8(hue_factor * 255), 8-bit wrap
+        return Image.merge('HSV', (Image.fromarray(np_h, 'L'), s, v)).convert('RGB')
+
+    rng = np.random.RandomState(5)
+    random.seed(5)
+    for trial in range(12):
+        a = rng.randint(0, 256, (37 + trial, 53, 3)).astype(np.uint8)
+        if trial % 3 == 0:
+            a[: a.shape[0] // 2] = a[: a.shape[0] // 2] // 8 * 8                # flat-ish regions: grey pixels (s = 0) and ties in max(r, g, b)
+            a[:, :10, 1] = a[:, :10, 0]; a[:, :5, 2] = a[:, :5, 0]
+        names = list(O.JITTER_OPS)
+        random.shuffle(names)
+        ops_ = [(n, random.uniform(-0.5, 0.5) if n == 'hue' else random.uniform(0.0, 2.2)) for n in names[: 1 + trial % 4]]
+        img = Image.fromarray(a, 'RGB')
+        for n, f in ops_:
+            img = tv_adjust(img, n, f)
+        mine = O.pil_color_jitter(a, ops_)
+        assert np.array_equal(mine, np.array(img)), (trial, ops_, int(np.abs(mine.astype(int) - np.array(img).astype(int)).max()))
