@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                 bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
                                                                 float* __restrict__ part, int S, int H, int items, float scale, long long* dbg) {
-  long long tcs = 0, tca = 0, tcb = 0, tc0 = dbg ? __builtin_readcyclecounter() : 0;
+  long long tcs = 0, tca = 0, tcb = 0, tw1 = 0, tw2 = 0, tc0 = dbg ? __builtin_readcyclecounter() : 0;      // lab stamps (dbg is null in the product library)
   constexpr int NP = (NKT + 1) / 2;
   constexpr int KP = NP * 32;                // rows of every LDS tile (zero padded)
   constexpr int RM = KP * 128;               // bytes of a row-major [KP][64] bf16 tile
@@ -375,7 +375,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
     // (ALL_LIVE: every wave's strip has at least one row inside the sequence, so every guarded load / store is issued; else
     // a wave may have skipped them and the count would be wrong -> wait for everything)
     if (ALL_LIVE) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    long long tb1 = dbg ? __builtin_readcyclecounter() : 0;
     __syncthreads();                                       // barrier 1
+    if (dbg) tw1 += __builtin_readcyclecounter() - tb1;
     if (dbias && prev_head >= 0) {                         // dv sums of the previous item, in wave order (the dk sums are zero)
       for (int c = 128 + tid; c < 192; c += nthr) {
         float t = bias_s[prev_head * 192 + c];
@@ -461,7 +463,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
     bk[0] = frag_rm(Ks, wave, 0, lane); bk[1] = frag_rm(Ks, wave, 1, lane);
     bv[0] = frag_rm(Vs, wave, 0, lane); bv[1] = frag_rm(Vs, wave, 1, lane);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // Q, dO landed (this wave's share); strips are in registers
+    long long tb2 = dbg ? __builtin_readcyclecounter() : 0;
     __syncthreads();                                                // barrier 2
+    if (dbg) tw2 += __builtin_readcyclecounter() - tb2;
     if (dbias) {                                                    // dq sums of this item, in wave order
       for (int c = tid; c < 64; c += nthr) {
         float t = bias_h[c];
@@ -585,8 +589,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
     }
   }
   if (dbg && lane == 0) {
-    long long* d = dbg + ((size_t)blockIdx.x * 16 + wave) * 4;
-    d[0] = tcs; d[1] = tca; d[2] = tcb; d[3] = (items - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    long long* d = dbg + ((size_t)blockIdx.x * 16 + wave) * 8;
+    d[0] = tcs; d[1] = tca; d[2] = tcb; d[3] = (items - blockIdx.x + gridDim.x - 1) / gridDim.x; d[4] = tw1; d[5] = tw2;
   }
 }
 
