@@ -28,7 +28,10 @@ __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
 //   * ds_read_b64_tr_b16 transposing reads (8 rows x 32 B per half wave): the 4 row pairs of 8 consecutive rows must land on 4
 //     different 32-B slots.  With the plain c ^ ((r >> 1) & 7) they shared two (rows r and r + 2 on the same banks: 25 % of the
 //     backward's LDS cycles were bank-conflict cycles, profiles/r03a_pmc_sq.txt); p -> ((p & 3) << 1) | (p >> 2) satisfies both.
-__device__ __forceinline__ int swz8(int r) { const int p = (r >> 1) & 7; return ((p & 3) << 1) | (p >> 2); }
+// (late round 3: the first "both patterns" permutation, p -> ((p & 3) << 1) | (p >> 2), turned out 2-way conflicted for the ds_read_b128 fragments --
+// the hardware's lane grouping is not the one assumed above.  tools/lab/lds_swizzle_search.hip times all 8! bijections on the GPU: 3456 are clean for
+// the b128 pattern, 1536 of those also for the transposing reads; this is the first of them, {0,2,4,6,5,7,1,3}.)
+__device__ __forceinline__ int swz8(int r) { const int p = (r >> 1) & 7, hi = p >> 2; return ((((p & 3) ^ (hi << 1)) << 1) | hi); }
 __device__ __forceinline__ int rm_off(int r, int c) { return r * 128 + ((c ^ swz8(r)) << 4); }
 
 // Stage S rows x 64 columns (global row stride ld) into a swizzled row-major tile of RP rows (zero padded) and/or
