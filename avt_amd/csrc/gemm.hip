@@ -63,6 +63,13 @@ struct GemmParams {
 #endif
 
 constexpr int BK64 = 64;
+// cache policy of the 8-phase kernel's operand streams (aux of buffer_load ... lds: 0 = default, 2 = nt)
+#ifndef AVT_LDA_AUX
+#define AVT_LDA_AUX 0
+#endif
+#ifndef AVT_LDB_AUX
+#define AVT_LDB_AUX 0
+#endif
 
 // XCD-aware bijective remap of the linear block id: XCD x (= id % 8 by dispatch order) owns a contiguous
 // range of logical blocks, ordered (split, tile row, tile column), so tiles sharing an A row-panel sit behind the same L2
@@ -417,11 +424,30 @@ __device__ __forceinline__ void epi_write_block_i(float* patch, const f32x16_t (
   }
 }
 
+// 16-byte global stores of the epilogue outputs with a selectable L2 policy.  AVT_ST_AUX = 0: plain stores (the line stays in
+// the XCD's L2: an M x 3072 activation written by one GEMM is consumed hundreds of microseconds later by another kernel, so all
+// it does there is push the B operand out); 16 = sc1 (write-through, the line is dropped from L2 -- MI355X_MICROARCH.md, price
+// list "stores of each flavour").  Rows are addressed relative to the wave tile's origin through a buffer descriptor.
+#ifndef AVT_ST_AUX
+#define AVT_ST_AUX 0
+#endif
+struct TileStore {
+  __amdgpu_buffer_rsrc_t r; bf16_t* base; int ld;
+  __device__ __forceinline__ void init(bf16_t* origin, int ld_) {
+    base = origin; ld = ld_;
+    if (AVT_ST_AUX != 0) r = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, 0xFFFFFFF0u, 0x00020000);
+  }
+  __device__ __forceinline__ void st(int drow, int dcol, u32x4_t v) const {
+    if (AVT_ST_AUX == 0) *(u32x4_t*)(base + (size_t)drow * ld + dcol) = v;
+    else __builtin_amdgcn_raw_buffer_store_b128(v, r, (uint32_t)((drow * ld + dcol) * 2), 0, AVT_ST_AUX);
+  }
+};
+
 // ---- fast path (bias / GELU (+ GELU') only, bf16 output): all arithmetic in the accumulator layout with packed fp32 ops,
 // bf16 pairs through a [32][WN] bf16 patch (ds_write_b64 in, 16 B per lane out), one 16-byte global store per lane and row
 template <int TN, int WN, int ACT>
 __device__ __forceinline__ void epi_fast_block(const GemmParams& p, const EpiBlk<TN> blk_, char* patch_c, char* patch_d,
-                                               const float* bias_l, int lane, int m0, int col0) {
+                                               const float* bias_l, int lane, int m0, int col0, const TileStore& sc, const TileStore& sd, int i32) {
   const f32x16_t* blk = blk_.t;
   constexpr int LDB = WN * 2 + 8;                                  // patch row pitch (bytes): 16 store lanes -> 32 distinct banks
   const int ml = lane & 31, h = lane >> 5;
@@ -459,8 +485,8 @@ __device__ __forceinline__ void epi_fast_block(const GemmParams& p, const EpiBlk
     u32x2_t lo2 = lo, hi2 = hi;
     if (p.C2) { const char* s2 = patch_2 + row * LDB + cl * 2; lo2 = *(const u32x2_t*)s2; hi2 = *(const u32x2_t*)(s2 + 8); }
     if (m < p.M && n < p.N) {
-      *(u32x4_t*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = (u32x4_t){lo[0], lo[1], hi[0], hi[1]};
-      if (p.C2) *(u32x4_t*)(p.C2 + (size_t)m * p.ldc2 + n) = (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]};
+      sc.st(i32 + row, cl, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
+      if (p.C2) sd.st(i32 + row, cl, (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]});
     }
   }
 }
@@ -471,13 +497,16 @@ __device__ __forceinline__ void epi_fast(const GemmParams& p, const f32x16_t (&a
   char* patch_c = wave_lds + WN * 4;
   char* patch_d = patch_c + 32 * LDB;
   for (int c_ = lane; c_ < WN; c_ += 64) bias_l[c_] = (p.bias && col0 + c_ < p.N) ? p.bias[col0 + c_] : 0.f;
+  TileStore sc, sd;
+  sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc);
+  sd.init(p.C2 ? p.C2 + (size_t)row0 * p.ldc2 + col0 : (bf16_t*)p.C, p.ldc2);
   if (ACT == 0) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       EpiBlk<TN> b;
 #pragma unroll
       for (int j = 0; j < TN; ++j) b.t[j] = acc[i][j];
-      epi_fast_block<TN, WN, ACT>(p, b, patch_c, patch_d, bias_l, lane, row0 + i * 32, col0);
+      epi_fast_block<TN, WN, ACT>(p, b, patch_c, patch_d, bias_l, lane, row0 + i * 32, col0, sc, sd, i * 32);
     }
   } else {
     // the GELU arithmetic of one block is ~1.5 k instructions: keep ONE copy of it (instruction cache) and move the block
@@ -491,7 +520,7 @@ __device__ __forceinline__ void epi_fast(const GemmParams& p, const f32x16_t (&a
         case 2: b = epi_take<TM, TN, 2>(acc); break;
         default: b = epi_take<TM, TN, 3>(acc); break;
       }
-      epi_fast_block<TN, WN, ACT>(p, b, patch_c, patch_d, bias_l, lane, row0 + i * 32, col0);
+      epi_fast_block<TN, WN, ACT>(p, b, patch_c, patch_d, bias_l, lane, row0 + i * 32, col0, sc, sd, i * 32);
     }
   }
 }
@@ -534,6 +563,9 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
     }
   };
   if (has_prim) { dma_block(0); if (TM > 1) dma_block(1); }
+  TileStore sc, sd;
+  sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc);
+  sd.init(p.C2 ? p.C2 + (size_t)row0 * p.ldc2 + col0 : (bf16_t*)p.C, p.ldc2);
   float cs[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) cs[k] = 0.f;
@@ -609,8 +641,8 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
       u32x2_t lo2 = lo, hi2 = hi;
       if (p.C2) { const char* s2 = patch_d + row * LDB + cl * 2; lo2 = *(const u32x2_t*)s2; hi2 = *(const u32x2_t*)(s2 + 8); }
       if (mm < p.M && n < p.N) {
-        *(u32x4_t*)((bf16_t*)p.C + (size_t)mm * p.ldc + n) = (u32x4_t){lo[0], lo[1], hi[0], hi[1]};
-        if (p.C2) *(u32x4_t*)(p.C2 + (size_t)mm * p.ldc2 + n) = (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]};
+        sc.st(i * 32 + row, cl, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
+        if (p.C2) sd.st(i * 32 + row, cl, (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]});
         if (p.colsum) {
           cs[0] += bflo(lo[0]); cs[1] += bfhi(lo[0]); cs[2] += bflo(lo[1]); cs[3] += bfhi(lo[1]);
           cs[4] += bflo(hi[0]); cs[5] += bfhi(hi[0]); cs[6] += bflo(hi[1]); cs[7] += bfhi(hi[1]);
@@ -1095,339 +1127,9 @@ int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk,
              : dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 0, SPREAD, PR, MINW, NWL>(p, a_kmajor, b_kmajor, s);
 }
 
-#ifdef AVT_LAB   // ---- lab-only kernel variants (negative results kept for A/B in tools/): not part of libavt_hip.so ----
-// ---- ping-pong kernel: 256x256 tile, 8 waves = two groups of four, half-K-tile ring ---------------------------
-// Group g owns the 128-row half g of the tile (wave tile 128x64).  Waves w and w+4 share a SIMD; the groups run the
-// same program one phase apart, so on every SIMD one wave issues its 16 MFMAs from registers (compute phase) while
-// the other reads its next fragments from LDS and issues its share of the LDS-DMA (load phase).  LDS holds four
-// half-K-tile slots (32 k each: A [256][32] + B [256][32] = 32 KB); a slot is refilled as soon as both groups have
-// read it, 1.5 K tiles ahead of its next use.  Four phases (one barrier each) per 64-deep K tile t:
-//     P0: G0 reads (t,h0), stages A(t+1,h1) | G1 computes (t-1,h1)        P1: G0 computes (t,h0) | G1 reads (t,h0), stages B(t+1,h1)
-//     P2: G0 reads (t,h1), stages A(t+2,h0) | G1 computes (t,h0)          P3: G0 computes (t,h1) | G1 reads (t,h1), stages B(t+2,h0)
-// Every wave keeps its two youngest 4-instruction DMA batches in flight across the barriers (s_waitcnt vmcnt(8)).
-#define PP_BARRIER() do { __builtin_amdgcn_sched_barrier(0); { PP_T0(); if (ABL != 3 && ABL != 4) asm volatile("s_barrier" ::: "memory"); PP_T1(c_bar); } __builtin_amdgcn_sched_barrier(0); } while (0)
-template <bool A_KMAJOR, bool B_KMAJOR, int EPI, int ABL = 0>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
-  constexpr int BM = 256, BN = 256, BK = 64, HK = 32, WM = 128, WN = 64, TM = 4, TN = 2;
-  constexpr int A_HALF = BM * HK * 2, B_HALF = BN * HK * 2, SLOT = A_HALF + B_HALF;   // 16 + 16 KB
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, wn = wave & 3;
-
-  const int ntile = p.tiles_m * p.tiles_n;
-  const int bid = blockIdx.x;
-  const int lb = xcd_remap(bid, ntile * p.splitk);          // an XCD owns a contiguous range of (split, tile): see xcd_remap
-  const int split = lb / ntile;
-  const int t = lb - split * ntile;
-  const int tm0 = (t / p.tiles_n) * BM;
-  const int tn0 = (t % p.tiles_n) * BN;
-  const int nk_total = (p.K + BK - 1) / BK;
-  // (32-bit arithmetic: nk_total * splitk < 2^31 for every operand below 4 GiB; the 64-bit form expands to ~200 scalar
-  // instructions at the start of every workgroup)
-  const int kt_begin = p.splitk == 1 ? 0 : (int)((unsigned)nk_total * (unsigned)split / (unsigned)p.splitk);
-  const int kt_end = p.splitk == 1 ? nk_total : (int)((unsigned)nk_total * (unsigned)(split + 1) / (unsigned)p.splitk);
-  const int nk = kt_end - kt_begin;
-
-  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  bf16x8_t af[2][TM], bfr[2][TN];
-  long long c_wait = 0, c_bar = 0, c_comp = 0, c_load = 0, c_t0 = 0, c_dma = 0;
-  const bool prof = (p.dbg != nullptr);
-  if (prof) c_t0 = __builtin_readcyclecounter();
-#define PP_T0() long long t__ = prof ? __builtin_readcyclecounter() : 0
-#define PP_T1(acc_) do { if (prof) acc_ += __builtin_readcyclecounter() - t__; } while (0)
-
-  // group 0 stages A half-tiles, group 1 stages B half-tiles (4 waves x 4 instructions = 16 KB each)
-  auto stage_half = [&](int kt_rel, int h) {       // K tile (relative), half h -> slot ((kt&1)*2 + h)
-    if (kt_rel >= nk || ABL == 1 || ABL == 4) return;
-    PP_T0();
-    char* base = lds + ((kt_rel & 1) * 2 + h) * SLOT;
-    const int k0 = (kt_begin + kt_rel) * BK + h * HK;
-    if (grp == 0) {
-      if (A_KMAJOR) stage_kmajor<BM, 4, HK>(ra, base, tm0, k0, p.lda, p.K, wn, lane);
-      else stage_kstrided<BM, 4, HK>(ra, base, tm0, k0, p.lda, p.M, wn, lane);
-    } else {
-      if (B_KMAJOR) stage_kmajor<BN, 4, HK>(rb, base + A_HALF, tn0, k0, p.ldb, p.K, wn, lane);
-      else stage_kstrided<BN, 4, HK>(rb, base + A_HALF, tn0, k0, p.ldb, p.N, wn, lane);
-    }
-    PP_T1(c_dma);
-  };
-  bool first_frag = true;
-  auto load_frags = [&](int kt_rel, int h) {
-    if ((ABL == 2 || ABL == 4) && !first_frag) { asm volatile("" ::: "memory"); return; }
-    first_frag = false;
-    PP_T0();
-    const char* la = lds + ((kt_rel & 1) * 2 + h) * SLOT;
-    const char* lb = la + A_HALF;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[ks][i] = A_KMAJOR ? frag_kmajor<HK>(la, grp * TM + i, ks, lane) : frag_kstrided<BM>(la, grp * TM + i, ks, lane);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bfr[ks][j] = B_KMAJOR ? frag_kmajor<HK>(lb, wn * TN + j, ks, lane) : frag_kstrided<BN>(lb, wn * TN + j, ks, lane);
-    }
-    PP_T1(c_load);
-  };
-  auto compute = [&]() {
-    PP_T0();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = mma<EPI>(af[ks][i], bfr[ks][j], acc[i][j]);
-    __builtin_amdgcn_s_setprio(0);
-    if (prof) { asm volatile("s_nop 0" ::: "memory"); }
-    PP_T1(c_comp);
-  };
-  // wait until this wave's share of every half-tile older than its two youngest batches has landed
-  auto wait_ring = [&](int it) {
-    PP_T0();
-    if (it + 2 < nk) wait_vmcnt<8>(); else wait_vmcnt<0>();
-    PP_T1(c_wait);
-  };
-
-  // load phase = fragment reads (asynchronous) -> this wave's share of the LDS-DMA refill -> ring wait -> lgkmcnt(0)
-  auto load_phase = [&](int it, int h) {
-    load_frags(it, h);
-    if (h == 0) stage_half(it + 1, 1); else stage_half(it + 2, 0);
-    wait_ring(it + h);
-    { PP_T0(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PP_T1(c_load); }
-  };
-  stage_half(0, 0); stage_half(0, 1); stage_half(1, 0);
-  wait_ring(-1);
-  PP_BARRIER();
-  if (grp == 0) {
-    for (int it = 0; it < nk; ++it) {
-      load_phase(it, 0);                // P0
-      PP_BARRIER();
-      compute();                        // P1
-      PP_BARRIER();
-      load_phase(it, 1);                // P2
-      PP_BARRIER();
-      compute();                        // P3
-      PP_BARRIER();
-    }
-    PP_BARRIER();                       // partner's trailing compute phase
-  } else {
-    for (int it = 0; it < nk; ++it) {
-      if (it > 0) compute();            // P0
-      PP_BARRIER();
-      load_phase(it, 0);                // P1
-      PP_BARRIER();
-      compute();                        // P2
-      PP_BARRIER();
-      load_phase(it, 1);                // P3
-      PP_BARRIER();
-    }
-    if (nk > 0) compute();
-    PP_BARRIER();
-  }
-  long long c_loop_end = prof ? __builtin_readcyclecounter() : 0;
-  gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + grp * WM, tn0 + wn * WN);
-  if (prof && lane == 0 && (wave == 0 || wave == 4)) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    long long* d = p.dbg + ((size_t)bid * 2 + grp) * 8;
-    d[0] = c_wait; d[1] = c_bar; d[2] = c_comp; d[3] = c_load; d[4] = c_loop_end - c_t0; d[5] = __builtin_readcyclecounter() - c_loop_end; d[6] = nk; d[7] = c_dma;
-  }
-}
-
-template <bool AK, bool BK_, int EPI, int ABL = 0>
-int launch_pp(const GemmParams& p, hipStream_t s) {
-  int grid = p.tiles_m * p.tiles_n * p.splitk;
-  constexpr int smem = (EPI == 0 && 8 * epi_wave_lds<64>() > 2 * (256 + 256) * 64 * 2) ? 8 * epi_wave_lds<64>() : 2 * (256 + 256) * 64 * 2;   // 128 KiB ring | epilogue patches
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_pp_kernel<AK, BK_, EPI, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_pp_kernel<AK, BK_, EPI, ABL>), dim3(grid), dim3(512), smem, s, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
-  return 0;
-}
-
-int dispatch_pp(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
-  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
-  const int nk = (p.K + 63) / 64;
-  if (splitk <= 0) {
-    splitk = 1;
-    if (epi == 1) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk, 1, 8);
-  }
-  if (splitk > nk) splitk = nk;
-  p.splitk = splitk;
-  if (epi == 0) {
-    if (a_kmajor && b_kmajor) {
-      static int abl = -1;
-      if (abl < 0) { const char* e = getenv("AVT_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
-      switch (abl) {          // lab-only variants (wrong results by construction): what does each piece cost?
-        case 1: return launch_pp<true, true, 0, 1>(p, s);
-        case 2: return launch_pp<true, true, 0, 2>(p, s);
-        case 3: return launch_pp<true, true, 0, 3>(p, s);
-        case 4: return launch_pp<true, true, 0, 4>(p, s);
-        default: break;
-      }
-      return launch_pp<true, true, 0>(p, s);
-    }
-    if (a_kmajor && !b_kmajor) return launch_pp<true, false, 0>(p, s);
-    if (!a_kmajor && !b_kmajor) return launch_pp<false, false, 0>(p, s);
-    return launch_pp<false, true, 0>(p, s);
-  }
-  if (a_kmajor && b_kmajor) return launch_pp<true, true, 1>(p, s);
-  if (a_kmajor && !b_kmajor) return launch_pp<true, false, 1>(p, s);
-  if (!a_kmajor && !b_kmajor) return launch_pp<false, false, 1>(p, s);
-  return launch_pp<false, true, 1>(p, s);
-}
-
-// ---- deep-A kernel: 256x256x64, 8 waves, activation operand 2 tiles ahead -------------------------------------------
-// In the forward / data-gradient GEMMs the A operand (activations, hundreds of MB) streams from HBM while B (weights,
-// a few MB) sits in L2.  The whole 160 KiB LDS is spent asymmetrically: A ring = 3 stages x 32 KB (two K tiles of
-// HBM latency cover), B ring = 2 stages x 32 KB.  Issue order per K tile is B(t+1) then A(t+2), so "all but the RA
-// youngest LDS-DMA instructions" (s_waitcnt vmcnt(RA)) is exactly "tile t+1 has landed".
-template <bool A_KMAJOR, bool B_KMAJOR, int EPI>
-__global__ __launch_bounds__(512) void gemm_deepa_kernel(GemmParams p) {
-  constexpr int BM = 256, BN = 256, BK = 64, NW = 8, WGN = 4, WM = 128, WN = 64, TM = 4, TN = 2, KS = 4;
-  constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;
-  constexpr int RA = 4, RB = 4;                        // LDS-DMA instructions per wave per A / B tile
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* const lds_b = lds + 3 * A_TILE;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WGN, wn = wave % WGN;
-
-  const int ntile = p.tiles_m * p.tiles_n;
-  const int bid = blockIdx.x;
-  const int lb = xcd_remap(bid, ntile * p.splitk);          // an XCD owns a contiguous range of (split, tile): see xcd_remap
-  const int split = lb / ntile;
-  const int t = lb - split * ntile;
-  const int tm0 = (t / p.tiles_n) * BM;
-  const int tn0 = (t % p.tiles_n) * BN;
-  const int nk_total = (p.K + BK - 1) / BK;
-  // (32-bit arithmetic: nk_total * splitk < 2^31 for every operand below 4 GiB; the 64-bit form expands to ~200 scalar
-  // instructions at the start of every workgroup)
-  const int kt_begin = p.splitk == 1 ? 0 : (int)((unsigned)nk_total * (unsigned)split / (unsigned)p.splitk);
-  const int kt_end = p.splitk == 1 ? nk_total : (int)((unsigned)nk_total * (unsigned)(split + 1) / (unsigned)p.splitk);
-  const int nk = kt_end - kt_begin;
-
-  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  auto a_part = [&](int kt_rel, int q) {
-    if (kt_rel >= nk) return;
-    char* base = lds + (kt_rel % 3) * A_TILE;
-    const int k0 = (kt_begin + kt_rel) * BK;
-    if (A_KMAJOR) stage_kmajor_part<BM, NW, BK>(ra, base, tm0, k0, p.lda, p.K, wave, lane, q);
-    else stage_kstrided_part<BM, NW, BK>(ra, base, tm0, k0, p.lda, p.M, wave, lane, q);
-  };
-  auto b_part = [&](int kt_rel, int q) {
-    if (kt_rel >= nk) return;
-    char* base = lds_b + (kt_rel & 1) * B_TILE;
-    const int k0 = (kt_begin + kt_rel) * BK;
-    if (B_KMAJOR) stage_kmajor_part<BN, NW, BK>(rb, base, tn0, k0, p.ldb, p.K, wave, lane, q);
-    else stage_kstrided_part<BN, NW, BK>(rb, base, tn0, k0, p.ldb, p.N, wave, lane, q);
-  };
-#pragma unroll
-  for (int q = 0; q < RA; ++q) a_part(0, q);
-#pragma unroll
-  for (int q = 0; q < RB; ++q) b_part(0, q);
-#pragma unroll
-  for (int q = 0; q < RA; ++q) a_part(1, q);
-
-  for (int it = 0; it < nk; ++it) {
-    if (it + 1 < nk) wait_vmcnt<RA>(); else wait_vmcnt<0>();
-    asm volatile("s_barrier" ::: "memory");
-    const char* la = lds + (it % 3) * A_TILE;
-    const char* lb = lds_b + (it & 1) * B_TILE;
-    bf16x8_t af[2][TM], bfr[2][TN];
-    auto ldf = [&](int ks, int b) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[b][i] = A_KMAJOR ? frag_kmajor<BK>(la, wm * TM + i, ks, lane) : frag_kstrided<BM>(la, wm * TM + i, ks, lane);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bfr[b][j] = B_KMAJOR ? frag_kmajor<BK>(lb, wn * TN + j, ks, lane) : frag_kstrided<BN>(lb, wn * TN + j, ks, lane);
-    };
-    ldf(0, 0);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) ldf(ks + 1, (ks + 1) & 1);
-      // dribble the 8 refill instructions over k-steps 0..2 (3 + 3 + 2): B(t+1) first, then A(t+2)
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int part = ks * 3 + q;
-        if (ks < 3 && part < RA + RB) { if (part < RB) b_part(it + 1, part); else a_part(it + 2, part - RB); }
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = mma<EPI>(af[ks & 1][i], bfr[ks & 1][j], acc[i][j]);
-    }
-  }
-  asm volatile("s_barrier" ::: "memory");
-  gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
-}
-
-template <bool AK, bool BK_, int EPI>
-int launch_deepa(const GemmParams& p, hipStream_t s) {
-  int grid = p.tiles_m * p.tiles_n * p.splitk;
-  constexpr int smem = 3 * 256 * 64 * 2 + 2 * 256 * 64 * 2;       // 160 KiB: the whole LDS of a CU
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_deepa_kernel<AK, BK_, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm_deepa_kernel<AK, BK_, EPI>), dim3(grid), dim3(512), smem, s, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
-  return 0;
-}
-
-int dispatch_deepa(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
-  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
-  const int nk = (p.K + 63) / 64;
-  if (splitk <= 0) {
-    splitk = 1;
-    if (epi == 1) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk, 1, 8);
-  }
-  if (splitk > nk) splitk = nk;
-  p.splitk = splitk;
-  if (epi == 0) {
-    if (a_kmajor && b_kmajor) return launch_deepa<true, true, 0>(p, s);
-    if (a_kmajor && !b_kmajor) return launch_deepa<true, false, 0>(p, s);
-    if (!a_kmajor && !b_kmajor) return launch_deepa<false, false, 0>(p, s);
-    return launch_deepa<false, true, 0>(p, s);
-  }
-  if (a_kmajor && b_kmajor) return launch_deepa<true, true, 1>(p, s);
-  if (a_kmajor && !b_kmajor) return launch_deepa<true, false, 1>(p, s);
-  if (!a_kmajor && !b_kmajor) return launch_deepa<false, false, 1>(p, s);
-  return launch_deepa<false, true, 1>(p, s);
-}
-
-#endif  // AVT_LAB
+#ifdef AVT_LAB   // lab-only kernel variants (negative results kept for A/B in tools/): not part of libavt_hip.so
+#include "../../tools/lab/gemm_lab_variants.inc"
+#endif
 
 // ---- 8-phase kernel: 256x256x64 tile, two wave groups half a phase apart, half-tile ring 1.5 K tiles deep ---------
 // The K tile is consumed in four phases, one 64x32 quadrant of the 128x64 wave tile each; every phase is
@@ -1541,7 +1243,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
     const uint32_t adv = (uint32_t)tile * kstepA;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offA[h][j] + adv, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offA[h][j] + adv, 0, 0, AVT_LDA_AUX);
   };
   auto stage_b = [&](int h, int tile) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t r = (tile < nk) ? rb : rb_null;
@@ -1549,7 +1251,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
     const uint32_t adv = (uint32_t)tile * kstepB;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offB[h][j] + adv, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offB[h][j] + adv, 0, 0, AVT_LDB_AUX);
   };
 
   bf16x8_t fa[2][4], fb0[4], fb1[4];
