@@ -134,8 +134,12 @@ class GpuClipTransform:
                         raise ValueError(f'bad colour-jitter operation {(op, f)}: ids 0..3, factors >= 0, hue in [-0.5, 0.5]')
                     op_ids[b, k] = op
                     fac[b, k] = float(int(float(f) * 255) & 255) if op == 3 else float(f)   # hue: np.uint8(hue_factor * 255), the 8-bit shift
-            return ops.video_preproc_jitter(clips_u8.contiguous(), p, op_ids.to(clips_u8.device), fac.to(clips_u8.device), self.crop,
-                                            self.scale_pix_val, self.mean, self.std, self.reverse_channels)
+            slot_mask = sum(((1 << s) if bool((op_ids[:, s] >= 0).any()) else 0) | ((16 << s) if bool((op_ids[:, s] == 1).any()) else 0)
+                            for s in range(4))                                       # host tensors: nothing is read back from the device
+            return ops.video_preproc_jitter(clips_u8.contiguous(), p, op_ids.to(clips_u8.device, non_blocking=True),
+                                            fac.to(clips_u8.device, non_blocking=True), self.crop, self.scale_pix_val, self.mean, self.std,
+                                            self.reverse_channels, max_hw=(max(q[0] for q in params), max(q[1] for q in params)),
+                                            slot_mask=slot_mask)
         out = ops.video_preproc(clips_u8.contiguous(), p, self.crop, self.scale_pix_val, self.mean, self.std, self.reverse_channels,
                                 quantize_u8=self.quantize_u8)
         if multi:                                   # (B * crops, T, 3, 1, h, w) -> the model's 7-D (B, #clips, #crops, C, T', H, W)

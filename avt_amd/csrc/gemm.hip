@@ -70,6 +70,9 @@ constexpr int BK64 = 64;
 #ifndef AVT_LDB_AUX
 #define AVT_LDB_AUX 0
 #endif
+#ifndef AVT_LDP_AUX          // the epilogue's second operand (saved derivative / residual), read exactly once
+#define AVT_LDP_AUX 0
+#endif
 
 // XCD-aware bijective remap of the linear block id: XCD x (= id % 8 by dispatch order) owns a contiguous
 // range of logical blocks, ordered (split, tile row, tile column), so tiles sharing an A row-panel sit behind the same L2
@@ -426,10 +429,12 @@ __device__ __forceinline__ void epi_write_block_i(float* patch, const f32x16_t (
 
 // 16-byte global stores of the epilogue outputs with a selectable L2 policy.  AVT_ST_AUX = 0: plain stores (the line stays in
 // the XCD's L2: an M x 3072 activation written by one GEMM is consumed hundreds of microseconds later by another kernel, so all
-// it does there is push the B operand out); 16 = sc1 (write-through, the line is dropped from L2 -- MI355X_MICROARCH.md, price
-// list "stores of each flavour").  Rows are addressed relative to the wave tile's origin through a buffer descriptor.
+// it does there is push the B operand out); 2 = nt (the line stays but is the first to go); 16 = sc1 (write-through, the line is
+// dropped from L2 -- MI355X_MICROARCH.md, price list "stores of each flavour").  Measured on the whole step (256 clips, same box,
+// profiles/r04_cache_policy.txt): plain 878.7 / 880.3 clips/s, sc1 883.6 / 882.7, nt 889.2 / 887.4 (+1.0 %; fc1 forward 3094 ->
+// 2990 us with sc1) -> nt is the product's policy.  Rows are addressed relative to the wave tile's origin through a buffer descriptor.
 #ifndef AVT_ST_AUX
-#define AVT_ST_AUX 0
+#define AVT_ST_AUX 2
 #endif
 struct TileStore {
   __amdgpu_buffer_rsrc_t r; bf16_t* base; int ld;
@@ -559,7 +564,7 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
       const int mr = prim_period ? (m % prim_period) : m;
       uint32_t off = (uint32_t)(((size_t)mr * (size_t)prim_ld + (size_t)n) * 2);
       if (m >= p.M || n >= p.N) off = 0xFFFFFFF0u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, AVT_LDS_PTR(opbuf + (i & 1) * OPB + itr * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, AVT_LDS_PTR(opbuf + (i & 1) * OPB + itr * 1024), 16, off, 0, 0, AVT_LDP_AUX);
     }
   };
   if (has_prim) { dma_block(0); if (TM > 1) dma_block(1); }
@@ -748,7 +753,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
         const int mr = prim_period ? (m % prim_period) : m;
         uint32_t off = (uint32_t)(((size_t)mr * (size_t)prim_ld + (size_t)e.n) * 2);
         if (m >= p.M || !e.ncol_ok) off = 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, AVT_LDS_PTR(opbuf + (i & 1) * OPB + itr * 1024), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, AVT_LDS_PTR(opbuf + (i & 1) * OPB + itr * 1024), 16, off, 0, 0, AVT_LDP_AUX);
       }
     };
     if (staged) { dma_block(0); if (TM > 1) dma_block(1); }

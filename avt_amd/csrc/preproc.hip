@@ -16,8 +16,33 @@
 // to_pil_image does pic.mul(255).byte() (truncation), to_tensor divides by 255 -- the resized pixels are cut to 8 bits.
 #include "common.hpp"
 #include "../../include/avt_hip.h"
+// No floating-point contraction anywhere in this file: every expression below restates a CPU computation (torch's bilinear kernel,
+// Pillow's C) whose 8-bit cuts are sensitive to the last bit; the fused multiply-adds that ARE part of those computations are
+// written out (__fmaf_rn).  hipcc contracts by default, through the __f*_rn intrinsics as well.
+#pragma clang fp contract(off)
 
 namespace {
+// torch.nn.functional.interpolate(mode='bilinear', align_corners=False) with an explicit size, restated bit for bit as torch's CPU
+// kernel evaluates it for float tensors (ATen UpSampleKernel.cpp, the separable Interpolate<2> loop as built with contraction on;
+// pinned by tools/lab/interp_order.py against torch 2.10 on the build host: 0 differing floats over 7 M pixels):
+//   source index  r = max(fma(in / out, dst + 0.5, -0.5), 0);  i0 = min(floor(r), in - 1);  w1 = clamp(r - i0, 0, 1);  w0 = 1 - w1
+//   pixel         top = fma(p00, wx0, p01 * wx1);  bot = fma(p10, wx0, p11 * wx1);  out = fma(top, wy0, bot * wy1)
+// on pixels that went through to_tensor's TRUE division by 255.  The 8-bit cut of the colour-jitter round trip
+// (floor(v * 255)) sits right behind this, so a different association order puts pixels near an integer level one level off.
+__device__ __forceinline__ void src_index(int in_size, int out_size, int dst, int& i0, int& i1, float& w0, float& w1) {
+  const float r = fmaxf(__fmaf_rn((float)in_size / (float)out_size, (float)dst + 0.5f, -0.5f), 0.f);
+  i0 = min((int)r, in_size - 1);
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  w1 = fminf(fmaxf(r - (float)i0, 0.f), 1.f);
+  w0 = 1.f - w1;
+}
+__device__ __forceinline__ float bilerp_u8(int a00, int a01, int a10, int a11, float wx0, float wx1, float wy0, float wy1) {
+  const float p00 = (float)a00 / 255.f, p01 = (float)a01 / 255.f, p10 = (float)a10 / 255.f, p11 = (float)a11 / 255.f;
+  const float top = __fmaf_rn(p00, wx0, __fmul_rn(p01, wx1));
+  const float bot = __fmaf_rn(p10, wx0, __fmul_rn(p11, wx1));
+  return __fmaf_rn(top, wy0, __fmul_rn(bot, wy1));
+}
+
 __global__ __launch_bounds__(256) void video_preproc_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
                                                             const int* __restrict__ params, int T, int H, int W, int OH, int OW,
                                                             float scale_pix, float m0, float m1, float m2, float is0, float is1,
@@ -33,13 +58,9 @@ __global__ __launch_bounds__(256) void video_preproc_kernel(const uint8_t* __res
     const int yr = y + ci;
     int xr = x + cj;
     if (flip) xr = new_w - 1 - xr;
-    // torch.nn.functional.interpolate(mode='bilinear', align_corners=False) with an explicit size: scale = in / out,
-    // source = scale * (dst + 0.5) - 0.5 clamped at 0, upper neighbour clamped at the edge
-    const float sy = fmaxf(((float)H / (float)new_h) * ((float)yr + 0.5f) - 0.5f, 0.f);
-    const float sx = fmaxf(((float)W / (float)new_w) * ((float)xr + 0.5f) - 0.5f, 0.f);
-    const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
-    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    int y0, y1, x0, x1; float hy, ly, hx, lx;
+    src_index(H, new_h, yr, y0, y1, hy, ly);
+    src_index(W, new_w, xr, x0, x1, hx, lx);
     const uint8_t* f = src + ((size_t)sb * T + t) * (size_t)H * W * 3;
     const uint8_t* p00 = f + ((size_t)y0 * W + x0) * 3;
     const uint8_t* p01 = f + ((size_t)y0 * W + x1) * 3;
@@ -49,9 +70,8 @@ __global__ __launch_bounds__(256) void video_preproc_kernel(const uint8_t* __res
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int sc = reverse ? 2 - c : c;
-      const float k = 1.f / 255.f;
-      float v = hy * (hx * (p00[sc] * k) + lx * (p01[sc] * k)) + ly * (hx * (p10[sc] * k) + lx * (p11[sc] * k));
-      if (quantize) v = floorf(v * 255.f) / 255.f;
+      float v = bilerp_u8(p00[sc], p01[sc], p10[sc], p11[sc], hx, lx, hy, ly);
+      if (quantize) v = floorf(__fmul_rn(v, 255.f)) / 255.f;
       const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), is = c == 0 ? is0 : (c == 1 ? is1 : is2);
       o[(size_t)c * OH * OW] = (v * scale_pix - m) * is;
     }
@@ -69,9 +89,8 @@ __global__ __launch_bounds__(256) void video_preproc_kernel(const uint8_t* __res
 //      (Convert.c) around an 8-bit wrap-around add of (int)(factor * 255) & 255 (handed in as the op's factor).  The clip's luma sum is an
 //      exact 64-bit integer sum.
 //   3. / 255, x scale_pix, (reverse channels), normalise, crop -> fp32.
-// No floating-point contraction from here to the end of the file: a fused multiply-add rounds differently from Pillow's C (hipcc contracts
-// by default, THROUGH the __f*_rn intrinsics as well -- measured: saturation was one level off in 0.1 % of the pixels).
-#pragma clang fp contract(off)
+// (No floating-point contraction, see the top of the file: a fused multiply-add rounds differently from Pillow's C -- measured:
+// saturation was one level off in 0.1 % of the pixels.)
 __device__ __forceinline__ int luma_u8(int r, int g, int b) { return (int)(((unsigned)r * 19595u + (unsigned)g * 38470u + (unsigned)b * 7471u + 0x8000u) >> 16); }
 __device__ __forceinline__ int blend_u8(int d, int im, float f) {
   const float t = ((float)d + (f * (float)(im - d)));
@@ -93,15 +112,20 @@ __device__ __forceinline__ void rgb2hsv_u8(int r, int g, int b, int& uh, int& us
   uh = min(max((int)((double)h * 255.0), 0), 255);
   us = min(max((int)((double)s * 255.0), 0), 255);
 }
-__device__ __forceinline__ int round_u8(float x) { return min(max((int)rintf(x), 0), 255); }
+// hsv2rgb_row with C's promotions spelled out (round-3 advisor finding: an all-fp32 version with rintf was one level off on 2 of the
+// 2^24 triples): (float)h * 6.0 / 255.0 is double arithmetic, f and fs are stored as floats, fs * f is a float product, the
+// arguments of round() are doubles and round() is half away from zero
+__device__ __forceinline__ int round_u8(double x) { return min(max((int)round(x), 0), 255); }
 __device__ __forceinline__ void hsv2rgb_u8(int uh, int us, int uv, int& r, int& g, int& b) {
   if (us == 0) { r = g = b = uv; return; }
-  const float h = (((float)uh * 6.0f) / 255.0f), fs = ((float)us / 255.0f), fv = (float)uv;
-  const int i = (int)floorf(h);
-  const float f = (h - (float)i);
-  const int p = round_u8((fv * (1.f - fs)));
-  const int q = round_u8((fv * (1.f - (fs * f))));
-  const int t = round_u8((fv * (1.f - (fs * (1.f - f)))));
+  const double hd = (((double)(float)uh * 6.0) / 255.0);
+  const int i = (int)floor(hd);
+  const float f = (float)(hd - (double)(float)i);
+  const float fs = (float)((double)(float)us / 255.0);
+  const double fv = (double)(float)uv;
+  const int p = round_u8((fv * (1.0 - (double)fs)));
+  const int q = round_u8((fv * (1.0 - (double)(fs * f))));
+  const int t = round_u8((fv * (1.0 - ((double)fs * (1.0 - (double)f)))));
   switch (i % 6) {
     case 0: r = uv; g = t; b = p; break;
     case 1: r = q; g = uv; b = p; break;
@@ -124,11 +148,9 @@ __global__ __launch_bounds__(256) void resize_flip_u8_kernel(const uint8_t* __re
     const int new_h = pp[0], new_w = pp[1], flip = pp[2], sb = pp[5];
     if (y >= new_h || x >= new_w) continue;
     const int xr = flip ? new_w - 1 - x : x;
-    const float sy = fmaxf(((float)H / (float)new_h) * ((float)y + 0.5f) - 0.5f, 0.f);
-    const float sx = fmaxf(((float)W / (float)new_w) * ((float)xr + 0.5f) - 0.5f, 0.f);
-    const int y0 = min((int)sy, H - 1), x0 = min((int)sx, W - 1);
-    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
-    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    int y0, y1, x0, x1; float hy, ly, hx, lx;
+    src_index(H, new_h, y, y0, y1, hy, ly);
+    src_index(W, new_w, xr, x0, x1, hx, lx);
     const uint8_t* f = src + ((size_t)sb * T + t) * (size_t)H * W * 3;
     const uint8_t* p00 = f + ((size_t)y0 * W + x0) * 3;
     const uint8_t* p01 = f + ((size_t)y0 * W + x1) * 3;
@@ -137,9 +159,8 @@ __global__ __launch_bounds__(256) void resize_flip_u8_kernel(const uint8_t* __re
     uint8_t* o = scratch + ((((size_t)b * T + t) * SH + y) * SW + x) * 3;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      // to_tensor divides by 255 (a true division, not a multiplication by the reciprocal: the 8-bit cut below is sensitive to the last bit)
-      const float v = hy * (hx * ((float)p00[c] / 255.f) + lx * ((float)p01[c] / 255.f)) + ly * (hx * ((float)p10[c] / 255.f) + lx * ((float)p11[c] / 255.f));
-      o[c] = (uint8_t)(int)floorf(v * 255.f);
+      const float v = bilerp_u8(p00[c], p01[c], p10[c], p11[c], hx, lx, hy, ly);
+      o[c] = (uint8_t)(int)floorf(__fmul_rn(v, 255.f));
     }
   }
 }
@@ -223,7 +244,7 @@ extern "C" size_t avt_video_jitter_scratch_bytes(int B, int T, int max_h, int ma
 
 extern "C" int avt_video_preproc_jitter_u8(const void* src, float* dst, const int* params, const int* jitter_ops, const float* jitter_factors,
                                            int B, int T, int H, int W, int OH, int OW, int max_h, int max_w, float scale_pix,
-                                           const float* mean3, const float* std3, int reverse_channels,
+                                           const float* mean3, const float* std3, int reverse_channels, int slot_mask,
                                            void* scratch, size_t scratch_bytes, unsigned long long* luma_sums, void* stream) {
   AVT_CHECK(src && dst && params && jitter_ops && jitter_factors && mean3 && std3 && scratch && luma_sums, "avt_video_preproc_jitter_u8: null argument");
   AVT_CHECK(B > 0 && T > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && max_h >= OH && max_w >= OW, "avt_video_preproc_jitter_u8: bad shape");
@@ -234,9 +255,14 @@ extern "C" int avt_video_preproc_jitter_u8(const void* src, float* dst, const in
   long g = (total + 255) / 256; if (g > 16384) g = 16384;
   hipLaunchKernelGGL(resize_flip_u8_kernel, dim3((int)g), dim3(256), 0, s, (const uint8_t*)src, (uint8_t*)scratch, params, T, H, W, max_h, max_w, total);
   for (int slot = 0; slot < 4; ++slot) {
-    (void)hipMemsetAsync(luma_sums, 0, (size_t)B * sizeof(unsigned long long), s);
-    const int bpc = 64;
-    hipLaunchKernelGGL(luma_sum_kernel, dim3(B * bpc), dim3(256), 0, s, (const uint8_t*)scratch, params, jitter_ops, slot, luma_sums, T, max_h, max_w, bpc);
+    // slot_mask (host knowledge of the device-side op table): bit s = some clip has an operation in slot s, bit 4 + s = some clip's
+    // operation in slot s is contrast (needs the clip's mean luma).  A caller that does not know passes 0xff.
+    if (!((slot_mask >> slot) & 1)) continue;
+    if ((slot_mask >> (4 + slot)) & 1) {
+      (void)hipMemsetAsync(luma_sums, 0, (size_t)B * sizeof(unsigned long long), s);
+      const int bpc = 64;
+      hipLaunchKernelGGL(luma_sum_kernel, dim3(B * bpc), dim3(256), 0, s, (const uint8_t*)scratch, params, jitter_ops, slot, luma_sums, T, max_h, max_w, bpc);
+    }
     hipLaunchKernelGGL(jitter_op_kernel, dim3((int)g), dim3(256), 0, s, (uint8_t*)scratch, params, jitter_ops, jitter_factors, slot, luma_sums, T, max_h, max_w, total);
   }
   const long tot_out = (long)B * T * OH * OW;

@@ -11,6 +11,17 @@
 //   qkv layout: [frames*S, 3*D] with columns [q | k | v], each head-major (timm reshape(N,S,3,H,hd)).
 #include <cstdlib>
 #include "common.hpp"
+// L2 policy of the attention kernels' streams (A/B switches).  Measured (profiles/r04_cache_policy.txt): nt on the K / V / Q / dO tile
+// loads costs 15 % (forward 708 -> 820 us at 2560 frames: the twelve heads of a frame read adjacent 128-byte pieces of the same qkv rows),
+// so the loads keep the default policy.
+#ifndef AVT_ATTN_LD_AUX
+#define AVT_ATTN_LD_AUX 0
+#endif
+#ifdef AVT_ATTN_ST_NT
+#define AVT_ATTN_STG(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define AVT_ATTN_STG(p, v) (*(p) = (v))
+#endif
 #include "../../include/avt_hip.h"
 
 namespace {
@@ -66,7 +77,7 @@ __device__ __forceinline__ void stage_head_dma(const bf16_t* src, int ld, int S,
     uint32_t off = (uint32_t)(((size_t)r * (size_t)ld + (size_t)c * 8) * 2);
     if (r >= S) off = 0xFFFFFFF0u;
     char* dst = rm + __builtin_amdgcn_readfirstlane(j) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(dst), 16, off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(dst), 16, off, 0, 0, AVT_ATTN_LD_AUX);
   }
 }
 
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         u32x2_t w; w[0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv); w[1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
-        *(u32x2_t*)(orow + dt * 16 + 4 * g) = w;
+        AVT_ATTN_STG((u32x2_t*)(orow + dt * 16 + 4 * g), w);
       }
       if (g == 0) lse[((size_t)frame * H + head) * S + q] = mx * scale + __logf(sum);
     }
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
       for (int dt = 0; dt < 4; ++dt) {
         if (q < S) {
           u32x2_t w; w[0] = pack2bf(acc[dt][0], acc[dt][1]); w[1] = pack2bf(acc[dt][2], acc[dt][3]);
-          *(u32x2_t*)(dbase + (size_t)q * ld + dt * 16 + 4 * g) = w;
+          AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)q * ld + dt * 16 + 4 * g), w);
         }
       }
       if (dbias) {
@@ -536,9 +547,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
       for (int dt = 0; dt < 4; ++dt) {
         if (key < S) {
           u32x2_t w; w[0] = pack2bf(adk[dt][0], adk[dt][1]); w[1] = pack2bf(adk[dt][2], adk[dt][3]);
-          *(u32x2_t*)(dbase + (size_t)key * ld + D + dt * 16 + 4 * g) = w;
+          AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + D + dt * 16 + 4 * g), w);
           u32x2_t x; x[0] = pack2bf(adv[dt][0], adv[dt][1]); x[1] = pack2bf(adv[dt][2], adv[dt][3]);
-          *(u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g) = x;
+          AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g), x);
         }
       }
       // qkv-bias gradient, k and v parts, without the 2 x 64 cross-lane sums per wave the accumulators would need:

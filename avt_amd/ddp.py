@@ -117,9 +117,10 @@ class GradReducer:
     def _exchange(self, buf):
         n = buf.numel()
         self.bytes_on_wire += n * buf.element_size()
-        if self.mode == 'rs_ag':
-            if n % self.world:
-                raise ValueError(f'rs_ag: bucket of {n} elements does not split over {self.world} ranks')
+        if self.mode == 'rs_ag' and n % self.world == 0:
+            # (bucket edges are multiples of 64 * world; only the tail bucket [0, _sent) that finish() sends can fail to divide
+            #  -- the arena's size is a multiple of 64, not of 64 * world, e.g. on 3, 5, 6 or 7 ranks -- and goes out as a plain
+            #  all-reduce below: the same sum)
             shard = buf.view(self.world, n // self.world)[dist.get_rank(self.group)]       # in place: the rank's own chunk
             dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group)
             src = shard if dist.get_backend(self.group) == 'nccl' else shard.clone()       # only RCCL gathers in place

@@ -45,22 +45,38 @@ class BasicLossAccuracy(nn.Module):
             raise NotImplementedError('balance_classes (class-weighted CE) is outside the accelerated path')
         self.xent = MultiDimCrossEntropy(ignore_index=IGNORE, reduction='none')
 
-    def _score(self, logits, labels, want_accuracy):
+    def _score(self, logits, labels, want_accuracy, done=None):
         if logits.shape[:-1] != labels.shape:
             raise ValueError(f'logits {tuple(logits.shape)} do not line up with labels {tuple(labels.shape)}')
-        loss, rank = self.xent.forward_with_rank(logits, labels)
+        loss, rank = done if done is not None else self.xent.forward_with_rank(logits, labels)
         if not want_accuracy:
             return loss, None
         return loss, utils.accuracy_from_rank(rank, labels, topk=(1, min(5, logits.size(-1))))
 
-    def forward(self, outputs, target, target_subclips):
+    @staticmethod
+    def labels_per_group(target, target_subclips):
+        """{target type: {output key prefix: labels}}: what every logits tensor of the model will be scored against -- the clip
+        label for the future rows, the mode of the per-frame labels for the past rows (func/train_eval_ops.py:46-77).  The
+        training operator hands this to the model so that classifier and cross entropy run as one node."""
+        out = {}
+        for ttype, labels in target.items():
+            out[ttype] = {'': labels}
+            if target_subclips is not None and ttype in target_subclips:
+                out[ttype][PAST_LOGITS_PREFIX] = _row_mode(target_subclips[ttype])
+        return out
+
+    def forward(self, outputs, target, target_subclips, scored=None):
+        """scored: {(key prefix, type): (un-reduced loss, rank)} already produced by the model's fused classifier + CE nodes for
+        exactly the labels of ``labels_per_group`` (BaseModel.take_scored()); anything missing is scored here."""
+        scored = scored or {}
+        groups = self.labels_per_group(target, target_subclips)
         losses, accuracies = {}, {}
         for ttype, labels in target.items():
-            losses[f'cls_{ttype}'], (top1, top5) = self._score(outputs[f'logits/{ttype}'], labels, True)
+            losses[f'cls_{ttype}'], (top1, top5) = self._score(outputs[f'logits/{ttype}'], labels, True, scored.get(('', ttype)))
             accuracies[f'acc1/{ttype}'], accuracies[f'acc5/{ttype}'] = top1, top5
             past = outputs.get(f'{PAST_LOGITS_PREFIX}logits/{ttype}')
-            if past is not None and target_subclips is not None:
-                losses[f'past_cls_{ttype}'], _ = self._score(past, _row_mode(target_subclips[ttype]), False)
+            if past is not None and PAST_LOGITS_PREFIX in groups[ttype]:
+                losses[f'past_cls_{ttype}'], _ = self._score(past, groups[ttype][PAST_LOGITS_PREFIX], False, scored.get((PAST_LOGITS_PREFIX, ttype)))
         return losses, accuracies
 
 
@@ -82,6 +98,19 @@ class Basic:
         target = self._to_device(data['target'])
         subclips = self._to_device(data['target_subclips']) if 'target_subclips' in data else None
         some_target = next(iter(target.values()))
-        outputs, aux_losses = self.model(data['video'].to(self.device, non_blocking=True), target_shape=some_target.shape)
-        losses, accuracies = self.cls_loss_acc_fn(outputs, target, subclips)
+        video = data['video'].to(self.device, non_blocking=True)
+        # training: the model gets the labels, so its classifier, the dropout in front of it and the cross entropy run as ONE
+        # autograd node (HipLinear.forward_with_loss -> avt_linear_softmax_xent_fwd / _bwd); the loss module then only reduces
+        fuse = (train_mode and torch.is_grad_enabled() and isinstance(self.cls_loss_acc_fn, BasicLossAccuracy)
+                and hasattr(self._bare_model(), 'take_scored'))
+        if fuse:
+            outputs, aux_losses = self.model(video, target_shape=some_target.shape,
+                                             cls_targets=self.cls_loss_acc_fn.labels_per_group(target, subclips))
+            losses, accuracies = self.cls_loss_acc_fn(outputs, target, subclips, scored=self._bare_model().take_scored())
+        else:
+            outputs, aux_losses = self.model(video, target_shape=some_target.shape)
+            losses, accuracies = self.cls_loss_acc_fn(outputs, target, subclips)
         return data, outputs, {**losses, **aux_losses}, accuracies
+
+    def _bare_model(self):
+        return getattr(self.model, 'module', self.model)          # a DistributedDataParallel-style wrapper keeps the model in .module

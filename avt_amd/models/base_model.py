@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from ..arena import get_arena
 from ..config import instantiate
+from .classifiers import DeviceDropout, HipLinear, fresh_seed
 
 CLS_MAP_PREFIX = 'cls_map_'
 PAST_LOGITS_PREFIX = 'past_'
@@ -31,6 +32,11 @@ _UNSUPPORTED = (
     ('project_dim_for_nce', lambda v: v is not None, 'projection MLP of the contrastive SSL variant'),
     ('add_regression_head', bool, 'regression head of the dense-anticipation variant'),
 )
+
+
+def _apply_dropout(rows, p, seed):
+    from .classifiers import _DropFn
+    return _DropFn.apply(rows, p, seed)
 
 
 def _mean_over_crops(dicts):
@@ -71,7 +77,7 @@ class BaseModel(nn.Module):
         self.temporal_aggregator_after_future_pred = instantiate(model_cfg.temporal_aggregator_after_future_pred,
                                                                  self.future_predictor.output_dim)
         width = self.temporal_aggregator_after_future_pred.output_dim
-        self.dropout = nn.Dropout(model_cfg.dropout)
+        self.dropout = DeviceDropout(model_cfg.dropout)          # nn.Dropout's place (no parameters), masks from the kernels' counter-based RNG
         # one trained classifier per target type; with use_cls_mappings only the first type is trained and the others are
         # read off it through the (src, dst) mapping matrices
         trained = list(self.num_classes.items())[:1] if model_cfg.use_cls_mappings else list(self.num_classes.items())
@@ -106,16 +112,42 @@ class BaseModel(nn.Module):
             super().zero_grad(set_to_none=set_to_none)
 
     # ---- classifier over any number of row groups in one launch ----------------------------------------------------
-    def _logits(self, groups):
+    def _logits(self, groups, cls_targets=None):
         """groups: [(key prefix, features (..., D))].  Dropout + every trained classifier run ONCE over the concatenated rows
         (the reference runs them per group, models/base_model.py:203-216; eval results are identical, training masks are
-        drawn in one call instead of two).  Mapped target types are a matmul on the source logits."""
+        drawn in one call instead of two).  Mapped target types are a matmul on the source logits.
+        cls_targets: {target type: {key prefix: labels (...)}} from the training operator.  For a type with labels the
+        classifier, the dropout in front of it and the cross entropy run as ONE autograd node (HipLinear.forward_with_loss);
+        its un-reduced loss and target rank per row group are left in ``self._scored[(prefix, type)]`` for the loss module."""
         flat = [f.reshape(-1, f.size(-1)) for _, f in groups]
         counts = [f.size(0) for f in flat]
-        rows = self.dropout(flat[0] if len(flat) == 1 else torch.cat(flat, dim=0))
+        rows = flat[0] if len(flat) == 1 else torch.cat(flat, dim=0)
+        self._scored = {}
+        fused = {}
+        for ttype, head in self.classifiers.items():
+            given = (cls_targets or {}).get(ttype)
+            if given is None or not isinstance(head, HipLinear) or not torch.is_grad_enabled():
+                continue
+            labels = [given.get(prefix) for prefix, _ in groups]
+            if any(l is not None and l.shape != f.shape[:-1] for l, (_, f) in zip(labels, groups)):
+                continue                                       # the loss module will say what does not line up
+            fused[ttype] = torch.cat([(l.reshape(-1).long() if l is not None else torch.full((n,), -1, device=rows.device, dtype=torch.long))
+                                      for l, n in zip(labels, counts)])
+        drop = (self.dropout.p, fresh_seed()) if (self.training and self.dropout.p > 0.0) else (0.0, 0)
+        self.dropout.last_seed = drop[1]
+        dropped = None
         out = {}
         for ttype, head in self.classifiers.items():
-            for (prefix, feats), piece in zip(groups, head(rows).split(counts, dim=0)):
+            if ttype in fused:
+                logits, loss, rank = head.forward_with_loss(rows, fused[ttype], -1, drop_p=drop[0], drop_seed=drop[1])
+                for (prefix, feats), lo, rk in zip(groups, loss.split(counts), rank.split(counts)):
+                    if cls_targets[ttype].get(prefix) is not None:
+                        self._scored[(prefix, ttype)] = (lo.reshape(feats.shape[:-1]), rk.reshape(feats.shape[:-1]))
+            else:
+                if dropped is None:                             # same mask as the fused heads (one dropout for all classifiers)
+                    dropped = rows if drop[0] == 0.0 else _apply_dropout(rows, *drop)
+                logits = head(dropped)
+            for (prefix, feats), piece in zip(groups, logits.split(counts, dim=0)):
                 out[f'{prefix}logits/{ttype}'] = piece.reshape(feats.shape[:-1] + (piece.size(-1),))
         src = next(iter(self.classifiers))
         for ttype in self.num_classes:
@@ -125,8 +157,13 @@ class BaseModel(nn.Module):
                     out[f'{prefix}logits/{ttype}'] = out[f'{prefix}logits/{src}'] @ mapping
         return out
 
+    def take_scored(self):
+        """{(key prefix, target type): (un-reduced loss, target rank)} of the last forward's fused classifier + CE nodes; cleared."""
+        scored, self._scored = getattr(self, '_scored', {}), {}
+        return scored
+
     # ---- one crop ----------------------------------------------------------------------------------------------------
-    def forward_singlecrop(self, video, target_shape=None):
+    def forward_singlecrop(self, video, target_shape=None, cls_targets=None):
         """video (B, #clips, C, T, H, W) -> (outputs, aux losses); key set of models/base_model.py:140-201."""
         B, n_clips = video.shape[:2]
         out, aux = {}, {}
@@ -155,7 +192,7 @@ class BaseModel(nn.Module):
         groups = [('', future_agg)]
         if self.classifier_on_past:
             groups.insert(0, (PAST_LOGITS_PREFIX, past))
-        out.update(self._logits(groups))
+        out.update(self._logits(groups, cls_targets))
         return out, aux
 
     # ---- any number of crops ---------------------------------------------------------------------------------------
@@ -170,5 +207,7 @@ class BaseModel(nn.Module):
             if torch.is_grad_enabled():
                 arena.attach_grads()
         crops = [video] if video.ndim == 6 else [video[:, :, c] for c in range(video.size(2))]
+        if len(crops) > 1:
+            kwargs.pop('cls_targets', None)       # multi-crop: the loss is taken on the crop-averaged logits, not per crop
         results = [self.forward_singlecrop(crop, *args, **kwargs) for crop in crops]
         return _mean_over_crops([r[0] for r in results]), _mean_over_crops([r[1] for r in results])

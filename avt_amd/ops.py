@@ -425,9 +425,12 @@ def video_preproc(src_u8, params, out_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), s
 
 
 def video_preproc_jitter(src_u8, params, jitter_ops, jitter_factors, out_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5),
-                         reverse_channels=False):
+                         reverse_channels=False, max_hw=None, slot_mask=None):
     """video_preproc with ColorJitterVideo: jitter_ops int32 (Bout, 4) in application order (0 brightness, 1 contrast, 2 saturation, 3 hue,
-    -1 none), jitter_factors fp32 (Bout, 4) (hue: the 8-bit shift).  The resized clips go through an 8-bit scratch buffer."""
+    -1 none), jitter_factors fp32 (Bout, 4) (hue: the 8-bit shift).  The resized clips go through an 8-bit scratch buffer.
+    max_hw = (max new_h, max new_w) over the clips and slot_mask (bit s: slot s used by some clip, bit 4 + s: by a contrast operation)
+    are what the caller that built ``params`` / ``jitter_ops`` on the host already knows (GpuClipTransform passes them: no device ->
+    host read, no launches for empty slots); left None they are read back from the device tensors (one small synchronising copy)."""
     import ctypes
     _chk(src_u8, torch.uint8, 'src'); _chk(params, torch.int32, 'params'); _chk(jitter_ops, torch.int32, 'jitter_ops'); _chk(jitter_factors, torch.float32, 'jitter_factors')
     assert src_u8.dim() == 5 and src_u8.size(-1) == 3 and src_u8.is_contiguous() and params.is_contiguous()
@@ -435,15 +438,19 @@ def video_preproc_jitter(src_u8, params, jitter_ops, jitter_factors, out_hw, sca
     OH, OW = out_hw
     B = params.size(0)
     assert params.shape == (B, 6) and jitter_ops.shape == (B, 4) and jitter_factors.shape == (B, 4)
-    hw = params[:, :2].max(dim=0).values.tolist()                   # one small device -> host read: the scratch pitch
-    max_h, max_w = int(hw[0]), int(hw[1])
+    if max_hw is None:
+        max_hw = params[:, :2].max(dim=0).values.tolist()           # device -> host read (callers with host-side params pass max_hw)
+    max_h, max_w = int(max_hw[0]), int(max_hw[1])
+    if slot_mask is None:
+        host_ops = jitter_ops.cpu()
+        slot_mask = sum(((1 << s) if bool((host_ops[:, s] >= 0).any()) else 0) | ((16 << s) if bool((host_ops[:, s] == 1).any()) else 0) for s in range(4))
     scratch = torch.empty(_lib.load().avt_video_jitter_scratch_bytes(B, T, max_h, max_w), device=src_u8.device, dtype=torch.uint8)
     sums = torch.zeros(B, device=src_u8.device, dtype=torch.int64)
     out = torch.empty((B, T, 3, 1, OH, OW), device=src_u8.device, dtype=torch.float32)
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
     _lib.call('avt_video_preproc_jitter_u8', _p(src_u8), _p(out), _p(params), _p(jitter_ops.contiguous()), _p(jitter_factors.contiguous()), B, T, H, W,
               OH, OW, max_h, max_w, float(scale_pix), ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p), int(reverse_channels),
-              _p(scratch), scratch.numel(), _p(sums), _stream())
+              int(slot_mask), _p(scratch), scratch.numel(), _p(sums), _stream())
     return out
 
 
@@ -481,16 +488,23 @@ def linear_softmax_xent_fwd(x, w, bias, target, C, ignore_index=-1):
     return logits, loss, lse, rank
 
 
-def linear_softmax_xent_bwd(logits, target, lse, gloss, x, w, C, dw=None, dbias=None, want_dx=True, dx_f32=True, ignore_index=-1):
-    """Backward of linear_softmax_xent_fwd: accumulates into dw [Cpad, K] / dbias [Cpad] (fp32) and returns dx [R, K] (or None)."""
+def linear_softmax_xent_bwd(logits, target, lse, gloss, x, w, C, dw=None, dbias=None, want_dx=True, dx_f32=True, ignore_index=-1,
+                            glogits=None, dx_drop_p=0.0, dx_drop_seed=0):
+    """Backward of linear_softmax_xent_fwd: accumulates into dw [Cpad, K] / dbias [Cpad] (fp32) and returns dx [R, K] (or None).
+    glogits: fp32 [R, >=C] gradient that reached the logits from another consumer (added into dlogits before its bf16 cut).
+    dx_drop_p / dx_drop_seed: mask of the dropout in front of the classifier, applied to dx in the dgrad GEMM's epilogue."""
     R, K = x.shape
     Cpad = w.size(0)
     dlogits = torch.empty((R, Cpad), device=x.device, dtype=BF16)
     dx = torch.empty((R, K), device=x.device, dtype=torch.float32 if dx_f32 else BF16) if want_dx else None
     ws = _wgrad_workspace(x.device, _lib.load().avt_gemm_accum_workspace_bytes(Cpad, K, R)) if dw is not None else None
     part, part_bytes = _partials(x.device, 'avt_colsum_workspace_bytes', R, Cpad) if dbias is not None else (None, 0)
-    _lib.call('avt_linear_softmax_xent_bwd', _p(logits), _ld(logits), _p(target), _p(lse), _p(gloss), _p(x), _ld(x), _p(w), _ld(w), _p(dlogits),
-              _p(dw), _ld(dw) if dw is not None else 0, _p(dbias), _p(dx), _ld(dx) if dx is not None else 0, int(dx_f32), R, C, Cpad, K,
+    if glogits is not None:
+        _chk(glogits, torch.float32, 'glogits')
+    _lib.call('avt_linear_softmax_xent_bwd', _p(logits), _ld(logits), _p(target), _p(lse), _p(gloss), _p(glogits),
+              _ld(glogits) if glogits is not None else 0, _p(x), _ld(x), _p(w), _ld(w), _p(dlogits),
+              _p(dw), _ld(dw) if dw is not None else 0, _p(dbias), _p(dx), _ld(dx) if dx is not None else 0, int(dx_f32),
+              float(dx_drop_p), int(dx_drop_seed), R, C, Cpad, K,
               ignore_index, _p(ws), ws.numel() if ws is not None else 0, part, part_bytes, _stream())
     return dx
 

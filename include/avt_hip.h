@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 4
+#define AVT_ABI_VERSION 5
 
 const char* avt_last_error(void);
 int avt_abi_version(void);
@@ -194,10 +194,13 @@ int avt_video_preproc_u8(const void* src, float* dst, const int* params, int B, 
  * 0 brightness | 1 contrast | 2 saturation (ImageEnhance = Image.blend with black | the clip's mean grey | the pixel's grey) | 3 hue
  * (8-bit HSV round trip) | -1 none; jitter_factors: fp32 [B][4], the blend factor, or for hue the 8-bit shift (int)(hue_factor * 255) & 255.
  * max_h / max_w >= every clip's new_h / new_w: pitch of the 8-bit `scratch` (avt_video_jitter_scratch_bytes); luma_sums: B x uint64 scratch.
- * Bit-exact against Pillow (tests/golden/g11_color_jitter.npz, generated through the reference's own wrapper). */
+ * slot_mask: what the host knows about the device-side op table -- bit s (0..3) = some clip has an operation in slot s (other slots
+ * are skipped), bit 4 + s = some clip's operation in slot s is contrast (only then is the clip's mean luma computed); 0xff = unknown.
+ * Bit-exact against Pillow (tests/golden/g11_color_jitter.npz, generated through the reference's own wrapper; the HSV round trip
+ * exhaustively over all 2^24 colours, tests/test_ops_gpu.py). */
 int avt_video_preproc_jitter_u8(const void* src, float* dst, const int* params, const int* jitter_ops, const float* jitter_factors,
                                 int B, int T, int H, int W, int OH, int OW, int max_h, int max_w, float scale_pix,
-                                const float* mean3, const float* std3, int reverse_channels,
+                                const float* mean3, const float* std3, int reverse_channels, int slot_mask,
                                 void* scratch, size_t scratch_bytes, unsigned long long* luma_sums, void* stream);
 size_t avt_video_jitter_scratch_bytes(int B, int T, int max_h, int max_w);
 
@@ -216,15 +219,22 @@ int avt_xent_bwd(const float* logits, int ld, const long* target, const float* l
  * fwd: logits[R, ldl >= Cpad] (fp32) = x[R,K] W[Cpad,K]^T + bias[Cpad];  loss[r] = lse[r] - logits[r, target[r]] (0 where target ==
  *      ignore_index), lse[r], rank[r] = number of logits above the target's (-1 where ignored; may be NULL).  C valid classes, the
  *      weight / bias rows C..Cpad-1 are zero padding (Cpad % 8 == 0).
- * bwd: dlogits = (softmax - onehot) * gloss[r] written ONCE as bf16 [R, Cpad] (caller scratch, zero padding columns) and consumed
+ * bwd: dlogits = (softmax - onehot) * gloss[r] (+ glogits[r, :C], fp32 [R, ldg], a gradient that reached the logits from another
+ *      consumer; may be NULL) written ONCE as bf16 [R, Cpad] (caller scratch, zero padding columns) and consumed
  *      in place by  dw[Cpad,K] (fp32) += dlogits^T x  (deterministic split-K: `workspace` of avt_gemm_accum_workspace_bytes(Cpad,K,R)),
- *      dbias[Cpad] += column sums (`partials`: see above),  dx[R,K] = dlogits W  (bf16, or fp32 when dx_f32).  dw / dbias / dx may be NULL. */
+ *      dbias[Cpad] += column sums (`partials`: see above),  dx[R,K] = dlogits W  (bf16, or fp32 when dx_f32), passed through the mask
+ *      of the dropout that preceded the classifier when dx_drop_p > 0 (keep(seed, r*K + k), the mask avt_dropout_bf16 draws; the
+ *      reference's nn.Dropout in front of the classifier, models/base_model.py:87-97).  dw / dbias / dx may be NULL.
+ * The drop-in model runs exactly this pair as ONE autograd node when the training operator hands it the targets
+ * (avt_amd/models/classifiers.py::HipLinear.forward_with_loss, avt_amd/func/train_eval_ops.py::Basic). */
 int avt_linear_softmax_xent_fwd(const void* x, int ldx, const void* w, int ldw, const float* bias, const long* target,
                                 float* logits, int ldl, float* loss, float* lse, int* rank,
                                 int R, int C, int Cpad, int K, long ignore_index, void* stream);
 int avt_linear_softmax_xent_bwd(const float* logits, int ldl, const long* target, const float* lse, const float* gloss,
+                                const float* glogits, int ldg,
                                 const void* x, int ldx, const void* w, int ldw, void* dlogits_bf16,
                                 float* dw, int lddw, float* dbias, void* dx, int lddx, int dx_f32,
+                                float dx_drop_p, uint64_t dx_drop_seed,
                                 int R, int C, int Cpad, int K, long ignore_index,
                                 void* workspace, size_t workspace_bytes, float* partials, size_t partials_bytes, void* stream);
 

@@ -466,15 +466,19 @@ def pil_rgb2hsv(rgb):
 
 
 def pil_hsv2rgb(hsv):
-    """Convert.c hsv2rgb_row: sextant i = floor(6 h / 255), p / q / t rounded to nearest."""
-    h = hsv[..., 0].astype(np.float32) * np.float32(6.0) / np.float32(255.0)
-    fs = hsv[..., 1].astype(np.float32) / np.float32(255.0)
+    """Convert.c hsv2rgb_row, with C's promotions spelled out: ``(float)h * 6.0 / 255.0`` is double arithmetic, ``f`` and ``fs`` are
+    stored as floats, ``fs * f`` is a float product, everything inside ``round()`` is double, and ``round`` is half away from zero.
+    Pinned exhaustively (all 2^24 triples) against Pillow 12.2.0 by tests/test_oracle_cpu.py."""
+    hd = hsv[..., 0].astype(np.float32).astype(np.float64) * 6.0 / 255.0
+    i = np.floor(hd).astype(np.int32)
+    f = (hd - i.astype(np.float32).astype(np.float64)).astype(np.float32)
+    fs = (hsv[..., 1].astype(np.float32).astype(np.float64) / 255.0).astype(np.float32)
     v = hsv[..., 2].astype(np.int32)
-    i = np.floor(h).astype(np.int32)
-    f = h - i.astype(np.float32)
-    fv = v.astype(np.float32)
-    rnd = lambda x: np.clip(np.round(x).astype(np.int32), 0, 255)
-    pp, q, t = rnd(fv * (1 - fs)), rnd(fv * (1 - fs * f)), rnd(fv * (1 - fs * (1 - f)))
+    fv = v.astype(np.float64)
+    rnd = lambda x: np.clip(np.floor(x + 0.5).astype(np.int32), 0, 255)           # round(): half away from zero (arguments are >= 0)
+    pp = rnd(fv * (1.0 - fs.astype(np.float64)))
+    q = rnd(fv * (1.0 - (fs * f).astype(np.float64)))                              # fs * f: float * float
+    t = rnd(fv * (1.0 - fs.astype(np.float64) * (1.0 - f.astype(np.float64))))
     i = i % 6
     out = np.stack([np.choose(i, [v, q, pp, pp, t, v]), np.choose(i, [t, v, v, q, pp, pp]), np.choose(i, [pp, pp, t, v, v, q])], -1)
     return np.where((hsv[..., 1] == 0)[..., None], np.repeat(v[..., None], 3, -1), out).astype(np.uint8)

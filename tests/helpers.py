@@ -128,3 +128,23 @@ def give_oracle_the_hip_masks(orc, seed, p):
         blk.attn.attn_dropout = FixedMaskDropout(p, s0 + 1)
         blk.attn.resid_dropout = FixedMaskDropout(p, s0 + 2)
         blk.mlp.dropout = FixedMaskDropout(p, s0 + 3)
+
+
+class SequencedMaskDropout(torch.nn.Module):
+    """The classifier dropout of the HIP model restated for the oracle.  The HIP model draws ONE mask over the concatenated
+    [past rows; future rows] x D matrix (avt_amd/models/base_model.py::_logits: element index = row * D + column); the
+    oracle applies its dropout to the past rows first and to the future rows second (models/base_model.py:203-216), so the
+    n-th call of a forward takes the next slice of that mask.  ``reset()`` before every oracle forward."""
+    def __init__(self, p, seed):
+        super().__init__()
+        self.p, self.seed, self.offset = p, seed, 0
+
+    def reset(self):
+        self.offset = 0
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        keep = rng_keep_mask(self.seed, self.offset + x.numel(), self.p)[self.offset:].view(x.shape)
+        self.offset += x.numel()
+        return x * keep * float(np.float32(1.0) / (np.float32(1.0) - np.float32(self.p)))

@@ -423,6 +423,100 @@ def test_dropout_on_training_step_matches_the_oracle_given_the_same_masks():
     assert not bad, bad[:10]
 
 
+def test_dropout_on_step_at_the_bench_head_matches_the_oracle_given_the_same_masks():
+    """Round 4: the step bench.py times, at its real head -- 768 -> AVT-h 2048 x 6 layers x 4 heads -> 3806 classes, T = 10, the
+    head's dropouts (p = 0.1) AND the classifier's dropout (p = 0.2, since round 4 drawn from the same counter-based device RNG,
+    one mask over the concatenated past + future rows) all ON -- against the fp32 oracle given exactly those masks
+    (tests/helpers.py restates the hash on the host), at the standard limits of the dropout-free tests."""
+    import itertools
+    from helpers import SequencedMaskDropout, give_oracle_the_hip_masks
+    from avt_amd.models.future_prediction import AVTh
+    IN, DH, L, H, C, B, T, P, PC = 768, 2048, 6, 4, 3806, 4, 10, 0.1, 0.2
+    torch.manual_seed(4321)
+    orc = build_oracle_model('feat', IN, DH, L, H, C)
+    _fill(orc)
+    model = build_hip_model('feat', IN, DH, L, H, C, head_drop=P, dropout=PC)
+    model.load_state_dict(orc.state_dict())
+    AVTh._seed_counter = itertools.count(11)
+    seed = (11 * 1000003 + torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+    from oracle.make_golden import synth_batch
+    video, target, sub = synth_batch(B, T, C, (IN, 1, 1, 1), seed=21)
+    out, losses, _, tot = hip_step(model, video.cuda(), target.cuda(), sub.cuda())
+    assert model.dropout.last_seed != 0
+    give_oracle_the_hip_masks(orc, seed, P)
+    orc.dropout = SequencedMaskDropout(PC, model.dropout.last_seed)
+    orc.train()
+    # the classifier mask bites: with the head's masks only, the logits are far away
+    orc.dropout.p = 0.0
+    n_out, _, _, _ = oracle_step(orc, video, target, sub)
+    orc.dropout.p = PC; orc.dropout.reset()
+    o_out, o_losses, _, o_tot = oracle_step(orc, video, target, sub)
+    assert rel(n_out['logits/action'], o_out['logits/action']) > 5e-2
+    assert rel(out['logits/action'], o_out['logits/action']) < TOL_OUT
+    assert rel(out['past_logits/action'], o_out['past_logits/action']) < TOL_OUT
+    assert rel(out['future'], o_out['future']) < TOL_OUT and rel(out['past'], o_out['past']) < TOL_OUT
+    for k in ['cls_action', 'past_cls_action', 'feat']:
+        assert rel(losses[k], o_losses[k]) < 3e-2, k
+    assert abs(float(tot) - float(o_tot)) / abs(float(o_tot)) < 3e-2
+    rows = _grad_report(model, orc)
+    assert len(rows) > 70
+    print('worst max-abs %s\nworst rel-L2 %s\nworst cosine %s' % (max(rows, key=lambda r: r[1]), max(rows, key=lambda r: r[2]), min(rows, key=lambda r: r[3])))
+    bad = [r for r in rows if r[1] > 4e-2 or r[2] > 3e-2 or r[3] < 0.999]
+    assert not bad, bad[:10]
+
+
+def test_one_node_classifier_loss_equals_the_two_node_path():
+    """Training through ``Basic`` runs dropout -> classifier -> cross entropy as ONE autograd node (the labels travel to the model,
+    HipLinear.forward_with_loss -> avt_linear_softmax_xent_fwd / _bwd); a caller that takes the logits from ``BaseModel`` and scores
+    them with ``BasicLossAccuracy`` itself gets two nodes.  Same kernels on the same values: identical losses and accuracies,
+    gradients equal up to the fp32 summation order of the deterministic split-K."""
+    from avt_amd.config import Cfg
+    from avt_amd.func.train_eval_ops import Basic, BasicLossAccuracy
+    from oracle.make_golden import synth_batch
+    IN, DH, L, H, C, B, T = 64, 128, 2, 4, 37, 3, 5
+    torch.manual_seed(7)
+    model = build_hip_model('feat', IN, DH, L, H, C)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.2)
+    video, target, sub = synth_batch(B, T, C, (IN, 1, 1, 1), seed=3)
+    video, target, sub = video.cuda(), target.cuda(), sub.cuda()
+    out1, losses1, accs1, tot1 = hip_step(model, video, target, sub)
+    assert not model.take_scored()                              # consumed by the loss module
+    g1 = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad()
+    model.train()
+    out2, aux2 = model(video, target_shape=target.shape)
+    losses2, accs2 = BasicLossAccuracy()(out2, {'action': target}, {'action': sub})
+    losses2.update(aux2)
+    tot2 = sum(LOSS_WTS[k] * v.mean() for k, v in losses2.items())
+    tot2.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(out1['logits/action'], out2['logits/action']) and torch.equal(out1['past_logits/action'], out2['past_logits/action'])
+    for k in losses2:
+        assert torch.equal(losses1[k], losses2[k]), k
+    for k in accs2:
+        assert float(accs1[k]) == float(accs2[k]), k
+    for n, p in model.named_parameters():
+        assert rel(p.grad, g1[n]) < 1e-5, n
+    # a second loss on the logits themselves reaches the node as a gradient of its logits output and is added in
+    model.zero_grad()
+    op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
+    _, out3, losses3, _ = op({'video': video, 'target': {'action': target}, 'target_subclips': {'action': sub}}, train_mode=True)
+    extra = lambda o: 0.3 * (o['logits/action'] ** 2).mean() + 0.1 * o['past_logits/action'].sum(-1).mean()
+    (sum(LOSS_WTS[k] * v.mean() for k, v in losses3.items()) + extra(out3)).backward()
+    g3 = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad()
+    out4, aux4 = model(video, target_shape=target.shape)
+    losses4, _ = BasicLossAccuracy()(out4, {'action': target}, {'action': sub})
+    losses4.update(aux4)
+    (sum(LOSS_WTS[k] * v.mean() for k, v in losses4.items()) + extra(out4)).backward()
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():
+        assert rel(p.grad, g3[n]) < 2e-2, n                      # (the two-node path rounds the summed fp32 gradient to bf16 once more)
+
+
 # ---- round 2: eval path (SURVEY 8f-1) ----------------------------------------------------------------------------------------
 def test_g6a_multicrop_rollout_tiny_vit_vs_reference_golden(golden_dir):
     """7-D multi-crop video (3 crops averaged, models/base_model.py:251-273) + KV-cache roll-out (output_len_eval = 3,

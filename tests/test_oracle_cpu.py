@@ -296,3 +296,16 @@ def test_pil_restatement_against_the_pillow_in_this_image():
             img = tv_adjust(img, n, f)
         mine = O.pil_color_jitter(a, ops_)
         assert np.array_equal(mine, np.array(img)), (trial, ops_, int(np.abs(mine.astype(int) - np.array(img).astype(int)).max()))
+
+
+def test_oracle_hsv_conversions_equal_pillow_on_every_colour():
+    """oracle/avt_oracle.py::pil_rgb2hsv / pil_hsv2rgb against Pillow itself (Convert.c) on all 2^24 triples -- the pin behind the device
+    kernels' exhaustive test.  (Round-3 advisor finding: a float32 / round-half-even restatement of hsv2rgb_row was one level off on 2
+    triples, e.g. (201, 199, 206) -> R 162 instead of 163.)"""
+    Image = pytest.importorskip('PIL.Image')
+    import numpy as np
+    from oracle import avt_oracle as O
+    a, b, c = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing='ij')
+    cube = np.stack([a, b, c], -1).reshape(4096, 4096, 3)
+    assert np.array_equal(O.pil_hsv2rgb(cube), np.asarray(Image.fromarray(cube, 'HSV').convert('RGB')))
+    assert np.array_equal(O.pil_rgb2hsv(cube), np.asarray(Image.fromarray(cube, 'RGB').convert('HSV')))
