@@ -19,7 +19,7 @@ from .arena import ParamArena
 
 class GradReducer:
     def __init__(self, model, bucket_bytes=64 << 20, process_group=None, overlap=True, always=False, mode='all_reduce',
-                 wire_dtype=torch.float32):
+                 wire_dtype=torch.float32, tail_bytes=None):
         self.model = model
         self.arena: ParamArena = model.arena
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -39,7 +39,13 @@ class GradReducer:
         self.wire_dtype = wire_dtype
         quantum = 64 * max(self.world, 1)
         self.bucket_elems = max(bucket_bytes // 4 // quantum, 1) * quantum
+        # The exchange that cannot hide behind backward is the LAST one (sent by finish(), after the first layers' backward).  Keep it
+        # small: as soon as the not-yet-produced head of the buffer is at most ``tail_bytes`` (default: half a bucket -- at 64 MiB that
+        # is the ViT's patch embedding + block 0, 31.5 MB), everything produced so far goes out at once instead of waiting for a
+        # full bucket, so finish() only has that head left.
+        self.tail_elems = (bucket_bytes // 2 if tail_bytes is None else tail_bytes) // 4
         self.overlap = overlap
+        self.paused = False                 # True: no exchange at all (bench: the same step without collectives in flight)
         self.comm_stream = torch.cuda.Stream() if self.arena.grad.is_cuda else None
         self._lo = self.arena.total         # everything in [_lo, total) has been produced
         self._sent = self.arena.total       # everything in [_sent, total) has been handed to the collective
@@ -87,9 +93,14 @@ class GradReducer:
             return
         start = a.offsets[a.name_of[id(first_param)]]
         self._lo = min(self._lo, start)
-        if (self.world > 1 or self.always) and self.overlap:
+        if (self.world > 1 or self.always) and self.overlap and not self.paused:
             while self._sent - self._lo >= self.bucket_elems:
                 self._launch(self._sent - self.bucket_elems, self._sent)
+            if 0 < self._lo <= self.tail_elems and self._sent > self._lo:
+                quantum = 64 * max(self.world, 1)
+                lo = (self._lo + quantum - 1) // quantum * quantum          # keep bucket edges on shard boundaries (rs_ag)
+                if lo < self._sent:
+                    self._launch(lo, self._sent)
 
     def _launch(self, s, e):
         a = self.arena
@@ -129,7 +140,7 @@ class GradReducer:
 
     def finish(self):
         """Reduce whatever is left (everything, if no hook fired) and order the compute stream after the collectives."""
-        if self.world <= 1 and not self.always:
+        if (self.world <= 1 and not self.always) or self.paused:
             return
         timed = self.comm_stream is not None
         if timed:

@@ -174,7 +174,7 @@ class Trainer:
     optional (``sync_loss``) because they stall the launch queue."""
     def __init__(self, model, train_eval_op, optimizer, lr_scheduler=None, loss_wts=None, distributed=False,
                  bucket_bytes=64 << 20, grad_clip=None, force_reducer=False, reduce_mode='all_reduce',
-                 wire_dtype=torch.float32):
+                 wire_dtype=torch.float32, tail_bytes=None):
         self.model, self.op, self.optimizer, self.lr_scheduler = model, train_eval_op, optimizer, lr_scheduler
         self.loss_wts = dict(loss_wts or {})
         self.fused = isinstance(optimizer, FusedSGD)
@@ -182,7 +182,8 @@ class Trainer:
         self.max_norm = gc.get('max_norm', None)                 # conf/config.yaml train_one_epoch_fn.grad_clip_params
         self.norm_type = float(gc.get('norm_type', 2.0))
         self.world = utils.get_world_size() if distributed else 1
-        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, always=force_reducer, mode=reduce_mode, wire_dtype=wire_dtype) if (self.world > 1 or force_reducer) else None
+        self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, always=force_reducer, mode=reduce_mode, wire_dtype=wire_dtype,
+                                   tail_bytes=tail_bytes) if (self.world > 1 or force_reducer) else None
         if self.reducer is not None:
             GradReducer.broadcast_parameters(model)
         self.last_losses = {}

@@ -12,7 +12,7 @@ ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_MUL_AUX = 0, 1, 2, 3       # with c2=
 OUT_BF16, OUT_F32, OUT_ACCUM_F32 = 0, 1, 2
 
 
-# When set to a list, every gemm() appends (variant, flops, start_event, end_event): bench.py's live roofline probe.
+# When set to a list, every gemm() appends (variant, flops, start_event, end_event, (M, N, K)): bench.py's live roofline probe.
 GEMM_TRACE = None
 FORCE_TILE = 0          # tests: route every auto-selected (tile=0) GEMM to one kernel, e.g. 808, to validate it inside the whole model
 
@@ -106,7 +106,7 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
               out_mode, splitk, tile, part, part_bytes, _stream())
     if trace is not None:
         ev1.record()
-        trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile), 2.0 * M * N * K, ev0, ev1))
+        trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile), 2.0 * M * N * K, ev0, ev1, (M, N, K)))
     return out
 
 
@@ -143,7 +143,7 @@ def gemm_accum(A, B, C, M, N, K):
         name = gemm_variant(M, N, K, False, False, OUT_ACCUM_F32, WGRAD_TILE if WGRAD_TILE != 2565 else 0).replace(',1>', ',2>')   # EPI 2 = slabs + ordered reduce
         if name.startswith('gemm_8p_kernel') and WGRAD_TILE in (0, 2565):
             name = 'gemm_w4_kernel<2>'                    # the library's default for 256x256-tile weight gradients
-        trace.append((name, 2.0 * M * N * K, ev0, ev1))
+        trace.append((name, 2.0 * M * N * K, ev0, ev1, (M, N, K)))
     return C
 
 

@@ -16,6 +16,10 @@ synthetic batch already resident in HBM.  Rank 0 prints ONE JSON lin
               / 2.5 PFLOP/s dense bf16.  ``dominant_kernel`` is the bf16 MFMA GEMM family measured live: 2*M*N*K
              of every launch in the timed region / their summed HIP-event durations.  ``traffic`` = HBM bytes per step from
              the committed rocprofv3 PMC pass over the same workload (profiles/pmc_step.json; null when none matches)
+  also       (N = 1) short runs of BASELINE configs 4 and 5 at their own architecture on this GPU, carried inside the same line:
+             T = 15 frames (128 clips) and ViT-L/16 (96 clips), 2 warm-up + 5 timed steps each -> value, ms_per_step, frac
+  comm       (N > 1) per-rank exchange accounting, the RCCL / NCCL environment knobs in effect, and the GEMM family's time per
+             step with and without collectives in flight (CU contention from RCCL's kernels shows up as the difference)
   cpu_baseline  the fp32 CPU oracle (a port of the reference's timm/HF path, oracle/avt_oracle.py) timed on this box's
              host cores on a bounded sample (B = 1 clip, 1 warm-up + 3 timed steps of fwd+bwd+SGD; min/max reported)
 """
@@ -94,7 +98,8 @@ def build(args, device, world):
     op = Basic(model, device, None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
     trainer = Trainer(model, op, opt, None, {'cls_action': 1.0, 'past_cls_action': 1.0, 'feat': 1.0}, distributed=world > 1,
                       bucket_bytes=args.bucket_mb << 20, reduce_mode=args.reduce_mode,
-                      wire_dtype=torch.bfloat16 if args.wire_dtype == 'bf16' else torch.float32)
+                      wire_dtype=torch.bfloat16 if args.wire_dtype == 'bf16' else torch.float32,
+                      tail_bytes=None if args.tail_mb < 0 else args.tail_mb << 20)
     rank = int(os.environ.get('RANK', 0))
     data = synthetic_batch(args.batch, args.frames, NUM_CLASSES, device, seed=42 + rank)
     return trainer, data
@@ -186,9 +191,17 @@ def main(argv=None):
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="'gloo' lets several ranks share one GPU (a functional check of the N > 1 path on a 1-GPU box; never a measurement)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-trace', action='store_true')
+    ap.add_argument('--no-also', action='store_true', help='skip the short T = 15 / ViT-L runs that the default N = 1 line carries in "also"')
+    ap.add_argument('--tail-mb', type=int, default=-1, help='the last (exposed) exchange is at most this many MiB of gradients (default: half a bucket)')
+    ap.add_argument('--nccl-max-nchannels', type=int, default=0, help='export NCCL_MAX_NCHANNELS before RCCL starts: fewer channels = fewer CUs taken from the GEMMs (0 = leave the environment alone)')
+    ap.add_argument('--nccl-min-nchannels', type=int, default=0, help='export NCCL_MIN_NCHANNELS before RCCL starts (0 = leave the environment alone)')
     argv = list(sys.argv[1:] if argv is None else argv)
     args = ap.parse_args(argv)
 
+    if args.nccl_max_nchannels > 0:
+        os.environ['NCCL_MAX_NCHANNELS'] = str(args.nccl_max_nchannels)           # read by RCCL when the communicator is created (below)
+    if args.nccl_min_nchannels > 0:
+        os.environ['NCCL_MIN_NCHANNELS'] = str(args.nccl_min_nchannels)
     world_env = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and 'RANK' not in os.environ:
         raise SystemExit(self_launch(args, argv))
@@ -203,63 +216,121 @@ def main(argv=None):
         local %= max(torch.cuda.device_count(), 1)             # ranks share the devices that exist
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
-    trainer, data = build(args, device, world)
-
     def sync():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.step(data)
-    sync()
-    trace = None if args.no_gemm_trace else []
-    ops.GEMM_TRACE = trace
+    def measure(a, steps, warmup, probe_no_comm=False):
+        """Build the model of configuration ``a``, run ``warmup`` untimed and ``steps`` timed steps; returns the raw numbers."""
+        trainer, data = build(a, device, world)
+        for _ in range(warmup):
+            trainer.step(data)
+        sync()
+        no_comm = None
+        if probe_no_comm and trainer.reducer is not None and not a.no_gemm_trace:
+            # the same step with the gradient exchange switched off: the GEMM family's time without RCCL's kernels on the CUs
+            # (3 untimed steps; the replicas drift apart meanwhile, so rank 0's parameters are broadcast again afterwards)
+            trainer.reducer.paused = True
+            ops.GEMM_TRACE = tr = []
+            for _ in range(3):
+                trainer.step(data)
+            sync()
+            ops.GEMM_TRACE = None
+            trainer.reducer.paused = False
+            no_comm = tr
+            trainer.reducer.broadcast_parameters(trainer.model)
+            trainer.step(data)
+            sync()
+        trace = None if a.no_gemm_trace else []
+        ops.GEMM_TRACE = trace
+        calls0 = _abi.N_CALLS
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, _, _, _ = trainer.step(data)
+        host_enqueue = time.perf_counter() - t0          # the Python side is done enqueuing; the GPU may still be running
+        sync()
+        elapsed_local = time.perf_counter() - t0
+        ops.GEMM_TRACE = None
+        res = {'elapsed_local': elapsed_local, 'host_enqueue': host_enqueue, 'abi_calls': _abi.N_CALLS - calls0, 'trace': trace,
+               'no_comm_trace': no_comm, 'loss': float(loss),
+               'comm': trainer.reducer.stats(last=steps) if trainer.reducer is not None else None}
+        del trainer, data
+        torch.cuda.empty_cache()
+        return res
+
     from avt_amd import lib as _abi
-    calls0 = _abi.N_CALLS
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _, _, _ = trainer.step(data)
-    host_enqueue = time.perf_counter() - t0          # the Python side is done enqueuing; the GPU may still be running
-    sync()
-    elapsed_local = time.perf_counter() - t0
-    abi_calls = _abi.N_CALLS - calls0
-    comm = trainer.reducer.stats(last=args.steps) if trainer.reducer is not None else None
+    m = measure(args, args.steps, args.warmup, probe_no_comm=True)
+    elapsed_local, host_enqueue, abi_calls, trace, comm, loss_val = (m['elapsed_local'], m['host_enqueue'], m['abi_calls'], m['trace'],
+                                                                      m['comm'], m['loss'])
     comm_all = [comm]
     if dist_on:
         comm_all = [None] * world
         dist.all_gather_object(comm_all, comm)
-    ops.GEMM_TRACE = None
     t = torch.tensor([elapsed_local], device=device, dtype=torch.float64)
     per_rank = [t.clone() for _ in range(world)]
     if dist_on:
         dist.all_gather(per_rank, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t)
-    loss_val = float(loss)
+
+    def gemm_rows(tr, steps, step_s):
+        """Group the traced GEMM launches by (kernel template, M, N, K): [(name, shape, launches/step, ms/step, TFLOP/s)]."""
+        groups = {}
+        for name, fl, e0, e1, shape in tr:
+            d = groups.setdefault((name, shape), [0.0, 0.0, 0])
+            d[0] += fl; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+        return [{'kernel': k[0], 'MNK': list(k[1]), 'launches_per_step': round(v[2] / steps, 1), 'ms_per_step': round(v[1] / steps * 1e3, 3),
+                 'tflops': round(v[0] / v[1] / 1e12, 1), 'share_of_step_time': round(v[1] / steps / step_s, 4)}
+                for k, v in groups.items() if v[1] > 0]
+
+    BIG = ('gemm_kernel<128', 'gemm_kernel<256', 'gemm_8p_kernel', 'gemm_w4_kernel', 'gemm_4w_kernel')
+
+    def roofline_of(a, clips_per_s, tr, steps, step_s):
+        D, L, _ = VIT[a.model]
+        fclip = flops_per_clip(D, L, a.frames)
+        step_tf = clips_per_s / world * fclip / 1e12
+        out = {'achieved': round(step_tf, 1), 'frac': round(step_tf / MFMA_PEAK_TFLOPS, 4),
+               'executed_frac': round(clips_per_s / world * (fclip - flops_skipped_per_clip(D, a.frames)) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+        if tr:
+            rows = [r for r in gemm_rows(tr, steps, step_s) if r['kernel'].startswith(BIG)]
+            fl = sum(r['tflops'] * r['ms_per_step'] for r in rows)            # TFLOP/s x ms = GFLOP per step
+            tm = sum(r['ms_per_step'] for r in rows)
+            if tm > 0:
+                large = [r for r in rows if r['share_of_step_time'] >= 0.02]
+                worst = min(large, key=lambda r: r['tflops']) if large else None
+                out['gemm_family'] = {'tflops': round(fl / tm, 1), 'frac': round(fl / tm / MFMA_PEAK_TFLOPS, 4), 'ms_per_step': round(tm, 2),
+                                      'share_of_step_time': round(tm * 1e-3 / step_s, 3)}
+                if worst is not None:
+                    out['worst_large_gemm_row'] = dict(worst, frac=round(worst['tflops'] / MFMA_PEAK_TFLOPS, 4),
+                                                       note='lowest-rate (kernel template, shape) group among those taking >= 2 % of the step')
+                out['rows'] = sorted(rows, key=lambda r: -r['ms_per_step'])[:8]
+        return out
 
     if rank == 0:
         D, L, _ = VIT[args.model]
         fclip = flops_per_clip(D, L, args.frames)
         clips = args.batch * world * args.steps / elapsed
+        step_s = elapsed / args.steps
         per_variant = {}
         if trace:
-            for name, fl, e0, e1 in trace:
+            for name, fl, e0, e1, _shape in trace:
                 d = per_variant.setdefault(name, [0.0, 0.0, 0])
                 d[0] += fl
                 d[1] += e0.elapsed_time(e1) * 1e-3
                 d[2] += 1
-        dom = {k: v for k, v in per_variant.items() if k.startswith(('gemm_kernel<128', 'gemm_kernel<256', 'gemm_8p_kernel', 'gemm_w4_kernel', 'gemm_4w_kernel'))}
+        dom = {k: v for k, v in per_variant.items() if k.startswith(BIG)}
         fl = sum(v[0] for v in dom.values())
         tm = sum(v[1] for v in dom.values())
         n_launch = sum(v[2] for v in dom.values())
         step_tf = clips / world * fclip / 1e12
         pmc = pmc_traffic(args)
+        rl = roofline_of(args, clips, trace, args.steps, step_s)
         roof = {'bound': 'mfma', 'scope': 'whole training step (fwd + bwd + SGD) per GPU: clips/s/GPU x algorithmic GFLOP/clip (SURVEY 8d)',
                 'achieved': round(step_tf, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(step_tf / MFMA_PEAK_TFLOPS, 4),
                 'frac_counts': 'algorithmic FLOPs (SURVEY 8d), including the part of the last ViT block that the CLS-only evaluation skips',
-                'executed_frac': round(clips / world * (fclip - flops_skipped_per_clip(D, args.frames)) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                'executed_frac': rl['executed_frac'],
                 'traffic': None if pmc is None else pmc['hbm_bytes_per_step'],
                 'traffic_source': None if pmc is None else pmc.get('source'),
                 'algorithmic_bytes_per_step': algorithmic_bytes_per_step(D, L, args.frames, args.batch),
@@ -274,7 +345,11 @@ def main(argv=None):
                 'achieved': round(ach, 1), 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4),
                 'launches': n_launch, 'avg_launch_us': round(tm / n_launch * 1e6, 2),
                 'avg_launch_gflop': round(fl / n_launch / 1e9, 3), 'share_of_step_time': round(tm / elapsed, 3),
+                'ms_per_step': round(tm / args.steps * 1e3, 2),
                 'per_variant_tflops': {k: round(v[0] / v[1] / 1e12, 1) for k, v in per_variant.items() if v[1] > 0}}
+            if 'worst_large_gemm_row' in rl:
+                roof['worst_large_gemm_row'] = rl['worst_large_gemm_row']
+                roof['largest_gemm_rows'] = rl['rows']
         name = 'ViT-B/16' if args.model.startswith('vit_base') else args.model
         out = {'metric': f'training clips/sec ({name}+AVT-h, {args.frames}x224^2 frames)',
                'value': round(clips, 2), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -289,7 +364,37 @@ def main(argv=None):
                         'note': 'rank 0: C-ABI calls (1-2 kernel launches each) and Python time to enqueue one step; enqueue >= ms_per_step means the step is host-bound'},
                'roofline': roof}
         if comm_all[0] is not None:
-            out['comm'] = {'per_rank': comm_all, 'note': 'comm_exposed_ms = time the optimizer waited for the gradient exchange after backward had finished'}
+            out['comm'] = {'per_rank': comm_all, 'note': 'comm_exposed_ms = time the optimizer waited for the gradient exchange after backward had finished',
+                           'env': {k: v for k, v in os.environ.items() if k.startswith(('NCCL_', 'RCCL_', 'HSA_ENABLE_IPC'))}}
+            if m['no_comm_trace'] and tm > 0:
+                nc = [r for r in gemm_rows(m['no_comm_trace'], 3, step_s) if r['kernel'].startswith(BIG)]
+                nc_ms = sum(r['ms_per_step'] for r in nc)
+                out['comm']['gemm_family_ms_per_step'] = {'with_collectives_in_flight': round(tm / args.steps * 1e3, 2), 'exchange_paused': round(nc_ms, 2),
+                                                          'note': 'rank 0, HIP events around every large-tile GEMM launch; the difference is what RCCL\'s kernels cost the GEMMs (CUs / HBM)'}
+
+    # BASELINE configs 4 and 5 at their own architecture, short runs inside the same line (N = 1 only; --no-also skips them): half of the
+    # headline's clips per GPU at T = 15 (128 of 256: the same 1920 frames), three eighths for ViT-L (96)
+    if world == 1 and not args.no_also and (args.model, args.frames) == ('vit_base_patch16_224', 10):
+        also = []
+        for label, kw in (('config 4: ViT-B/16 + AVT-h, T = 15', dict(frames=15, batch=max(1, args.batch // 2))),
+                          ('config 5: ViT-L/16 + AVT-h, T = 10', dict(model='vit_large_patch16_224', batch=max(1, args.batch * 3 // 8)))):
+            a2 = argparse.Namespace(**{**vars(args), **kw})
+            m2 = measure(a2, 5, 2)
+            c2 = a2.batch * 5 / m2['elapsed_local']
+            r2 = roofline_of(a2, c2, m2['trace'], 5, m2['elapsed_local'] / 5)
+            entry = {'config': f'{label}, {a2.batch} clips/GPU', 'model': a2.model, 'frames': a2.frames, 'clips_per_gpu': a2.batch,
+                     'value': round(c2, 2), 'unit': 'clips/s', 'ms_per_step': round(m2['elapsed_local'] / 5 * 1e3, 3), 'steps': 5, 'warmup': 2,
+                     'frac': r2['frac'], 'executed_frac': r2['executed_frac'], 'final_loss': round(m2['loss'], 4)}
+            if 'gemm_family' in r2:
+                entry['gemm_family_frac'] = r2['gemm_family']['frac']
+            if 'worst_large_gemm_row' in r2:
+                w = r2['worst_large_gemm_row']
+                entry['worst_large_gemm_row'] = {'kernel': w['kernel'], 'MNK': w['MNK'], 'tflops': w['tflops'], 'share_of_step_time': w['share_of_step_time']}
+            also.append(entry)
+        if rank == 0:
+            out['also'] = also
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -152,3 +152,26 @@ def test_bench_two_ranks_end_to_end_over_gloo():
     assert d['value'] > 0 and 'cpu_baseline' not in d
     assert len(d['comm']['per_rank']) == 2 and all(c['buckets_per_step'] >= 1 and 'comm_exposed_ms' in c for c in d['comm']['per_rank'])
     assert d['host']['abi_calls_per_step'] > 100 and d['roofline']['executed_frac'] < d['roofline']['frac']
+    # round 4: the line says what the collectives cost the GEMMs (same step with the exchange paused) and which RCCL knobs were in effect
+    g = d['comm']['gemm_family_ms_per_step']
+    assert g['with_collectives_in_flight'] > 0 and g['exchange_paused'] > 0 and 'env' in d['comm'] and 'also' not in d
+
+
+def test_bench_single_gpu_line_carries_configs_4_and_5():
+    """`python bench.py` at N = 1 appends short runs of BASELINE configs 4 (T = 15) and 5 (ViT-L/16) to the ONE JSON line (`also`), and
+    names the worst large GEMM row next to the family number.  Tiny batch here: a functional check of the line's shape."""
+    import json
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', '8', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['config']['clips_per_gpu'] == 8 and d['value'] > 0
+    also = d['also']
+    assert [a['frames'] for a in also] == [15, 10] and [a['model'] for a in also] == ['vit_base_patch16_224', 'vit_large_patch16_224']
+    assert [a['clips_per_gpu'] for a in also] == [4, 3] and all(a['value'] > 0 and 0 < a['executed_frac'] < a['frac'] for a in also)
+    w = d['roofline']['worst_large_gemm_row']
+    assert w['tflops'] > 0 and len(w['MNK']) == 3 and w['share_of_step_time'] >= 0.02

@@ -201,6 +201,22 @@ model.segs[1].grad_ready_hook(arena.params[1], arena.params[2])
 model.segs[0].grad_ready_hook(arena.params[0], arena.params[0])
 red.finish()
 assert close(arena.grad, expect), float((arena.grad - expect).abs().max())
+# the tail rule: once the not-yet-produced head of the buffer is at most tail_bytes, everything produced so far is sent at once, so
+# that finish() -- the only exchange backward cannot hide -- has just that head left; and a paused reducer exchanges nothing
+red2 = GradReducer(model, bucket_bytes=4 * 1500, mode=MODE, wire_dtype=WIRE, tail_bytes=4 * 1200)
+red2.start_step(); arena.grad.copy_(g_local)
+model.segs[2].grad_ready_hook(arena.params[3], arena.params[4])
+model.segs[1].grad_ready_hook(arena.params[1], arena.params[2])          # produced down to element 1000 <= 1200: flush now
+q = 64 * world
+assert 1000 <= red2._sent < 1000 + q, red2._sent          # nothing but the head (rounded to a shard boundary) is left for finish()
+n_before = red2.launched
+model.segs[0].grad_ready_hook(arena.params[0], arena.params[0])
+red2.finish()
+assert red2.launched == n_before + 1 and close(arena.grad, expect)
+red2.paused = True
+red2.start_step(); arena.grad.copy_(g_local)
+model.segs[2].grad_ready_hook(arena.params[3], arena.params[4]); red2.finish()
+assert red2.launched == 0 and torch.equal(arena.grad, g_local)
 try:
     GradReducer(model, mode='ring')
     raise SystemExit('unknown mode accepted')
