@@ -68,57 +68,8 @@ __device__ __forceinline__ void gelu_erf_both(float x, float& y, float& dy) {
   y = x * cdf;
   dy = cdf + x * 0.3989422804014327f * ex;
 }
-// two elements at a time with packed fp32 arithmetic (v_pk_mul/fma/add_f32).  Phi(x) = 1/2 + x R(x^2) on |x| <= 3 sqrt(2), with
-// R(u) = (1 / (2 sqrt 2)) P(u / 2) from the degree-8 near-minimax fit erf(z) = z P(z^2) on |z| <= 3 (|error| of Phi <= 1.2e-5, far
-// below bf16 resolution of the outputs; beyond the clamp Phi is 0 / 1 to 1e-5 and x phi(x) < 3e-4); one v_exp_f32 per element for
-// the density term of the derivative.  Working in x^2 directly (coefficients rescaled, the 1/sqrt 2 and the 1/2 folded in) takes
-// 8 vector instructions per 4 elements off the round-2 form (z = x / sqrt 2, z^2, z P, * 1/2 + 1/2): the epilogue is bound by
-// the vector-ALU issue rate (profiles/r03_issue_rules.txt), where one exponential costs 1.5 packed FMAs.
-// Two pairs at once, written on 4-vectors: every step becomes two INDEPENDENT packed instructions, so the two Horner chains interleave.
-// With one pair per call hipcc ran the chains one after the other and every v_pk_fma_f32 waited on its predecessor (an `s_nop` between
-// each two: 151 per 32-row block of the epilogue).
-__device__ __forceinline__ void gelu_erf_both4(f32x2_t& x0, f32x2_t& x1, f32x2_t& d0, f32x2_t& d1) {
-  const f32x4_t x = {x0[0], x0[1], x1[0], x1[1]};
-  f32x4_t xc;
-#ifdef AVT_GELU_DEG6
-  // degree-6 fit on |x| <= 3.8 (|error of Phi| <= 6.5e-5, of x Phi <= 2.5e-4: a quarter of a bf16 half-ulp at 0.25): two Horner steps less
-#pragma unroll
-  for (int k = 0; k < 4; ++k) xc[k] = __builtin_amdgcn_fmed3f(x[k], -3.8f, 3.8f);
-  const f32x4_t u = xc * xc;
-  f32x4_t pl = u * 3.665766933e-08f + -2.272457041e-06f;
-  pl = pl * u + 6.068471427e-05f;
-  pl = pl * u + -9.315468779e-04f;
-  pl = pl * u + 9.316632347e-03f;
-  pl = pl * u + -6.571978265e-02f;
-  pl = pl * u + 3.986767432e-01f;
-#else
-#pragma unroll
-  for (int k = 0; k < 4; ++k) xc[k] = __builtin_amdgcn_fmed3f(x[k], -4.242640687f, 4.242640687f);
-  const f32x4_t u = xc * xc;
-  f32x4_t pl = u * 5.626728078e-11f + -5.371838974e-09f;
-  pl = pl * u + 2.268286700e-07f;
-  pl = pl * u + -5.646199191e-06f;
-  pl = pl * u + 9.359048303e-05f;
-  pl = pl * u + -1.109399554e-03f;
-  pl = pl * u + 9.818116925e-03f;
-  pl = pl * u + -6.634692091e-02f;
-  pl = pl * u + 3.989031466e-01f;
-#endif
-  const f32x4_t cdf = xc * pl + 0.5f;
-  f32x2_t kexp = {-0.7213475204444817f, -0.7213475204444817f};          // opaque scalar pairs: with a literal hipcc multiplies element by element
-  f32x2_t kphi = {0.3989422804014327f, 0.3989422804014327f};
-  asm("" : "+s"(kexp), "+s"(kphi));
-  const f32x2_t a0 = (f32x2_t){u[0], u[1]} * kexp, a1 = (f32x2_t){u[2], u[3]} * kexp;     // exp(-x^2/2) = 2^a
-  const f32x4_t a = {a0[0], a0[1], a1[0], a1[1]};
-  f32x4_t ex;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) ex[k] = __builtin_amdgcn_exp2f(a[k]);
-  const f32x2_t c0 = {cdf[0], cdf[1]}, c1 = {cdf[2], cdf[3]}, e0 = {ex[0], ex[1]}, e1 = {ex[2], ex[3]};
-  // the density term on the CLAMPED argument: beyond the clamp x phi(x) keeps the (tiny) value it has at the clamp instead of growing with x
-  const f32x2_t xc0 = {xc[0], xc[1]}, xc1 = {xc[2], xc[3]};
-  d0 = (xc0 * kphi) * e0 + c0; d1 = (xc1 * kphi) * e1 + c1;
-  x0 = x0 * c0; x1 = x1 * c1;
-}
+// (the erf GELU of the GEMM epilogues is a table look-up since round 4: csrc/gemm.hip, "GELU by table"; the packed-polynomial form of
+// rounds 2-3 -- degree-8 fit of Phi on |x| <= 3 sqrt 2 + one v_exp_f32 per element -- measured 4 % slower on the fc1-forward launches)
 __device__ __forceinline__ void gelu_tanh_both(float x, float& y, float& dy) {
   float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
   float t = fast_tanh(u);
@@ -176,13 +127,11 @@ __device__ __forceinline__ bf16x8_t tr_join(u32x2_t lo, u32x2_t hi) {
 __device__ __forceinline__ uint32_t lds_addr32(const char* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 
 // ---- streamed tensors (read or written exactly once by a kernel): non-temporal hint -----------------------------------------
-#ifdef AVT_STREAM_NT
-#define AVT_LDG(p) __builtin_nontemporal_load(p)
-#define AVT_STG(p, v) __builtin_nontemporal_store((v), (p))
-#else
-#define AVT_LDG(p) (*(p))
-#define AVT_STG(p, v) (*(p) = (v))
-#endif
+// Measured per kernel (profiles/r04_cache_policy.txt, 2560 frames): LayerNorm forward 295 -> 283 us, backward 623 -> 602 us with nt
+// loads and stores (adopted there); the fused SGD does not gain (1.83-2.14 vs 2.19 ms) and the attention kernels lose with nt on
+// their 8-byte stores (forward 727 -> 945 us) and on their tile loads (708 -> 820 us): those keep the default policy.
+#define AVT_LDG_NT(p) __builtin_nontemporal_load(p)
+#define AVT_STG_NT(p, v) __builtin_nontemporal_store((v), (p))
 
 // ---- host-side error channel -------------------------------------------------------------------------
 void avt_set_error(const char* fmt, ...);

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
     for (int i = 0; i < V; ++i) {
       int c = lane + i * 64;
       if (c < nchunk) {
-        u32x4_t w = AVT_LDG((const u32x4_t*)(xr + c * 8));
+        u32x4_t w = AVT_LDG_NT((const u32x4_t*)(xr + c * 8));
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[i][2 * e] = bflo(w[e]); v[i][2 * e + 1] = bfhi(w[e]); }
 #pragma unroll
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
         u32x4_t w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = pack2bf(o[2 * e], o[2 * e + 1]);
-        AVT_STG((u32x4_t*)(yr + c * 8), w);
+        AVT_STG_NT((u32x4_t*)(yr + c * 8), w);
       }
     }
   }
@@ -121,9 +121,9 @@ __global__ __launch_bounds__(256, MINW) void ln_bwd_kernel(const bf16_t* __restr
       const int c = lane + i * 64;
       nx[i] = (u32x4_t){0u, 0u, 0u, 0u}; nd[i] = nx[i]; nr[i] = nx[i];
       if (ok && c < nchunk) {
-        nx[i] = AVT_LDG((const u32x4_t*)(xr + c * 8));
-        nd[i] = AVT_LDG((const u32x4_t*)(dyr + c * 8));
-        if (dres) nr[i] = AVT_LDG((const u32x4_t*)(rr + c * 8));
+        nx[i] = AVT_LDG_NT((const u32x4_t*)(xr + c * 8));
+        nd[i] = AVT_LDG_NT((const u32x4_t*)(dyr + c * 8));
+        if (dres) nr[i] = AVT_LDG_NT((const u32x4_t*)(rr + c * 8));
       }
     }
     nmean = ok ? mean_in[row] : 0.f; nrstd = ok ? rstd_in[row] : 0.f;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, MINW) void ln_bwd_kernel(const bf16_t* __restr
         u32x4_t w;
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[e] = pack2bf(o[2 * e], o[2 * e + 1]);
-        AVT_STG((u32x4_t*)(dxr + c * 8), w);
+        AVT_STG_NT((u32x4_t*)(dxr + c * 8), w);
         if (colsum) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) { ac[i][2 * e] += bflo(w[e]); ac[i][2 * e + 1] += bfhi(w[e]); }   // sum what the consumer GEMM will see
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void ln_fwd2_kernel(const bf16_t* __restrict__
     for (int i = 0; i < 3; ++i) {
       const int row = row0 + (r1[i] ? 1 : 0);
       u32x4_t w = (u32x4_t){0u, 0u, 0u, 0u};
-      if (row < rows) w = AVT_LDG((const u32x4_t*)(x + (size_t)row * ldx + cc[i] * 8));
+      if (row < rows) w = AVT_LDG_NT((const u32x4_t*)(x + (size_t)row * ldx + cc[i] * 8));
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[i][2 * e] = bflo(w[e]); v[i][2 * e + 1] = bfhi(w[e]); s += v[i][2 * e] + v[i][2 * e + 1]; }
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void ln_fwd2_kernel(const bf16_t* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         w[e] = pack2bf((v[i][2 * e] - m) * rs * gam[i][2 * e] + bet[i][2 * e], (v[i][2 * e + 1] - m) * rs * gam[i][2 * e + 1] + bet[i][2 * e + 1]);
-      if (row < rows) AVT_STG((u32x4_t*)(y + (size_t)row * ldy + cc[i] * 8), w);
+      if (row < rows) AVT_STG_NT((u32x4_t*)(y + (size_t)row * ldy + cc[i] * 8), w);
     }
   }
 }

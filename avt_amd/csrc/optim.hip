@@ -14,8 +14,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
   long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * 256 * 4;
   for (; i + 4 <= n; i += stride) {
-    f32x4_t pv = AVT_LDG((f32x4_t*)(p + i)), gv = AVT_LDG((f32x4_t*)(g + i)), bv = {0.f, 0.f, 0.f, 0.f};
-    if (!first) bv = AVT_LDG((f32x4_t*)(buf + i));
+    f32x4_t pv = *(f32x4_t*)(p + i), gv = *(f32x4_t*)(g + i), bv = {0.f, 0.f, 0.f, 0.f};
+    if (!first) bv = *(f32x4_t*)(buf + i);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float gg = gv[e] * grad_scale + wd * pv[e];
@@ -24,10 +24,10 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
       bv[e] = b;
       pv[e] = pv[e] - lr * step;
     }
-    AVT_STG((f32x4_t*)(p + i), pv);
-    AVT_STG((f32x4_t*)(buf + i), bv);
-    if (shadow) { u32x2_t w; w[0] = pack2bf(pv[0], pv[1]); w[1] = pack2bf(pv[2], pv[3]); AVT_STG((u32x2_t*)(shadow + i), w); }
-    if (zero_grad) AVT_STG((f32x4_t*)(g + i), ((f32x4_t){0.f, 0.f, 0.f, 0.f}));
+    *(f32x4_t*)(p + i) = pv;
+    *(f32x4_t*)(buf + i) = bv;
+    if (shadow) { u32x2_t w; w[0] = pack2bf(pv[0], pv[1]); w[1] = pack2bf(pv[2], pv[3]); *(u32x2_t*)(shadow + i) = w; }
+    if (zero_grad) *(f32x4_t*)(g + i) = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
   if (i < n) {
     for (long j = i; j < n; ++j) {

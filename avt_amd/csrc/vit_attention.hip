@@ -10,6 +10,7 @@
 // the row-major LDS tiles with gfx950's transposing ds_read_b64_tr_b16, so nothing is ever transposed in memory.
 //   qkv layout: [frames*S, 3*D] with columns [q | k | v], each head-major (timm reshape(N,S,3,H,hd)).
 #include <cstdlib>
+#include <type_traits>
 #include "common.hpp"
 // L2 policy of the attention kernels' streams (A/B switches).  Measured (profiles/r04_cache_policy.txt): nt on the K / V / Q / dO tile
 // loads costs 15 % (forward 708 -> 820 us at 2560 frames: the twelve heads of a frame read adjacent 128-byte pieces of the same qkv rows),
@@ -17,11 +18,8 @@
 #ifndef AVT_ATTN_LD_AUX
 #define AVT_ATTN_LD_AUX 0
 #endif
-#ifdef AVT_ATTN_ST_NT
-#define AVT_ATTN_STG(p, v) __builtin_nontemporal_store((v), (p))
-#else
+// ... and so do the 8-byte output stores (nt there: forward 727 -> 945 us, backward 2276 -> 2576 us).
 #define AVT_ATTN_STG(p, v) (*(p) = (v))
-#endif
 #include "../../include/avt_hip.h"
 
 namespace {
@@ -608,10 +606,314 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
   }
 }
 
+// ---- single-pass backward (round 4) -------------------------------------------------------------------------------------------
+// The two-phase kernel above evaluates the scores and dP = dO V^T twice (once per query strip for dQ, once per key strip for
+// dK / dV): 2 x 676 of its 2444 MFMAs per item and both softmax recomputations.  Here every (query tile, key tile) pair is evaluated
+// ONCE, by the wave that owns the key strip (wave w = keys 16w .. 16w+15, K / V strips held in registers straight from global):
+//     chunk c = queries 32c .. 32c+31:   S^T, dP^T (4 MFMAs per query tile)  ->  P, dS  ->  dV += P^T dO, dK += dS^T Q (8 MFMAs)
+//                                        dS (bf16) -> LDS buffer c & 1, [key][32 queries], 72-byte rows
+//     barrier c
+//     dQ of the chunk's two query tiles = dS K, read back through transposing LDS reads; the 2 x 2 (query tile, half of the head dim)
+//     products go to four different waves (h = 4c .. 4c+3 -> wave h mod NKT: every wave gets two of the 26 over an item), 14 MFMAs
+//     each, while everybody else is already in chunk c+1.
+// 1768 MFMAs per item instead of 2444, one softmax pass, 8 barriers per item instead of 2.  LDS: Q, dO, K tiles (84 KB; V never goes
+// to LDS) + two dS buffers (32 KB) + per-query scalars and the bias staging = 131 KB.  Tiles are single-buffered: the rows of
+// Q / dO that chunk c consumed are re-filled with the NEXT item's rows (LDS-DMA) right after barrier c, the K tile right after the
+// item's first barrier -- it is needed at barrier 0 at the earliest.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// rows [8j, 8j + 8) of a head's [S][64] slice -> the swizzled row-major tile (one LDS-DMA instruction)
+__device__ __forceinline__ void dma_rows8(__amdgpu_buffer_rsrc_t rsrc, int ld, int S, char* rm, int j, int lane) {
+  const int r = j * 8 + (lane >> 3);
+  const int c = (lane & 7) ^ swz8(r);
+  uint32_t off = (uint32_t)(((size_t)r * (size_t)ld + (size_t)c * 8) * 2);
+  if (r >= S) off = 0xFFFFFFF0u;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(rm + j * 1024), 16, off, 0, 0, AVT_ATTN_LD_AUX);
+}
+
+template <int NKT, bool ALL_LIVE>
+__global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                                 const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                 bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
+                                                                 float* __restrict__ part, int S, int H, int items, float scale) {
+  constexpr int NP = (NKT + 1) / 2;          // 32-query chunks = key / query tile pairs
+  constexpr int KP = NP * 32;                // rows of every LDS tile (zero padded)
+  constexpr int RM = KP * 128;               // bytes of a row-major [KP][64] bf16 tile
+  constexpr int DSP = 72;                    // dS buffer: [key][32 queries] bf16, 72-byte rows (4 consecutive rows x 32 B and 16 rows x 8 B hit distinct banks)
+  constexpr int DSB = KP * DSP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Qs = smem;
+  char* dOs = smem + RM;
+  char* Ks = smem + 2 * RM;
+  char* dSb = smem + 3 * RM;
+  float* lse_s = (float*)(smem + 3 * RM + 2 * DSB);    // lse * log2(e)
+  float* dq_s = lse_s + KP;                  // D[q] * scale,  D[q] = sum_d dO[q,d] O[q,d]
+  float* bias_s = dq_s + KP;                 // [H][3*64] column sums of dq | dk | dv, kept for the whole kernel
+  float* stq_s = bias_s + H * 192;           // [NKT][64] this item's dq sums per query tile
+  float* stv_s = stq_s + NKT * 64;           // [NP][64]  this item's dO sums per query pair (= the dv sums: every row of P sums to one)
+  int prev_head = -1;
+  const int D = H * HD, ld = 3 * D;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = 64 * NKT;
+  const int g = lane >> 4, i16 = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const float sl = scale * LOG2E;
+  if (dbias) for (int i = tid; i < H * 192; i += nthr) bias_s[i] = 0.f;
+  // key rows past the last wave's strip exist in the dS buffers (the dQ products walk whole 32-key pairs) but are never written: zero
+  // them once -- they meet all-zero K rows, and 0 x (whatever bits the LDS held) must not be a NaN
+  for (int i = tid; i < 2 * (KP - NKT * 16) * (DSP / 4); i += nthr) {
+    const int b = i / ((KP - NKT * 16) * (DSP / 4)), r = i % ((KP - NKT * 16) * (DSP / 4));
+    ((uint32_t*)(dSb + b * DSB + NKT * 16 * DSP))[r] = 0u;
+  }
+
+  uint32_t tr0[4], trK[4];                   // per-lane addresses of the transposing reads: Q / dO tiles, K tile
+  tr_lane_offsets(lane, tr0);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { tr0[dt] += lds_addr32(smem); trK[dt] = tr0[dt] + 2 * RM; }
+  char* const dswr = dSb + (16 * wave + i16) * DSP + 8 * g;                                       // this lane's dS writes: key row, queries 4g..4g+3 of a tile
+  const uint32_t dsrd = lds_addr32(dSb) + (uint32_t)((4 * g + (i16 >> 2)) * DSP + (i16 & 3) * 8);  // this lane's address in a transposing read of the buffer
+  const int k0 = wave * 16, key = k0 + i16;  // own key strip; the same rows as a QUERY tile for the per-query scalars
+
+  // own strips of the NEXT item (B-operand layout, straight from global): K, V of this wave's keys; dO, O of the same rows as queries
+  bf16x8_t nk[2], nv[2], ndo[2], no[2];
+  float nlq = 0.f;
+  auto fetch_strips = [&](int it) __attribute__((always_inline)) {
+    const int fr = it / H, hd = it % H;
+    const size_t r0 = (size_t)fr * S;
+    int lane_f = lane;                         // (opaque: the strips' per-lane global offsets are recomputed here, not kept across the item)
+    asm volatile("" : "+v"(lane_f));
+    load_strip(qkv + r0 * ld + D + hd * HD, ld, S, k0, lane_f, nk);
+    load_strip(qkv + r0 * ld + 2 * D + hd * HD, ld, S, k0, lane_f, nv);
+    load_strip(dout + r0 * D + hd * HD, D, S, k0, lane_f, ndo);
+    load_strip(out + r0 * D + hd * HD, D, S, k0, lane_f, no);
+    const int key_f = k0 + (lane_f & 15);
+    nlq = (key_f < S) ? lse[((size_t)fr * H + hd) * S + key_f] * LOG2E : 0.f;
+  };
+  int item = blockIdx.x;
+  if (item < items) {
+    const size_t r0 = (size_t)(item / H) * S;
+    stage_head_dma(qkv + r0 * ld + (item % H) * HD, ld, S, Qs, KP, wv, NKT, lane);
+    stage_head_dma(dout + r0 * D + (item % H) * HD, D, S, dOs, KP, wv, NKT, lane);
+    fetch_strips(item);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  for (; item < items; item += gridDim.x) {
+    const int frame = item / H, head = item % H;
+    const size_t row0 = (size_t)frame * S;
+    bf16_t* dbase = dqkv + row0 * ld + head * HD;
+    const bool has_next = item + gridDim.x < items;
+    const int nitem = has_next ? item + gridDim.x : item;
+    const size_t nr0 = (size_t)(nitem / H) * S;
+    __amdgpu_buffer_rsrc_t nrq = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + nr0 * ld + (nitem % H) * HD), 0, 0x7FFFFFF0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t nrdo = __builtin_amdgcn_make_buffer_rsrc((void*)(dout + nr0 * D + (nitem % H) * HD), 0, 0x7FFFFFF0u, 0x00020000);
+
+    // own strips have landed once everything but the youngest 8 vector-memory operations (the previous item's dK / dV stores) is done;
+    // older than the strips are the prefetched Q / dO rows of this item and the dQ stores of the previous one
+    if (ALL_LIVE) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bf16x8_t bk[2], bv[2];
+    bk[0] = nk[0]; bk[1] = nk[1]; bv[0] = nv[0]; bv[1] = nv[1];
+    {
+      float dsum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += (float)ndo[ks][e] * (float)no[ks][e];
+      dsum = gsum(dsum) * scale;
+      int lane_s = lane;                        // (opaque: these LDS addresses are used once per item)
+      asm volatile("" : "+v"(lane_s));
+      if (lane_s < 16) { dq_s[k0 + lane_s] = dsum; lse_s[k0 + lane_s] = nlq; }         // k0 + 15 < NKT * 16 <= KP; rows past the sequence: 0 / 0
+      if (NKT * 16 < KP && wv == 0 && lane_s < KP - NKT * 16) { dq_s[NKT * 16 + lane_s] = 0.f; lse_s[NKT * 16 + lane_s] = 0.f; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // barrier S: scalars visible; every wave is done with the previous item
+    if (dbias && prev_head >= 0) {            // the previous item's sums, folded in tile order by the column's owner thread
+      float* bh = bias_s + prev_head * 192;
+      for (int c = tid; c < 64; c += nthr) {
+        float t = bh[c];
+#pragma unroll
+        for (int w = 0; w < NKT; ++w) t += stq_s[w * 64 + c];
+        bh[c] = t;
+        float u = bh[128 + c];
+#pragma unroll
+        for (int w = 0; w < NP; ++w) u += stv_s[w * 64 + c];
+        bh[128 + c] = u;
+      }
+    }
+    prev_head = head;
+    stage_head_dma(qkv + row0 * ld + D + head * HD, ld, S, Ks, KP, wv, NKT, lane);       // K tile: first read after barrier 0
+
+    f32x4_t adk[4], adv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = adk[dt]; }
+
+    static_for<0, NP>([&](auto c_) __attribute__((always_inline)) {
+      constexpr int c = decltype(c_)::value;
+      // software pipeline: the transposing reads of the dO tile (for dV) are requested first and land under the score / softmax work;
+      // those of the Q tile (for dK) are requested before the dV products and land under them
+      bf16x8_t tfo[4], tfq[4];
+      frag4_tr_na<RM, NP>(tfo, tr0, c);                                     // dO tile, queries of pair c
+      f32x4_t pv2[2], ds2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int qt = 2 * c + u;
+        pv2[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        ds2[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (qt < NKT) {
+          f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          s = mfma16(frag_rm(Qs, qt, 0, lane), bk[0], s);
+          s = mfma16(frag_rm(Qs, qt, 1, lane), bk[1], s);
+          dp = mfma16(frag_rm(dOs, qt, 0, lane), bv[0], dp);
+          dp = mfma16(frag_rm(dOs, qt, 1, lane), bv[1], dp);
+          const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g);      // pre-scaled by log2(e)
+          const f32x4_t d4 = *(const f32x4_t*)(dq_s + qt * 16 + 4 * g);       // pre-scaled by `scale`
+          const f32x2_t s01 = (f32x2_t){s[0], s[1]} * sl - (f32x2_t){l4[0], l4[1]}, s23 = (f32x2_t){s[2], s[3]} * sl - (f32x2_t){l4[2], l4[3]};
+          const f32x2_t e01 = (f32x2_t){dp[0], dp[1]} * scale - (f32x2_t){d4[0], d4[1]}, e23 = (f32x2_t){dp[2], dp[3]} * scale - (f32x2_t){d4[2], d4[3]};
+          const f32x2_t p01 = (f32x2_t){__builtin_amdgcn_exp2f(s01[0]), __builtin_amdgcn_exp2f(s01[1])};
+          const f32x2_t p23 = (f32x2_t){__builtin_amdgcn_exp2f(s23[0]), __builtin_amdgcn_exp2f(s23[1])};
+          const f32x2_t d01 = p01 * e01, d23 = p23 * e23;
+          pv2[u] = (f32x4_t){p01[0], p01[1], p23[0], p23[1]};
+          ds2[u] = (f32x4_t){d01[0], d01[1], d23[0], d23[1]};
+        }
+      }
+      const bf16x8_t bp = pack_pair(pv2[0], pv2[1]);
+      union { bf16x8_t v; uint32_t w[4]; } bd;
+      bd.v = pack_pair(ds2[0], ds2[1]);
+      // dS of (own keys) x (the chunk's 32 queries) -> buffer c & 1: two 8-byte stores per lane (queries 4g..4g+3 of each tile); the buffer's
+      // previous contents (chunk c - 2) were consumed before barrier c - 1
+      *(u32x2_t*)(dswr + (c & 1) * DSB) = (u32x2_t){bd.w[0], bd.w[1]};
+      *(u32x2_t*)(dswr + (c & 1) * DSB + 32) = (u32x2_t){bd.w[2], bd.w[3]};
+      asm volatile("" ::: "memory");                                          // (the stores above are queued before the reads below)
+      frag4_tr_na<0, NP>(tfq, tr0, c);                                       // Q tile: 8 reads, the youngest LDS operations of this wave
+      asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(tfo[0]), "+v"(tfo[1]), "+v"(tfo[2]), "+v"(tfo[3]));   // everything older has returned: the dO fragments
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) adv[dt] = mfma16(tfo[dt], bp, adv[dt]);
+      if (dbias && wv == c) {
+        // colsum(dV) = sum_k sum_q P[q,k] dO[q] = sum_q dO[q] (every row of P sums to one): wave c takes the 32 queries of pair c from the
+        // fragments it has just read, as one more product with an all-ones B operand, and parks the 64 sums in its staging row
+        union { bf16x8_t v; uint32_t w[4]; } ones;
+        ones.w[0] = ones.w[1] = ones.w[2] = ones.w[3] = 0x3F803F80u;
+        f32x4_t cs[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) cs[dt] = mfma16(tfo[dt], ones.v, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+        // (the 11 wait states an 8-pass MFMA result needs before a memory instruction reads it, explicit and tied to the registers)
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]));
+        if (i16 == 0) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) *(f32x4_t*)(stv_s + c * 64 + dt * 16 + 4 * g) = cs[dt];
+        }
+      }
+      lgkm_wait4(tfq[0], tfq[1], tfq[2], tfq[3]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) adk[dt] = mfma16(tfq[dt], bd.v, adk[dt]);
+      if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the K tile has landed
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // barrier c: dS chunk complete; the chunk's Q / dO rows are free
+      // ---- dQ of the chunk's two query tiles: four (tile, half) products, one wave each ----
+      static_for<0, 4>([&](auto hh_) __attribute__((always_inline)) {
+        constexpr int h = 4 * c + decltype(hh_)::value;
+        if constexpr (h < 2 * NKT) {
+          if (wv == h % NKT) {
+            constexpr int qt = h >> 1, half = h & 1, u = qt & 1;
+            f32x4_t acc[2];
+            acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
+            // fragments of key pair t + 1 are requested before the products of pair t (two register sets)
+            bf16x8_t bb[2], ka[2], kb[2];
+            auto rd = [&](auto t_) __attribute__((always_inline)) {
+              constexpr int t = decltype(t_)::value;
+              constexpr int o = (c & 1) * DSB + 32 * t * DSP + 32 * u;
+              const u32x2_t lo = ds_read_tr_na<o>(dsrd), hi = ds_read_tr_na<o + 16 * DSP>(dsrd);     // keys 32t + 4g + j | 32t + 16 + 4g + j
+              bb[t & 1] = tr_join(lo, hi);
+              ka[t & 1] = frag_tr_na<0, t>(trK[2 * half]);
+              kb[t & 1] = frag_tr_na<0, t>(trK[2 * half + 1]);
+            };
+            rd(std::integral_constant<int, 0>{});
+            static_for<0, NP>([&](auto t_) __attribute__((always_inline)) {
+              constexpr int t = decltype(t_)::value;
+              if constexpr (t + 1 < NP) {
+                rd(std::integral_constant<int, t + 1>{});
+                asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bb[t & 1]), "+v"(ka[t & 1]), "+v"(kb[t & 1]));     // the 6 reads just queued may still be out
+              } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[t & 1]), "+v"(ka[t & 1]), "+v"(kb[t & 1]));
+              }
+              acc[0] = mfma16(ka[t & 1], bb[t & 1], acc[0]);
+              acc[1] = mfma16(kb[t & 1], bb[t & 1], acc[1]);
+            });
+            int lane_d = lane;                       // (opaque: the store addresses are recomputed here instead of being kept -- spilled -- across the item)
+            asm volatile("" : "+v"(lane_d));
+            const int q = qt * 16 + (lane_d & 15);
+            if (q < S) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                u32x2_t w; w[0] = pack2bf(acc[j][0], acc[j][1]); w[1] = pack2bf(acc[j][2], acc[j][3]);
+                AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)q * ld + (2 * half + j) * 16 + 4 * (lane_d >> 4)), w);
+              }
+            }
+            if (dbias) {
+              // q part of the qkv-bias gradient: sums over the tile's 16 queries = the 16 lanes of a DPP row (rows past the sequence are
+              // exactly zero).  The accumulators come straight out of the matrix pipe into hand-written DPP adds: the wait states are
+              // tied to the registers so that no MFMA can be scheduled below them
+              asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
+              lsum16x4(acc[0]); lsum16x4(acc[1]);
+              if (i16 == 0) {
+                *(f32x4_t*)(stq_s + qt * 64 + (2 * half) * 16 + 4 * g) = acc[0];
+                *(f32x4_t*)(stq_s + qt * 64 + (2 * half + 1) * 16 + 4 * g) = acc[1];
+              }
+            }
+          }
+        }
+      });
+      // the NEXT item's Q / dO rows of this chunk (4 + 4 LDS-DMA instructions of 8 rows), spread over the waves
+      if (has_next) {
+        for (int j = wv; j < 8; j += NKT) {
+          if (j < 4) dma_rows8(nrq, ld, S, Qs, 4 * c + j, lane);
+          else dma_rows8(nrdo, D, S, dOs, 4 * c + j - 4, lane);
+        }
+      }
+    });
+
+    // next item's strips: requested after the register-hungry loop, hidden behind the stores and the item's first barrier
+    fetch_strips(nitem);                        // unconditional (re-fetches this item at the end): keeps the counted wait above exact
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      if (key < S) {
+        u32x2_t w; w[0] = pack2bf(adk[dt][0], adk[dt][1]); w[1] = pack2bf(adk[dt][2], adk[dt][3]);
+        AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + D + dt * 16 + 4 * g), w);
+        u32x2_t x; x[0] = pack2bf(adv[dt][0], adv[dt][1]); x[1] = pack2bf(adv[dt][2], adv[dt][3]);
+        AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g), x);
+      }
+    }
+  }
+  if (dbias) {
+    __syncthreads();
+    if (prev_head >= 0) {
+      float* bh = bias_s + prev_head * 192;
+      for (int c = tid; c < 64; c += nthr) {
+        float t = bh[c];
+#pragma unroll
+        for (int w = 0; w < NKT; ++w) t += stq_s[w * 64 + c];
+        bh[c] = t;
+        float u = bh[128 + c];
+#pragma unroll
+        for (int w = 0; w < NP; ++w) u += stv_s[w * 64 + c];
+        bh[128 + c] = u;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < H * 192; i += nthr) {
+      const int hh = i / 192, c = i % 192;
+      const float v = bias_s[i];
+      const int o = (c >> 6) * D + hh * HD + (c & 63);
+      if (part) part[(size_t)blockIdx.x * (3 * D) + o] = v;
+      else if (v != 0.f) unsafeAtomicAdd(&dbias[o], v);
+    }
+  }
+}
+
 int pick_nkt(int S) { int n = (S + 15) / 16; if (n <= 1) return 1; if (n <= 2) return 2; if (n <= 4) return 4; if (n <= 8) return 8; return 13; }
 
 template <int NKT> size_t fwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128; }     // K, V x 2 buffers
 template <int NKT> size_t bwd_smem(int H) { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128 + (size_t)(2 * NP * 32 + H * 192 + NKT * 192) * 4; }
+
+template <int NKT> size_t bwd1_smem(int H) { constexpr int NP = (NKT + 1) / 2, KP = NP * 32; return (size_t)3 * KP * 128 + (size_t)2 * KP * 72 + (size_t)(2 * KP + H * 192 + NKT * 64 + NP * 64) * 4; }
 
 template <int NKT>
 int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, int H, float scale, hipStream_t s) {
@@ -630,6 +932,26 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, in
 template <int NKT>
 int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, float* dbias,
                float* part, size_t part_bytes, int frames, int S, int H, float scale, hipStream_t s) {
+#ifndef AVT_ATTN_BWD_TWO_PHASE
+  {
+    // single-pass kernel (default since round 4); the two-phase kernel stays selectable for A/B (-DAVT_ATTN_BWD_TWO_PHASE)
+    const size_t sm1 = bwd1_smem<NKT>(H);
+    if (sm1 > 160 * 1024) { avt_set_error("avt_vit_attn_bwd: H = %d needs more LDS than a CU has", H); return -1; }
+    (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
+    (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
+    const bool live = S > (NKT - 1) * 16;
+    const int items1 = frames * H;
+    const int pc = (int)((160 * 1024) / sm1) < 1 ? 1 : (int)((160 * 1024) / sm1);
+    int grid1 = 256 * (pc > 8 ? 8 : pc);
+    if (grid1 > items1) grid1 = items1;
+    if (!dbias) part = nullptr;
+    if (part && part_bytes < (size_t)grid1 * 3 * H * HD * 4) { avt_set_error("avt_vit_attn_bwd: partials workspace too small"); return -1; }
+    if (live) hipLaunchKernelGGL((vit_attn_bwd1_kernel<NKT, true>), dim3(grid1), dim3(64 * NKT), sm1, s, qkv, out, dout, lse, dqkv, dbias, part, S, H, items1, scale);
+    else hipLaunchKernelGGL((vit_attn_bwd1_kernel<NKT, false>), dim3(grid1), dim3(64 * NKT), sm1, s, qkv, out, dout, lse, dqkv, dbias, part, S, H, items1, scale);
+    if (part) { float* outs[1] = {dbias}; return avt_reduce_partials(part, grid1, 3L * H * HD, outs, 1, s); }
+    return 0;
+  }
+#endif
   size_t sm = bwd_smem<NKT>(H);
   if (sm > 160 * 1024) { avt_set_error("avt_vit_attn_bwd: H = %d needs more LDS than a CU has", H); return -1; }
   (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);

@@ -332,6 +332,15 @@ def test_vit_attention(ops, frames, S, H):
         e = relerr(dqkv[:, j * D:(j + 1) * D], ref_dqkv[:, j * D:(j + 1) * D])
         assert e < 2e-2, (name, e)
     assert relerr(dbias, ref_dqkv.sum(0)) < 2e-2
+    # the three parts of the qkv-bias gradient separately (each has its own path inside the backward kernel: DPP sums of the dQ
+    # accumulators; the identity colsum(dK) = 0; the dO column sums as one more matrix product) -- also for S % 16 != 0, where the
+    # strips / tiles past the sequence must contribute exactly nothing
+    col = ref_dqkv.sum(0)
+    scale_ref = float(col.abs().max())
+    for j, name in enumerate('qkv'):
+        e = float((dbias[j * D:(j + 1) * D] - col[j * D:(j + 1) * D]).abs().max()) / scale_ref
+        assert e < 2e-2, (name, e)
+    assert float(dbias[D:2 * D].abs().max()) == 0.0          # colsum(dK) is zero exactly (every row of dS sums to zero): nothing is ever added
 
 
 @pytest.mark.parametrize('frames,S,H', [(3, 197, 12), (2, 5, 4), (5, 64, 2), (1, 65, 3), (9, 197, 16), (2, 256, 1)])
