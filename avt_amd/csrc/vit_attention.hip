@@ -260,16 +260,27 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
     const float sl = scale * LOG2E;
     const float mxs = mx * sl;
     float sum = 0.f;
+    // probabilities, packed to bf16 pair by pair as they are produced (the fp32 score registers die here: room for a second set of V
+    // fragments below)
+    bf16x8_t pb[NP];
   #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
+    for (int t = 0; t < NP; ++t) {
   #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int key = kt * 16 + 4 * g + r;
-        float pv = __builtin_amdgcn_exp2f(fmaf(st[kt][r], sl, -mxs));
-        if (!ALL_LIVE || kt == NKT - 1) pv = (key < S) ? pv : 0.f;
-        st[kt][r] = pv;
-        sum += pv;
+      for (int u = 0; u < 2; ++u) {
+        const int kt = 2 * t + u;
+        if (kt < NKT) {
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int key = kt * 16 + 4 * g + r;
+            float pv = __builtin_amdgcn_exp2f(fmaf(st[kt][r], sl, -mxs));
+            if (!ALL_LIVE || kt == NKT - 1) pv = (key < S) ? pv : 0.f;
+            st[kt][r] = pv;
+            sum += pv;
+          }
+        }
       }
+      pb[t] = pack_pair(st[2 * t], st[2 * t + 1]);
+    }
     sum = gsum(sum);
     f32x4_t o[4];
   #pragma unroll
@@ -280,14 +291,19 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   #pragma unroll
       for (int dt = 0; dt < 4; ++dt) vaddr[dt] = vb + troff[dt];
     }
+    // P V with the V fragments of key pair t + 1 requested before the products of pair t (two register sets)
+    bf16x8_t vf[2][4];
+    frag4_tr_na<0, NP>(vf[0], vaddr, 0);
   #pragma unroll
     for (int t = 0; t < NP; ++t) {
-      bf16x8_t pb = pack_pair(st[2 * t], st[2 * t + 1]);
-      bf16x8_t vf[4];
-      frag4_tr_na<0, NP>(vf, vaddr, t);
-      lgkm_wait4(vf[0], vf[1], vf[2], vf[3]);
+      if (t + 1 < NP) {
+        frag4_tr_na<0, NP>(vf[(t + 1) & 1], vaddr, t + 1);
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vf[t & 1][0]), "+v"(vf[t & 1][1]), "+v"(vf[t & 1][2]), "+v"(vf[t & 1][3]));   // the 8 reads just queued may still be out
+      } else {
+        lgkm_wait4(vf[t & 1][0], vf[t & 1][1], vf[t & 1][2], vf[t & 1][3]);
+      }
   #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(vf[dt], pb, o[dt]);
+      for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(vf[t & 1][dt], pb[t], o[dt]);
     }
     const int q = q0 + (lane & 15);
     if (q < S) {
