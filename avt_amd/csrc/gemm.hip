@@ -100,12 +100,14 @@ __device__ __forceinline__ f32x16_t mma(bf16x8_t a, bf16x8_t b, f32x16_t c) {
 // epilogue of these launches is bound by the vector-ALU issue rate (profiles/r03x_pmc_sq.txt: 353 M non-MFMA vector instructions per
 // launch = 0.26 of the SIMD-cycles next to 0.43 of MFMA).  The table form rounds the biased pre-activation to bf16 (one
 // v_cvt_pk_bf16_f32 per pair -- the same rounding the stored activation would get one step later) and reads {GELU, GELU'} as a packed
-// bf16 pair from a 24-KB LDS table indexed by the bf16 bits: 24 exponents (2^-13 <= |x| < 2^11) x 128 mantissas x sign, generated by
+// bf16 pair from a 24-KB LDS table indexed by the bf16 bits: 24 exponents (2^-16 <= |x| < 2^8) x 128 mantissas x sign, generated by
 // tools/gen/gelu_table.py from the exact erf form in double precision.  11 vector instructions + 2 ds_read_b32 per PAIR of elements.
-// Outside the table: |x| < 2^-13 takes the entry of 2^-13 (|error| <= 3e-5 on GELU, GELU' = 0.5 is exact to bf16); |x| >= 2^11 (or NaN)
+// Outside the table: |x| < 2^-16 takes the entry of 2^-16 (|error| <= 7.7e-6 on GELU, GELU' = 0.5 is exact to bf16); |x| >= 2^8 (or NaN)
 // is handled exactly by a fix-up pass that a block only enters when one of its values is that large (tracked with one v_pk_max_u16 per pair).
-constexpr int GELU_TAB_ELO = 114, GELU_TAB_NEXP = 24, GELU_TAB_NT = GELU_TAB_NEXP * 128;
+constexpr int GELU_TAB_ELO = 111, GELU_TAB_NEXP = 24, GELU_TAB_NT = GELU_TAB_NEXP * 128;
 constexpr int GELU_TAB_BYTES = 2 * GELU_TAB_NT * 4;                       // 24576
+constexpr float GELU_TAB_TOP = 256.f;                                     // = 2^(GELU_TAB_ELO + GELU_TAB_NEXP - 127): first magnitude above the table
+static_assert(GELU_TAB_ELO + GELU_TAB_NEXP - 127 == 8, "GELU_TAB_TOP");
 __device__ const uint32_t g_gelu_tab[2 * GELU_TAB_NT] = {
 #include "gelu_table.inc"
 };
@@ -121,7 +123,8 @@ __device__ __forceinline__ uint32_t gelu_tab_offsets(uint32_t w, u16x2_t& mx) {
   const u16x2_t sg = __builtin_bit_cast(u16x2_t, w) >> (u16x2_t){13, 13};
   return (__builtin_bit_cast(uint32_t, sg) & 0x00040004u) | __builtin_bit_cast(uint32_t, i8);
 }
-// exact values for a pre-activation the table does not cover from above (|x| >= 2^11, inf, NaN): GELU = x | -0, GELU' = 1 | 0
+// exact values for a pre-activation the table does not cover from above (|x| >= 2^8, inf, NaN): GELU = x | -0 (|GELU(x)| < 1e-300 there),
+// GELU' = 1 | 0
 __device__ __forceinline__ void gelu_big(float x, bf16_t& h, bf16_t& d) {
   if (x != x) { h = 0x7fc0; d = 0x7fc0; return; }
   h = x > 0.f ? f2bf(x) : (bf16_t)0x8000; d = x > 0.f ? (bf16_t)0x3f80 : (bf16_t)0;
@@ -133,7 +136,8 @@ __device__ __forceinline__ void gelu_tab_scalar(float x, float& y, float& dy) {
   const uint32_t off = gelu_tab_offsets(pack2bf(x, x), mx) & 0xffffu;
   const uint32_t e = *(const uint32_t*)((const char*)g_gelu_tab + off);
   y = bflo(e); dy = bfhi(e);
-  if (!(fabsf(x) < 2048.f)) { bf16_t hb, db; gelu_big(x, hb, db); y = bf2f(hb); dy = bf2f(db); }
+  const float xr = bf2f(f2bf(x));                                            // the bf16-rounded pre-activation, as in the look-up
+  if (!(fabsf(xr) < GELU_TAB_TOP)) { bf16_t hb, db; gelu_big(xr, hb, db); y = bf2f(hb); dy = bf2f(db); }
 }
 __device__ __forceinline__ void gelu_tab_both4(f32x2_t& x0, f32x2_t& x1, f32x2_t& d0, f32x2_t& d1) {
   float y, d;
@@ -544,8 +548,8 @@ __device__ __forceinline__ void epi_fast_block(const GemmParams& p, const EpiBlk
           const int nl = j * 32 + 8 * q + 4 * h;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float x = blk[j][4 * q + e] + bias_l[nl + e];
-            if (!(fabsf(x) < 2048.f)) {
+            const float x = bf2f(f2bf(blk[j][4 * q + e] + bias_l[nl + e]));       // the bf16-rounded pre-activation, as in the look-up
+            if (!(fabsf(x) < GELU_TAB_TOP)) {
               bf16_t hb, db; gelu_big(x, hb, db);
               *(bf16_t*)(patch_c + ml * LDB + (nl + e) * 2) = hb;
               if (p.C2) *(bf16_t*)(patch_d + ml * LDB + (nl + e) * 2) = db;

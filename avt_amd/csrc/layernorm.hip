@@ -284,6 +284,9 @@ __global__ __launch_bounds__(256) void ln_fwd2_kernel(const bf16_t* __restrict__
 }
 
 
+#ifndef LN_BWD_MINW
+#define LN_BWD_MINW 3
+#endif
 int pick_v(int D) { int nchunk = D / 8; return (nchunk + 63) / 64; }
 
 }  // namespace
@@ -330,7 +333,7 @@ extern "C" int avt_layernorm_bwd(const void* dy, int lddy, const void* x, int ld
     int g = (rows + 3) / 4; if (g > 768) g = 768;
     grid = g;
     AVT_CHECK(!part || part_bytes >= (size_t)3 * grid * D * 4, "avt_layernorm_bwd: partials workspace too small");
-    hipLaunchKernelGGL((ln_bwd_kernel<2, 3, false>), dim3(g), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma,
+    hipLaunchKernelGGL((ln_bwd_kernel<2, LN_BWD_MINW, false>), dim3(g), dim3(256), 0, s, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, mean, rstd, gamma,
                        (const bf16_t*)dres, lddres, (bf16_t*)dx, lddx, dgamma, dbeta, colsum, rows, D, part);
     AVT_LAUNCH_CHECK();
   } else {
