@@ -477,7 +477,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __
       if (dbias) {
         // q part of the qkv-bias gradient: sums over the strip's 16 queries = the 16 lanes of a DPP row (queries past the end of the
         // sequence have all-zero Q / dO / O strips, hence dS = 0 and dQ = 0 exactly: no mask); one 16-byte store per (dt, g)
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // the accumulators come out of the matrix pipe (the assembly below is opaque to the hazard recogniser)
+        // the accumulators come out of the matrix pipe (the assembly below is opaque to the hazard recogniser): the wait states are tied to
+        // the registers, so that no MFMA can be scheduled below them (round-3 advisor finding)
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) lsum16x4(acc[dt]);
         if ((lane & 15) == 0) {
