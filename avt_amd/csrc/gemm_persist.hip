@@ -1,0 +1,497 @@
+// Persistent form of the 8-phase bf16 GEMM (gemm.hip: gemm_8p_kernel) for the large ViT contractions with both operands
+// k-major: C[M,N] = epilogue(A[M,K] . B[N,K]^T), 256x256x64 tiles, eight waves, one workgroup per CU.
+//
+// Why: with K = 768 an output tile is 12 K tiles = 24.6 k cycles of MFMA work per SIMD, and gemm_8p_kernel spends another
+// 14-33 k cycles per tile with the matrix pipe idle (tools/gemm_timeline.py, profiles/r03_tile_timeline.txt): operand fill
+// after the workgroup starts, the epilogue, the drain of its stores before the workgroup can retire, the launch of the next
+// workgroup on the CU.  Here a workgroup stays on its CU and walks a list of output tiles; the reduction stream is continuous
+// across tiles:
+//   * the LDS-DMA stages that gemm_8p_kernel issues past the end of the reduction (zero fill, to keep its counted waits uniform)
+//     fetch the NEXT output tile's first K tile instead (A0h, B0h, B1h, A1h -> the four parity-0 slots of the ring);
+//   * the epilogue then runs in the four parity-1 slots (64 KB) plus the 32 KB (8 KB next to the GELU table) behind the ring,
+//     while those 64 KB of operands arrive; its patches are 128-byte-pitch, XOR-swizzled (4 KB per 32x64 block instead of
+//     4.25 KB) so that two patches -- or one patch and one second-operand buffer -- fit a wave's 8-KB share of a slot;
+//   * the stores of a tile drain under the next tile's first phases (the first counted wait that has to see them retired
+//     is the one of phase 2), nothing waits for them at a workgroup boundary, and the kernel arguments, descriptors, per-lane
+//     offsets and the GELU table are set up once per workgroup instead of once per tile.
+// The second operand of the epilogue (residual / saved derivative) of a tile's first 32-row block is requested two phases
+// before the reduction ends (into the space behind the ring, idle during the K loop); the bias strip is fetched at the start
+// of the last iteration.
+// Results are bit-identical to gemm_8p_kernel's (same MFMA order, same epilogue arithmetic in the same order).
+//
+// Tile order: the XCD-aware order of gemm.hip (an XCD owns a contiguous range of tiles, column strips when B does not fit
+// an L2); workgroup b takes the tiles that blockIdx b, b + G, b + 2G, ... would have been given by the dispatcher.
+#include "gemm_tile.hpp"
+
+namespace {
+
+constexpr int PK_HALF = 128 * 64 * 2;                      // one half-tile slot of the ring: 16 KB
+
+// swizzled wave-private patch [32 rows][128 B]: the 8-byte position q8 (0..15) of row r lives at position q8 ^ (r & 15).
+// Writes (accumulator layout: lane = row, 8 B per (j, q)): the 32 lanes of a half-wave hit 16 positions x 2 rows each = every
+// bank twice (256 B in two cycles); reads (row strips: 8 lanes per row, two 8-byte halves): 4 rows x 8 positions, same.
+__device__ __forceinline__ int patch_wr(int ml, int h, int j, int q) { return ml * 128 + (((8 * j + 2 * q + h) ^ (ml & 15)) << 3); }
+__device__ __forceinline__ int patch_rd(int row, int pc, int half) { return row * 128 + (((2 * pc + half) ^ (row & 15)) << 3); }
+
+// row-strip side of a block: read the lane's 16 bytes of rows it*8 + rl back and store them
+template <bool TWO>
+__device__ __forceinline__ void pk_store_block(const char* patch_c, const char* patch_d, int lane, int i32, const TileStore& sc, const TileStore& sd) {
+  const int rl = lane >> 3, pc = lane & 7;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + rl;
+    const u32x2_t lo = *(const u32x2_t*)(patch_c + patch_rd(row, pc, 0)), hi = *(const u32x2_t*)(patch_c + patch_rd(row, pc, 1));
+    sc.st(i32 + row, pc * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
+    if (TWO) {
+      const u32x2_t lo2 = *(const u32x2_t*)(patch_d + patch_rd(row, pc, 0)), hi2 = *(const u32x2_t*)(patch_d + patch_rd(row, pc, 1));
+      sd.st(i32 + row, pc * 8, (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]});
+    }
+  }
+}
+
+// EPK 0: C = bf16(acc + bias)
+__device__ __forceinline__ void pk_epi_plain(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, const float* bias_l,
+                                             int lane, int row0, int col0) {
+  const int ml = lane & 31, h = lane >> 5;
+  TileStore sc;
+  sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nl = j * 32 + 8 * q + 4 * h;
+        const f32x4_t b = *(const f32x4_t*)(bias_l + nl);
+        const f32x2_t v0 = (f32x2_t){acc[i][j][4 * q], acc[i][j][4 * q + 1]} + (f32x2_t){b[0], b[1]};
+        const f32x2_t v1 = (f32x2_t){acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} + (f32x2_t){b[2], b[3]};
+        *(u32x2_t*)(patch + patch_wr(ml, h, j, q)) = (u32x2_t){pack2bf(v0[0], v0[1]), pack2bf(v1[0], v1[1])};
+      }
+    pk_store_block<false>(patch, patch, lane, i * 32, sc, sc);
+  }
+}
+
+// EPK 1: C = GELU(acc + bias), C2 = GELU'(acc + bias), both by the LDS table (see gemm_tile.hpp: epi_fast_block, TAB)
+__device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const EpiBlk<2> blk_, char* patch_c, char* patch_d, const float* bias_l,
+                                                  int lane, int i32, const TileStore& sc, const TileStore& sd, const char* tab) {
+  const f32x16_t* blk = blk_.t;
+  const int ml = lane & 31, h = lane >> 5;
+  u16x2_t mx = {0, 0};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    uint32_t off[8], e[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nl = j * 32 + 8 * q + 4 * h;
+      const f32x4_t b = *(const f32x4_t*)(bias_l + nl);
+      const f32x2_t v0 = (f32x2_t){blk[j][4 * q], blk[j][4 * q + 1]} + (f32x2_t){b[0], b[1]};
+      const f32x2_t v1 = (f32x2_t){blk[j][4 * q + 2], blk[j][4 * q + 3]} + (f32x2_t){b[2], b[3]};
+      off[2 * q] = gelu_tab_offsets(pack2bf(v0[0], v0[1]), mx);
+      off[2 * q + 1] = gelu_tab_offsets(pack2bf(v1[0], v1[1]), mx);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      e[2 * k] = *(const uint32_t*)(tab + (off[k] & 0xffffu));
+      e[2 * k + 1] = *(const uint32_t*)(tab + (off[k] >> 16));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t h0 = __builtin_amdgcn_perm(e[4 * q + 1], e[4 * q], 0x05040100u), d0 = __builtin_amdgcn_perm(e[4 * q + 1], e[4 * q], 0x07060302u);
+      const uint32_t h1 = __builtin_amdgcn_perm(e[4 * q + 3], e[4 * q + 2], 0x05040100u), d1 = __builtin_amdgcn_perm(e[4 * q + 3], e[4 * q + 2], 0x07060302u);
+      *(u32x2_t*)(patch_d + patch_wr(ml, h, j, q)) = (u32x2_t){d0, d1};
+      *(u32x2_t*)(patch_c + patch_wr(ml, h, j, q)) = (u32x2_t){h0, h1};
+    }
+  }
+  constexpr unsigned short HI = ((GELU_TAB_ELO + GELU_TAB_NEXP) << 7) - 1;
+  if (__builtin_expect(__any((mx[0] > HI) | (mx[1] > HI)), 0)) {          // some value of this block lies above the table: patch those elements
+#pragma unroll 1
+    for (int j = 0; j < 2; ++j)
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {
+        const int nl = j * 32 + 8 * q + 4 * h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = bf2f(f2bf(blk[j][4 * q + e] + bias_l[nl + e]));
+          if (!(fabsf(x) < GELU_TAB_TOP)) {
+            bf16_t hb, db; gelu_big(x, hb, db);
+            *(bf16_t*)(patch_c + patch_wr(ml, h, j, q) + e * 2) = hb;
+            *(bf16_t*)(patch_d + patch_wr(ml, h, j, q) + e * 2) = db;
+          }
+        }
+      }
+  }
+  if (p.C2) pk_store_block<true>(patch_c, patch_d, lane, i32, sc, sd);
+  else pk_store_block<false>(patch_c, patch_d, lane, i32, sc, sd);
+}
+__device__ __forceinline__ void pk_epi_gelu(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch_c, char* patch_d, const float* bias_l,
+                                            int lane, int row0, int col0, const char* tab) {
+  TileStore sc, sd;
+  sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc);
+  sd.init(p.C2 ? p.C2 + (size_t)row0 * p.ldc2 + col0 : (bf16_t*)p.C, p.ldc2);
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {          // one copy of the block's code (instruction cache), the block moved into place
+    EpiBlk<2> b;
+    switch (i) {
+      case 0: b = epi_take<4, 2, 0>(acc); break;
+      case 1: b = epi_take<4, 2, 1>(acc); break;
+      case 2: b = epi_take<4, 2, 2>(acc); break;
+      default: b = epi_take<4, 2, 3>(acc); break;
+    }
+    pk_epi_gelu_block(p, b, patch_c, patch_d, bias_l, lane, i * 32, sc, sd, tab);
+  }
+}
+
+// second operand of the epilogue (EPK 2: residual, EPK 3: saved derivative): 32 rows x 64 columns of bf16 per block, LDS-DMA, the
+// layout of gemm_tile.hpp's epi_fast_ext (position (row r, chunk pc) holds chunk pc ^ ((r >> 1) & 7) of row r)
+struct PkOperand {
+  __amdgpu_buffer_rsrc_t r; int ld;
+  __device__ __forceinline__ void init(const bf16_t* ptr, int ld_) { r = __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0xFFFFFFF0u, 0x00020000); ld = ld_; }
+  __device__ __forceinline__ void dma_block(char* buf, int lane, int row0, int col0, int i) const {
+    const int rl = lane >> 3, pc = lane & 7;
+#pragma unroll
+    for (int itr = 0; itr < 4; ++itr) {
+      const int r_ = itr * 8 + rl;
+      const int m = row0 + i * 32 + r_;
+      const int n = col0 + ((pc ^ ((r_ >> 1) & 7)) * 8);
+      const uint32_t off = (uint32_t)(((size_t)m * (size_t)ld + (size_t)n) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(buf + itr * 1024), 16, off, 0, 0, AVT_LDP_AUX);
+    }
+  }
+};
+
+// EPK 2: C = bf16(acc + bias + res);  EPK 3: C = bf16((acc + 0) * aux), column sums of the rounded outputs.
+// Block 0's operand is already on its way into `buf0` (requested during the last K iteration); blocks 1 and 3 use `buf1`.
+template <int EPK>
+__device__ __forceinline__ void pk_epi_ext(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, char* buf0, char* buf1,
+                                           const PkOperand& op, float bias_v, int lane, int row0, int col0) {
+  const int ml = lane & 31, h = lane >> 5;
+  const int rl = lane >> 3, pc = lane & 7;
+  op.dma_block(buf1, lane, row0, col0, 1);
+  f32x4_t bb[2][4];
+  if (EPK == 2) {          // the bias strip goes through the (still unused) patch once: lane l holds bias[col0 + l]
+    ((float*)patch)[lane] = bias_v;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bb[j][q] = *(const f32x4_t*)(patch + (j * 32 + 8 * q + 4 * h) * 4);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bb[j][q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+  TileStore sc;
+  sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc);
+  float cs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cs[k] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // VMEM operations younger than DMA(i): i = 0: DMA(1);  1: stores(0), DMA(2);  2: stores(0) [DMA(2) is DMA(i)], ... -- as in epi_fast_ext:
+    // i = 0: 4;  i = 1: 8;  i = 2: 12;  i = 3: 8 (one store per row strip)
+    switch (i) {
+      case 0: wait_vmcnt<4>(); break;
+      case 1: wait_vmcnt<8>(); break;
+      case 2: wait_vmcnt<12>(); break;
+      default: wait_vmcnt<8>(); break;
+    }
+    const char* buf = (i & 1) ? buf1 : buf0;
+    u32x2_t opv[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        opv[j][q] = *(const u32x2_t*)(buf + ml * 128 + (((j * 4 + q) ^ ((ml >> 1) & 7)) * 16) + h * 8);
+    if (i + 2 < 4) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer's previous contents are in registers
+      op.dma_block((i & 1) ? buf1 : buf0, lane, row0, col0, i + 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x2_t v0 = (f32x2_t){acc[i][j][4 * q], acc[i][j][4 * q + 1]} + (f32x2_t){bb[j][q][0], bb[j][q][1]};
+        f32x2_t v1 = (f32x2_t){acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} + (f32x2_t){bb[j][q][2], bb[j][q][3]};
+        const f32x2_t o0 = (f32x2_t){bflo(opv[j][q][0]), bfhi(opv[j][q][0])}, o1 = (f32x2_t){bflo(opv[j][q][1]), bfhi(opv[j][q][1])};
+        if (EPK == 3) { v0 *= o0; v1 *= o1; } else { v0 += o0; v1 += o1; }
+        *(u32x2_t*)(patch + patch_wr(ml, h, j, q)) = (u32x2_t){pack2bf(v0[0], v0[1]), pack2bf(v1[0], v1[1])};
+      }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + rl;
+      const u32x2_t lo = *(const u32x2_t*)(patch + patch_rd(row, pc, 0)), hi = *(const u32x2_t*)(patch + patch_rd(row, pc, 1));
+      sc.st(i * 32 + row, pc * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
+      if (EPK == 3 && p.colsum) {
+        cs[0] += bflo(lo[0]); cs[1] += bfhi(lo[0]); cs[2] += bflo(lo[1]); cs[3] += bfhi(lo[1]);
+        cs[4] += bflo(hi[0]); cs[5] += bfhi(hi[0]); cs[6] += bflo(hi[1]); cs[7] += bfhi(hi[1]);
+      }
+    }
+  }
+  if (EPK == 3 && p.colsum) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) cs[q] += __shfl_xor(cs[q], o, 64);
+    }
+    if (lane < 8) {
+      if (p.colsum_part) {
+        float* dst = p.colsum_part + (size_t)(row0 / 128) * p.N + col0 + pc * 8;
+        *(f32x4_t*)dst = (f32x4_t){cs[0], cs[1], cs[2], cs[3]};
+        *(f32x4_t*)(dst + 4) = (f32x4_t){cs[4], cs[5], cs[6], cs[7]};
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) unsafeAtomicAdd(&p.colsum[col0 + pc * 8 + q], cs[q]);
+      }
+    }
+  }
+}
+
+// EPK: 0 = bias | 1 = bias, GELU (+ GELU') by table | 2 = bias, + residual | 3 = * saved derivative (+ column sums)
+template <int EPK>
+__global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p) {
+  constexpr int BK = 64, HALF = PK_HALF;
+  constexpr int TABB = (EPK == 1) ? GELU_TAB_BYTES : 0;
+  constexpr bool HAS_OP = (EPK == 2 || EPK == 3);
+  extern __shared__ __attribute__((aligned(16))) char smem8[];
+  char* const lds = smem8 + TABB;                       // the ring: 8 half-tile slots (kind x K-tile parity), as in gemm_8p_kernel
+  char* const ext = lds + 8 * HALF;                     // behind the ring: 32 KB (8 KB next to the table), idle during the K loop
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+  if constexpr (EPK == 1) {       // the table: once per workgroup
+    __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)g_gelu_tab, 0, GELU_TAB_BYTES, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < GELU_TAB_BYTES / (8 * 1024); ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, AVT_LDS_PTR(smem8 + (wave * (GELU_TAB_BYTES / 8192) + i) * 1024), 16,
+                                               (uint32_t)((wave * (GELU_TAB_BYTES / 8192) + i) * 1024 + lane * 16), 0, 0, 0);
+  }
+  // the wave's epilogue space: 8 KB in a parity-1 slot (two waves per slot), and its share of the space behind the ring
+  char* const P1 = lds + (2 * wn + 1) * HALF + grp * 8192;
+  char* const P2 = ext + wave * (EPK == 1 ? 1024 : 4096);
+
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int nk = p.K / BK;                               // even, >= 4 (host-checked)
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t ra_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0, 0x00020000);
+
+  // per-lane source offsets of the wave's two DMA instructions per half-tile, relative to the tile's origin and K tile 0.  They (and
+  // the fragment addresses) are re-derived from an opaque copy of the lane id at the start of every tile, so that none of the K
+  // loop's per-lane state stays in registers across the epilogue
+  uint32_t offA[2][2], offB[2][2];
+  int lane_k = lane;
+  auto lane_state = [&]() __attribute__((always_inline)) {
+    lane_k = lane;
+    asm volatile("" : "+v"(lane_k));
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = j * 64 + wave * 8 + (lane_k >> 3);                         // LDS row of the half-tile
+        const int c = (lane_k & 7) ^ kmajor_swz<BK>(r);
+        offA[h][j] = (uint32_t)(((size_t)(j * 128 + (r & 63) + h * 64) * (size_t)p.lda + (size_t)(c * 8)) * 2);
+        offB[h][j] = (uint32_t)(((size_t)((r >> 5) * 64 + (r & 31) + h * 32) * (size_t)p.ldb + (size_t)(c * 8)) * 2);
+      }
+  };
+  lane_state();
+  char* const dstw = lds + wave * 8 * (BK * 2);
+  constexpr int JSTEP = 8192;
+
+  // tile walk (32-bit byte offsets: every operand is below 4 GiB)
+  struct Tile { int tm0, tn0; uint32_t a, b; };
+  auto tile_at = [&](int vb) __attribute__((always_inline)) {
+    const int t_ = xcd_remap(vb, ntile);
+    int tm_i, tn_i;
+    if (p.strip_w > 0) {
+      const int per = p.tiles_m * p.strip_w;
+      const int strip = t_ / per, r_ = t_ - strip * per;
+      const int w_ = min(p.strip_w, p.tiles_n - strip * p.strip_w);
+      tm_i = r_ / w_; tn_i = strip * p.strip_w + (r_ - tm_i * w_);
+    } else { tm_i = t_ / p.tiles_n; tn_i = t_ - tm_i * p.tiles_n; }
+    Tile t;
+    t.tm0 = tm_i * 256; t.tn0 = tn_i * 256;
+    t.a = (uint32_t)t.tm0 * (uint32_t)p.lda * 2u; t.b = (uint32_t)t.tn0 * (uint32_t)p.ldb * 2u;
+    return t;
+  };
+  int vb = blockIdx.x;
+  const int vstep = gridDim.x;
+  Tile cur = tile_at(vb), nxt = cur;
+  bool has_next = vb + vstep < ntile;
+  if (has_next) nxt = tile_at(vb + vstep);
+
+  // slot index = kind * 2 + (K tile & 1); kinds 0 = A0h, 1 = B0h, 2 = B1h, 3 = A1h.  kt counts the current tile's K tiles; kt == nk is
+  // K tile 0 of the next output tile (zero fill through an empty descriptor when there is none)
+  auto stage_a = [&](int h, int kt) __attribute__((always_inline)) {
+    const bool in = kt < nk;
+    const __amdgpu_buffer_rsrc_t r = (in || has_next) ? ra : ra_null;
+    const uint32_t adv = in ? cur.a + (uint32_t)kt * (BK * 2) : nxt.a + (uint32_t)(kt - nk) * (BK * 2);
+    char* d = dstw + ((h ? 3 : 0) * 2 + (kt & 1)) * HALF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offA[h][j] + adv, 0, 0, AVT_LDA_AUX);
+  };
+  auto stage_b = [&](int h, int kt) __attribute__((always_inline)) {
+    const bool in = kt < nk;
+    const __amdgpu_buffer_rsrc_t r = (in || has_next) ? rb : rb_null;
+    const uint32_t adv = in ? cur.b + (uint32_t)kt * (BK * 2) : nxt.b + (uint32_t)(kt - nk) * (BK * 2);
+    char* d = dstw + ((h ? 2 : 1) * 2 + (kt & 1)) * HALF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offB[h][j] + adv, 0, 0, AVT_LDB_AUX);
+  };
+  bf16x8_t fa[2][4], fb0[4], fb1[4], fb0n[4];
+  auto read_a = [&](bf16x8_t (&f)[2][4], int h, int par) __attribute__((always_inline)) {
+    const char* slot = lds + ((h ? 3 : 0) * 2 + par) * HALF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) f[i][ks] = frag_kmajor<BK>(slot + grp * 64 * (BK * 2), i, ks, lane_k);
+  };
+  auto read_b = [&](bf16x8_t (&f)[4], int h, int par) __attribute__((always_inline)) {
+    const char* slot = lds + ((h ? 2 : 1) * 2 + par) * HALF;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) f[ks] = frag_kmajor<BK>(slot + wn * 32 * (BK * 2), 0, ks, lane_k);
+  };
+
+  PkOperand op;
+  if (HAS_OP) op.init(EPK == 3 ? p.aux : p.res, EPK == 3 ? p.ldaux : p.ldres);
+
+#define P8_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define P8_PIN() __builtin_amdgcn_sched_barrier(0)
+#define P8_MFMA(FA, FB, I0, J)                                                                          \
+  do {                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                     \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
+        acc[(I0) + i][J] = mma<0>(FA[i][ks], FB[ks], acc[(I0) + i][J]);                                  \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  } while (0)
+// the first touch of an accumulator quadrant in a tile (phases 0-3 of its first iteration) starts from the MFMA's zero operand
+// instead of 128 v_mov_b32 per wave and tile
+#define P8_MFMA0(FA, FB, I0, J)                                                                         \
+  do {                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    if (t == 0) {                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[(I0) + i][J] = mma<0>(FA[i][0], FB[0], zero16);  \
+    } else {                                                                                             \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) acc[(I0) + i][J] = mma<0>(FA[i][0], FB[0], acc[(I0) + i][J]); \
+    }                                                                                                    \
+    _Pragma("unroll") for (int ks = 1; ks < 4; ++ks)                                                     \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                      \
+        acc[(I0) + i][J] = mma<0>(FA[i][ks], FB[ks], acc[(I0) + i][J]);                                  \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  } while (0)
+
+  // first tile: its K tile 0 (the later tiles find theirs in the ring when they start)
+  stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
+  wait_vmcnt<0>();
+  P8_BARRIER();
+
+  for (;;) {
+    // here: the four parity-0 slots hold K tile 0 of `cur`, every other slot is free, nothing but stores is in flight
+    stage_a(0, 1); stage_b(0, 1);
+    if (grp == 1) P8_BARRIER();
+    f32x16_t acc[4][2];                                     // (first written by the zero-operand MFMAs of iteration 0)
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float bias_v = 0.f;
+    const int m0_e = cur.tm0 + grp * 128, n0_e = cur.tn0 + wn * 64;
+    read_b(fb0, 0, 0);
+#pragma nounroll
+    for (int t = 0; t < nk; t += 2) {
+      const bool last = t + 2 >= nk;
+      // ---- even K tile t (slot parity 0).  t == 0: B1h / A1h of K tile 0 landed before the epilogue's barrier -- no counted wait
+      //      (a vmcnt(8) there would wait for the previous tile's stores) ----
+      read_a(fa, 0, 0); P8_PIN(); stage_b(1, t + 1); if (t) wait_vmcnt<8>(); P8_BARRIER();
+      P8_MFMA0(fa, fb0, 0, 0); P8_BARRIER();
+      read_b(fb1, 1, 0); P8_PIN(); stage_a(1, t + 1); if (t) wait_vmcnt<8>(); P8_BARRIER();
+      P8_MFMA0(fa, fb1, 0, 1); P8_BARRIER();
+      read_a(fa, 1, 0); P8_PIN(); stage_a(0, t + 2); wait_vmcnt<6>(); P8_BARRIER();
+      P8_MFMA0(fa, fb1, 2, 1); P8_BARRIER();
+      read_b(fb0n, 0, 1); P8_PIN(); stage_b(0, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+      P8_MFMA0(fa, fb0, 2, 0); P8_BARRIER();
+      // ---- odd K tile t+1 (slot parity 1).  In the last iteration the stages of "K tile nk" fetch the next output tile's K tile 0;
+      //      those of K tile nk + 1 are left out (their slots become the epilogue's) ----
+      if (last && (EPK == 0 || EPK == 1 || EPK == 2) && p.bias) bias_v = p.bias[n0_e + lane_k];   // used two phases later at the earliest
+      read_a(fa, 0, 1); P8_PIN(); stage_b(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+      P8_MFMA(fa, fb0n, 0, 0); P8_BARRIER();
+      read_b(fb1, 1, 1); P8_PIN(); stage_a(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+      P8_MFMA(fa, fb1, 0, 1); P8_BARRIER();
+      read_a(fa, 1, 1); P8_PIN();
+      if (!last) { stage_a(0, t + 3); wait_vmcnt<6>(); }
+      else {
+        if (HAS_OP) op.dma_block(P2, lane_k, m0_e, n0_e, 0);          // the epilogue's second operand, block 0 -> behind the ring
+      }
+      P8_BARRIER();
+      P8_MFMA(fa, fb1, 2, 1); P8_BARRIER();
+      if (!last) { read_b(fb0, 0, 0); P8_PIN(); stage_b(0, t + 3); wait_vmcnt<8>(); }
+      P8_BARRIER();
+      P8_MFMA(fa, fb0n, 2, 0); P8_BARRIER();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (grp == 0) P8_BARRIER();
+    P8_BARRIER();                                          // every fragment read retired: the parity-1 slots are free
+    {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      if constexpr (EPK == 0) {
+        ((float*)P2)[lane_e] = bias_v;
+        pk_epi_plain(p, acc, P1, (const float*)P2, lane_e, m0_e, n0_e);
+      } else if constexpr (EPK == 1) {
+        ((float*)P2)[lane_e] = bias_v;
+        pk_epi_gelu(p, acc, P1, P1 + 4096, (const float*)P2, lane_e, m0_e, n0_e, smem8);
+      } else {
+        pk_epi_ext<EPK>(p, acc, P1, P2, P1 + 4096, op, bias_v, lane_e, m0_e, n0_e);
+      }
+    }
+    wait_vmcnt<16>();                                      // everything older than the tile's last 16 stores: the next tile's K tile 0
+    P8_BARRIER();                                          // ... for every wave's share of it; and every patch has been read back
+    if (!has_next) break;
+    lane_state();
+    vb += vstep;
+    cur = nxt;
+    has_next = vb + vstep < ntile;
+    if (has_next) nxt = tile_at(vb + vstep);
+  }
+#undef P8_PIN
+#undef P8_MFMA
+#undef P8_MFMA0
+#undef P8_BARRIER
+}
+
+template <int EPK>
+int launch_8pp(const GemmParams& p, int grid, hipStream_t s) {
+  constexpr int smem = 8 * PK_HALF + (EPK == 1 ? GELU_TAB_BYTES + 8192 : 32768);
+  static_assert(smem <= 160 * 1024, "persistent 8-phase kernel: LDS");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_8pp_kernel<EPK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_8pp_kernel<EPK>), dim3(grid), dim3(512), smem, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 1;
+}
+
+}  // namespace
+
+int avt_gemm_persist(GemmParams& p, int kinds, hipStream_t s) {
+  // covered: full 256x256 tiles, an even number (>= 4) of 64-wide K tiles, bf16 output through 16-byte stores, one of the four epilogues
+  if (p.splitk != 1 || p.out_f32 || !p.wide_ok || p.drop_thresh || p.res_period) return 0;
+  if (p.M % 256 || p.N % 256 || p.K % 128 || p.K < 256) return 0;
+  const int ntile = p.tiles_m * p.tiles_n;
+  if (ntile < 512) return 0;                                // fewer than two tiles per CU: nothing to overlap
+  if ((uint64_t)p.a_bytes + 256ull * p.lda * 2 >= (1ull << 32) || (uint64_t)p.b_bytes + 256ull * p.ldb * 2 >= (1ull << 32)) return 0;
+  const int grid = 256;                                     // one workgroup per CU (a multiple of the 8 XCDs)
+  if ((kinds & 1) && p.act == 0 && !p.res && !p.colsum && !p.C2) return launch_8pp<0>(p, grid, s);
+  if ((kinds & 2) && p.act == 1 && !p.res && !p.colsum) return launch_8pp<1>(p, grid, s);
+  if ((kinds & 4) && p.act == 0 && p.res && !p.colsum && !p.C2) return launch_8pp<2>(p, grid, s);
+  if ((kinds & 8) && p.act == 3 && p.aux && !p.res && !p.bias && !p.C2) return launch_8pp<3>(p, grid, s);
+  return 0;
+}

@@ -1,0 +1,102 @@
+"""Persistent 8-phase GEMM (gemm_persist.hip) against gemm_8p_kernel on the ViT-B shapes of the 256-clip step: bit equality and time per launch.
+Needs the lab library (AVT_HIP_LIB=avt_amd/libavt_hip_lab.so): AVT_GEMM_PERSIST = bit mask of the epilogue kinds routed to the persistent kernel.
+usage: python tools/lab/persist_check.py [frames=2560] [kinds=15]"""
+import os
+import sys
+import torch
+
+sys.path.insert(0, '.')
+from avt_amd import ops  # noqa: E402
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2560
+kinds = int(sys.argv[2]) if len(sys.argv) > 2 else 15
+M = frames * 197
+M -= M % 256
+dev = 'cuda'
+g = torch.Generator(device=dev).manual_seed(1)
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(shape, device=dev, generator=g) * scale).to(torch.bfloat16)
+
+
+def timed(fn, it=8):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / it
+
+
+x768 = rnd(M, 768)
+x2304 = rnd(M, 2304, scale=0.5)
+x3072 = rnd(M, 3072, scale=0.5)
+resid = rnd(M, 768)
+pre = rnd(M, 3072)
+cases = [
+    # name, kind bit, A, N, kwargs
+    ('qkv fwd   K=768  N=2304 bias', 1, x768, 2304, dict(bias=True)),
+    ('fc1 dgrad K=3072 N=768', 1, x3072, 768, dict()),
+    ('qkv dgrad K=2304 N=768', 1, x2304, 768, dict()),
+    ('fc1 fwd   K=768  N=3072 gelu+c2', 2, x768, 3072, dict(bias=True, act=ops.ACT_GELU_ERF, c2=True)),
+    ('proj fwd  K=768  N=768 bias+res', 4, x768, 768, dict(bias=True, res=True)),
+    ('fc2 fwd   K=3072 N=768 bias+res', 4, x3072, 768, dict(bias=True, res=True)),
+    ('fc2 dgrad K=768  N=3072 *aux colsum', 8, x768, 3072, dict(act=ops.ACT_MUL_AUX, aux=True, colsum=True)),
+]
+ok = True
+for name, bit, A, N, kw in cases:
+    if not (kinds & bit):
+        continue
+    K = A.size(1)
+    W = rnd(N, K, scale=0.03)
+    args = {}
+    if kw.get('bias'):
+        args['bias'] = torch.randn(N, device=dev, generator=g)
+    if 'act' in kw:
+        args['act'] = kw['act']
+    if kw.get('res'):
+        args['res'] = resid
+    if kw.get('aux'):
+        args['aux'] = pre
+
+    def run():
+        a = dict(args)
+        c2 = torch.empty((M, N), device=dev, dtype=torch.bfloat16) if kw.get('c2') else None
+        cs = torch.zeros(N, device=dev) if kw.get('colsum') else None
+        if c2 is not None:
+            a['c2'] = c2
+        if cs is not None:
+            a['colsum'] = cs
+        out = ops.linear_fwd(A, W, **a)
+        return out, c2, cs
+
+    res = {}
+    for mode in ('0', str(kinds)):
+        os.environ['AVT_GEMM_PERSIST'] = mode
+        out, c2, cs = run()
+        torch.cuda.synchronize()
+        us = timed(lambda: run())
+        res[mode] = (out, c2, cs, us)
+    o0, c0, s0, t0 = res['0']
+    o1, c1, s1, t1 = res[str(kinds)]
+    same = torch.equal(o0.view(torch.int16), o1.view(torch.int16))
+    if c0 is not None:
+        same = same and torch.equal(c0.view(torch.int16), c1.view(torch.int16))
+    if s0 is not None:
+        same = same and torch.equal(s0, s1)
+    nbad = (o0.view(torch.int16) != o1.view(torch.int16)).sum().item()
+    ok = ok and same
+    tf = 2.0 * M * N * K / 1e12
+    print(f'{name:38s} 8p {t0:8.1f} us ({tf / t0 * 1e6 / 1e3:5.3f} PF/s)   persistent {t1:8.1f} us ({tf / t1 * 1e6 / 1e3:5.3f} PF/s)   '
+          f'{(t0 / t1 - 1) * 100:+5.1f} %   bit-equal {same} (diff elems {nbad})', flush=True)
+    if not same:
+        d = (o0.float() - o1.float()).abs()
+        idx = torch.nonzero(o0.view(torch.int16) != o1.view(torch.int16))
+        print('   max abs diff', d.max().item(), ' first diffs at', idx[:6].tolist(), ' rows%256', sorted(set((idx[:2000, 0] % 256).tolist()))[:40],
+              ' cols%256', sorted(set((idx[:2000, 1] % 256).tolist()))[:40], flush=True)
+print('ALL BIT-EQUAL' if ok else 'MISMATCH', flush=True)
