@@ -19,8 +19,15 @@
 // of the last iteration.
 // Results are bit-identical to gemm_8p_kernel's (same MFMA order, same epilogue arithmetic in the same order).
 //
-// Tile order: the XCD-aware order of gemm.hip (an XCD owns a contiguous range of tiles, column strips when B does not fit
-// an L2); workgroup b takes the tiles that blockIdx b, b + G, b + 2G, ... would have been given by the dispatcher.
+// Tile order and scheduling: the XCD-aware order of gemm.hip (an XCD owns a contiguous range of tiles, column strips when B does
+// not fit an L2), handed out dynamically: one ticket counter per XCD in device memory, a workgroup (which reads its XCC_ID) draws the
+// next tile of its XCD's range.  A workgroup that finds a CU only late -- the collectives of a data-parallel step occupy CUs while
+// the backward GEMMs run -- draws what is left or nothing; a static assignment would make such a launch take twice as long.
+// The ticket for the tile after next is requested by wave 0 during the epilogue (a returning atomic issued before the tile's stores,
+// so that in-order retirement has it back by the counted wait at the epilogue's end) and reaches the other waves through LDS at the
+// barrier that ends the epilogue; the last workgroup to leave zeroes the counters for the next launch on the stream.
+// (Built with -mllvm -amdgpu-atomic-optimizer-strategy=None: the optimizer would turn the one-lane atomic into a wave reduction
+// followed by an immediate s_waitcnt vmcnt(0).)
 #include "gemm_tile.hpp"
 
 namespace {
@@ -32,6 +39,20 @@ constexpr int PK_HALF = 128 * 64 * 2;                      // one half-tile slot
 // bank twice (256 B in two cycles); reads (row strips: 8 lanes per row, two 8-byte halves): 4 rows x 8 positions, same.
 __device__ __forceinline__ int patch_wr(int ml, int h, int j, int q) { return ml * 128 + (((8 * j + 2 * q + h) ^ (ml & 15)) << 3); }
 __device__ __forceinline__ int patch_rd(int row, int pc, int half) { return row * 128 + (((2 * pc + half) ^ (row & 15)) << 3); }
+
+// the lane id, re-derived where it is needed (volatile: not merged with an earlier copy, so no register holds it across the K loop)
+__device__ __forceinline__ int pk_lane_id() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+// `tkt` != nullptr in wave 0 while tiles may be left: lane 0 draws the ticket for the tile after next (the value is back when the
+// counted wait at the end of the epilogue has passed)
+__device__ __forceinline__ int pk_ticket(int* tkt, int lane) {
+  int tk = 0x7fffffff;
+  if (tkt && lane == 0) tk = __hip_atomic_fetch_add(tkt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return tk;
+}
 
 // row-strip side of a block: read the lane's 16 bytes of rows it*8 + rl back and store them
 template <bool TWO>
@@ -128,15 +149,10 @@ __device__ __forceinline__ void pk_epi_gelu(const GemmParams& p, const f32x16_t 
   TileStore sc, sd;
   sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc);
   sd.init(p.C2 ? p.C2 + (size_t)row0 * p.ldc2 + col0 : (bf16_t*)p.C, p.ldc2);
-#pragma unroll 1
-  for (int i = 0; i < 4; ++i) {          // one copy of the block's code (instruction cache), the block moved into place
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {          // (unrolled: a single copy of the block's code would need the block moved into place -- 32 more registers)
     EpiBlk<2> b;
-    switch (i) {
-      case 0: b = epi_take<4, 2, 0>(acc); break;
-      case 1: b = epi_take<4, 2, 1>(acc); break;
-      case 2: b = epi_take<4, 2, 2>(acc); break;
-      default: b = epi_take<4, 2, 3>(acc); break;
-    }
+    b.t[0] = acc[i][0]; b.t[1] = acc[i][1];
     pk_epi_gelu_block(p, b, patch_c, patch_d, bias_l, lane, i * 32, sc, sd, tab);
   }
 }
@@ -162,8 +178,9 @@ struct PkOperand {
 // EPK 2: C = bf16(acc + bias + res);  EPK 3: C = bf16((acc + 0) * aux), column sums of the rounded outputs.
 // Block 0's operand is already on its way into `buf0` (requested during the last K iteration); blocks 1 and 3 use `buf1`.
 template <int EPK>
-__device__ __forceinline__ void pk_epi_ext(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, char* buf0, char* buf1,
-                                           const PkOperand& op, float bias_v, int lane, int row0, int col0) {
+__device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, char* buf0, char* buf1,
+                                          const PkOperand& op, float bias_v, int lane, int row0, int col0, int* tkt) {
+  int tk = 0x7fffffff;
   const int ml = lane & 31, h = lane >> 5;
   const int rl = lane >> 3, pc = lane & 7;
   op.dma_block(buf1, lane, row0, col0, 1);
@@ -189,9 +206,11 @@ __device__ __forceinline__ void pk_epi_ext(const GemmParams& p, const f32x16_t (
   for (int i = 0; i < 4; ++i) {
     // VMEM operations younger than DMA(i): i = 0: DMA(1);  1: stores(0), DMA(2);  2: stores(0) [DMA(2) is DMA(i)], ... -- as in epi_fast_ext:
     // i = 0: 4;  i = 1: 8;  i = 2: 12;  i = 3: 8 (one store per row strip)
+    // The wave that draws a ticket does so right after the wait of block 0 (one more operation younger than DMA(1): its wait of block 1
+    // allows 9; the ticket has two blocks' time to return before the wait of block 2 needs it retired)
     switch (i) {
-      case 0: wait_vmcnt<4>(); break;
-      case 1: wait_vmcnt<8>(); break;
+      case 0: wait_vmcnt<4>(); tk = pk_ticket(tkt, lane); break;
+      case 1: if (tkt) wait_vmcnt<9>(); else wait_vmcnt<8>(); break;
       case 2: wait_vmcnt<12>(); break;
       default: wait_vmcnt<8>(); break;
     }
@@ -244,11 +263,12 @@ __device__ __forceinline__ void pk_epi_ext(const GemmParams& p, const f32x16_t (
       }
     }
   }
+  return tk;
 }
 
 // EPK: 0 = bias | 1 = bias, GELU (+ GELU') by table | 2 = bias, + residual | 3 = * saved derivative (+ column sums)
 template <int EPK>
-__global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p) {
+__global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, int* __restrict__ sched) {
   constexpr int BK = 64, HALF = PK_HALF;
   constexpr int TABB = (EPK == 1) ? GELU_TAB_BYTES : 0;
   constexpr bool HAS_OP = (EPK == 2 || EPK == 3);
@@ -283,8 +303,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p) {
   uint32_t offA[2][2], offB[2][2];
   int lane_k = lane;
   auto lane_state = [&]() __attribute__((always_inline)) {
-    lane_k = lane;
-    asm volatile("" : "+v"(lane_k));
+    lane_k = pk_lane_id();
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -301,8 +320,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p) {
 
   // tile walk (32-bit byte offsets: every operand is below 4 GiB)
   struct Tile { int tm0, tn0; uint32_t a, b; };
-  auto tile_at = [&](int vb) __attribute__((always_inline)) {
-    const int t_ = xcd_remap(vb, ntile);
+  auto tile_at = [&](int t_) __attribute__((always_inline)) {        // t_ = position in the XCD-ordered walk (see gemm.hip: xcd_remap)
     int tm_i, tn_i;
     if (p.strip_w > 0) {
       const int per = p.tiles_m * p.strip_w;
@@ -315,11 +333,23 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p) {
     t.a = (uint32_t)t.tm0 * (uint32_t)p.lda * 2u; t.b = (uint32_t)t.tn0 * (uint32_t)p.ldb * 2u;
     return t;
   };
-  int vb = blockIdx.x;
-  const int vstep = gridDim.x;
-  Tile cur = tile_at(vb), nxt = cur;
-  bool has_next = vb + vstep < ntile;
-  if (has_next) nxt = tile_at(vb + vstep);
+  // this XCD's range of the walk and its ticket counter (one 128-byte line per XCD; sched[8 * 32] counts the workgroups that have left)
+  uint32_t xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  const int xq = ntile >> 3, xr = ntile & 7;
+  const int x_start = ((int)xcc < xr) ? (int)xcc * (xq + 1) : xr * (xq + 1) + ((int)xcc - xr) * xq;
+  const int x_cnt = xq + (((int)xcc < xr) ? 1 : 0);
+  int* const my_counter = sched + xcc * 32;
+  int* const mailbox = (int*)(ext + 512);                 // free at both times it is used (start of the kernel, end of an epilogue)
+  // the first two tickets
+  if (tid == 0) mailbox[0] = __hip_atomic_fetch_add(my_counter, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int tk0 = __builtin_amdgcn_readfirstlane(mailbox[0]);
+  __syncthreads();
+  bool has_cur = tk0 < x_cnt, has_next = tk0 + 1 < x_cnt;
+  Tile cur = tile_at(x_start + (has_cur ? tk0 : 0)), nxt = cur;
+  if (has_next) nxt = tile_at(x_start + tk0 + 1);
 
   // slot index = kind * 2 + (K tile & 1); kinds 0 = A0h, 1 = B0h, 2 = B1h, 3 = A1h.  kt counts the current tile's K tiles; kt == nk is
   // K tile 0 of the next output tile (zero fill through an empty descriptor when there is none)
@@ -389,11 +419,19 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p) {
   } while (0)
 
   // first tile: its K tile 0 (the later tiles find theirs in the ring when they start)
+  if (has_cur) {
   stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
   wait_vmcnt<0>();
   P8_BARRIER();
 
+#ifdef AVT_LAB
+  int tile_k = 0;
+#endif
   for (;;) {
+#ifdef AVT_LAB
+    long long ts_top = 0, ts_loop = 0, ts_epi = 0, ts_w2 = 0;
+    if (p.dbg) ts_top = __builtin_readcyclecounter();
+#endif
     // here: the four parity-0 slots hold K tile 0 of `cur`, every other slot is free, nothing but stores is in flight
     stage_a(0, 1); stage_b(0, 1);
     if (grp == 1) P8_BARRIER();
@@ -411,13 +449,20 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p) {
       P8_MFMA0(fa, fb0, 0, 0); P8_BARRIER();
       read_b(fb1, 1, 0); P8_PIN(); stage_a(1, t + 1); if (t) wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA0(fa, fb1, 0, 1); P8_BARRIER();
+#ifdef AVT_LAB
+      long long tw0 = 0;
+      if (p.dbg && t == 0) tw0 = __builtin_readcyclecounter();
+#endif
       read_a(fa, 1, 0); P8_PIN(); stage_a(0, t + 2); wait_vmcnt<6>(); P8_BARRIER();
+#ifdef AVT_LAB
+      if (p.dbg && t == 0) ts_w2 = __builtin_readcyclecounter() - tw0;
+#endif
       P8_MFMA0(fa, fb1, 2, 1); P8_BARRIER();
       read_b(fb0n, 0, 1); P8_PIN(); stage_b(0, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA0(fa, fb0, 2, 0); P8_BARRIER();
       // ---- odd K tile t+1 (slot parity 1).  In the last iteration the stages of "K tile nk" fetch the next output tile's K tile 0;
       //      those of K tile nk + 1 are left out (their slots become the epilogue's) ----
-      if (last && (EPK == 0 || EPK == 1 || EPK == 2) && p.bias) bias_v = p.bias[n0_e + lane_k];   // used two phases later at the earliest
+      if (last && (EPK == 0 || EPK == 1 || EPK == 2) && p.bias) bias_v = p.bias[n0_e + pk_lane_id()];   // used two phases later at the earliest
       read_a(fa, 0, 1); P8_PIN(); stage_b(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb0n, 0, 0); P8_BARRIER();
       read_b(fb1, 1, 1); P8_PIN(); stage_a(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
@@ -425,7 +470,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p) {
       read_a(fa, 1, 1); P8_PIN();
       if (!last) { stage_a(0, t + 3); wait_vmcnt<6>(); }
       else {
-        if (HAS_OP) op.dma_block(P2, lane_k, m0_e, n0_e, 0);          // the epilogue's second operand, block 0 -> behind the ring
+        if (HAS_OP) op.dma_block(P2, pk_lane_id(), m0_e, n0_e, 0);          // the epilogue's second operand, block 0 -> behind the ring
       }
       P8_BARRIER();
       P8_MFMA(fa, fb1, 2, 1); P8_BARRIER();
@@ -436,32 +481,78 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (grp == 0) P8_BARRIER();
     P8_BARRIER();                                          // every fragment read retired: the parity-1 slots are free
+#ifdef AVT_LAB
+    if (p.dbg) ts_loop = __builtin_readcyclecounter();
+#endif
+    int tk;
     {
-      int lane_e = lane;
-      asm volatile("" : "+v"(lane_e));
+      const int lane_e = pk_lane_id();
+      int* const tkt = (wave == 0 && has_next) ? my_counter : nullptr;       // wave 0 draws the ticket for the tile after next
       if constexpr (EPK == 0) {
+        tk = pk_ticket(tkt, lane_e);
         ((float*)P2)[lane_e] = bias_v;
         pk_epi_plain(p, acc, P1, (const float*)P2, lane_e, m0_e, n0_e);
       } else if constexpr (EPK == 1) {
+        tk = pk_ticket(tkt, lane_e);
         ((float*)P2)[lane_e] = bias_v;
         pk_epi_gelu(p, acc, P1, P1 + 4096, (const float*)P2, lane_e, m0_e, n0_e, smem8);
       } else {
-        pk_epi_ext<EPK>(p, acc, P1, P2, P1 + 4096, op, bias_v, lane_e, m0_e, n0_e);
+        tk = pk_epi_ext<EPK>(p, acc, P1, P2, P1 + 4096, op, bias_v, lane_e, m0_e, n0_e, tkt);
       }
     }
-    wait_vmcnt<16>();                                      // everything older than the tile's last 16 stores: the next tile's K tile 0
+#ifdef AVT_LAB
+    if (p.dbg) ts_epi = __builtin_readcyclecounter();
+#endif
+    wait_vmcnt<16>();                                      // everything older than the tile's last 16 stores: the next tile's K tile 0, the ticket
+    if (wave == 0 && pk_lane_id() == 0) mailbox[0] = tk;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     P8_BARRIER();                                          // ... for every wave's share of it; and every patch has been read back
+#ifdef AVT_LAB
+    if (p.dbg && (tid == 0 || tid == 256) && tile_k < 128) {   // tile start, end of K loop, epilogue issued, next tile may start, phase-2 wait of iteration 0
+      long long* d_ = p.dbg + (((size_t)blockIdx.x * 128 + tile_k) * 2 + grp) * 8;
+      d_[0] = ts_top; d_[1] = ts_loop; d_[2] = ts_epi; d_[3] = __builtin_readcyclecounter(); d_[4] = ts_w2; d_[5] = xcc; d_[6] = nk; d_[7] = tile_k;
+    }
+    ++tile_k;
+#endif
     if (!has_next) break;
+    const int tk_v = mailbox[0];                           // (consumed a few hundred cycles later: the read is off the critical path)
     lane_state();
-    vb += vstep;
     cur = nxt;
-    has_next = vb + vstep < ntile;
-    if (has_next) nxt = tile_at(vb + vstep);
+    const int tkn = __builtin_amdgcn_readfirstlane(tk_v);
+    has_next = tkn < x_cnt;
+    if (has_next) nxt = tile_at(x_start + tkn);
+  }
+  }
+  // leave: the last workgroup of the launch zeroes the counters (the next launch on this stream finds them clean)
+  if (tid == 0) {
+    const int gone = __hip_atomic_fetch_add(sched + 8 * 32, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone == (int)gridDim.x - 1) {
+#pragma unroll
+      for (int x = 0; x < 8; ++x) __hip_atomic_store(sched + x * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sched + 8 * 32, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #undef P8_PIN
 #undef P8_MFMA
 #undef P8_MFMA0
 #undef P8_BARRIER
+}
+
+// ticket counters: a ring of blocks (8 counters + the leave count, a 128-byte line each) per device, zeroed once; every launch
+// leaves its block zeroed.  Launches on one stream are ordered; launches on different streams draw different blocks.
+constexpr int PK_SCHED_INTS = 9 * 32, PK_SCHED_BLOCKS = 64;
+int* sched_block() {
+  static int* base[16] = {};
+  static unsigned next_block = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!base[dev]) {
+    int* ptr = nullptr;
+    if (hipMalloc(&ptr, (size_t)PK_SCHED_BLOCKS * PK_SCHED_INTS * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemset(ptr, 0, (size_t)PK_SCHED_BLOCKS * PK_SCHED_INTS * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); return nullptr; }
+    base[dev] = ptr;
+  }
+  return base[dev] + (size_t)(next_block++ % PK_SCHED_BLOCKS) * PK_SCHED_INTS;
 }
 
 template <int EPK>
@@ -473,7 +564,9 @@ int launch_8pp(const GemmParams& p, int grid, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gemm_8pp_kernel<EPK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_8pp_kernel<EPK>), dim3(grid), dim3(512), smem, s, p);
+  int* sched = sched_block();
+  if (!sched) return 0;                                     // no counter block: the caller's non-persistent kernel does the job
+  hipLaunchKernelGGL((gemm_8pp_kernel<EPK>), dim3(grid), dim3(512), smem, s, p, sched);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 1;

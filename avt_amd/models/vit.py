@@ -205,7 +205,7 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
         saved['blocks'][i] = None
         # x2 = act @ W2^T + b2 + x1          (db2 was accumulated by the producer of dx)
         ops.linear_wgrad(dx, act, gr(blk.mlp.fc2.weight))
-        # data gradients of qkv / fc1 / fc2 read the transposed bf16 shadow W^T k-major (arena.transposed_of); proj stays as it is
+        # data gradients read the transposed bf16 shadow W^T k-major (arena.transposed_of): both operands k-major = the persistent 8-phase kernel
         dh = ops.linear_fwd(dx, sh_t(blk.mlp.fc2.weight), act=ops.ACT_MUL_AUX, aux=pre, colsum=gr(blk.mlp.fc1.bias))
         del act, pre
         ops.linear_wgrad(dh, ln2, gr(blk.mlp.fc1.weight))
@@ -215,7 +215,7 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
                                 dres=dx, colsum=gr(blk.attn.proj.bias))
         del dln2, x1, dx
         ops.linear_wgrad(dx1, att, gr(blk.attn.proj.weight))
-        datt = ops.linear_dgrad(dx1, sh(blk.attn.proj.weight))
+        datt = ops.linear_fwd(dx1, sh_t(blk.attn.proj.weight))
         dqkv = ops.vit_attn_bwd(qkv, att, datt, lse, N, S, H, dbias=gr(blk.attn.qkv.bias))
         del datt, att, qkv
         ops.linear_wgrad(dqkv, ln1, gr(blk.attn.qkv.weight))

@@ -1,0 +1,35 @@
+"""Lab: per-tile timeline of the persistent 8-phase GEMM from in-kernel cycle stamps (libavt_hip_lab.so, AVT_GEMM_DBG_PTR): K loop,
+epilogue issue, wait + barrier before the next tile, and the phase-2 wait of a tile's first iteration (= the previous tile's store drain).
+usage: python tools/lab/persist_timeline.py [frames=2560]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+os.environ.setdefault('AVT_HIP_LIB', os.path.join(ROOT, 'avt_amd', 'libavt_hip_lab.so'))
+dbg = torch.zeros(256 * 128 * 2 * 8, device='cuda', dtype=torch.int64)
+os.environ['AVT_GEMM_DBG_PTR'] = hex(dbg.data_ptr())
+from avt_amd import ops
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2560
+M = frames * 197; M -= M % 256
+r = lambda *s: (torch.rand(s, device='cuda') * 2 - 1).to(torch.bfloat16)
+x768, x3072 = r(M, 768), r(M, 3072)
+resid, pre = r(M, 768), r(M, 3072)
+cases = [('qkv fwd (bias)', x768, 2304, dict(bias=torch.rand(2304, device='cuda'))),
+         ('fc1 dgrad (plain, K=3072)', x3072, 768, dict()),
+         ('fc1 fwd (gelu + c2)', x768, 3072, dict(bias=torch.rand(3072, device='cuda'), act=ops.ACT_GELU_ERF, c2=torch.empty((M, 3072), device='cuda', dtype=torch.bfloat16))),
+         ('proj fwd (bias + res)', x768, 768, dict(bias=torch.rand(768, device='cuda'), res=resid)),
+         ('fc2 dgrad (* aux, colsum)', x768, 3072, dict(act=ops.ACT_MUL_AUX, aux=pre, colsum=torch.zeros(3072, device='cuda')))]
+for name, A, N, kw in cases:
+    K = A.size(1)
+    W = r(N, K)
+    for _ in range(2):
+        dbg.zero_()
+        ops.linear_fwd(A, W, **kw)
+        torch.cuda.synchronize()
+    d = dbg.view(-1, 8)
+    d = d[d[:, 0] > 0].cpu().double()
+    top, loop, epi, nxt, w2, k = d[:, 0], d[:, 1], d[:, 2], d[:, 3], d[:, 4], d[:, 7]
+    mid = (k > 0) & (k < k.max())
+    f = lambda v: f'{v[mid].mean():8.0f} (sd {v[mid].std():6.0f})'
+    print(f'== {name}: {len(d)} records, tiles per workgroup up to {int(k.max()) + 1}; cycles (100 MHz ticks x clock ratio -- s_memtime units):')
+    print(f'   K loop {f(loop - top)}   epilogue issue {f(epi - loop)}   wait+barrier {f(nxt - epi)}   tile total {f(nxt - top)}   phase-2 wait of iteration 0 {f(w2)}', flush=True)
