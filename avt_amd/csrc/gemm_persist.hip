@@ -56,23 +56,24 @@ __device__ __forceinline__ int pk_ticket(int* tkt, int lane) {
 
 // row-strip side of a block: read the lane's 16 bytes of rows it*8 + rl back and store them
 template <bool TWO>
-__device__ __forceinline__ void pk_store_block(const char* patch_c, const char* patch_d, int lane, int i32, const TileStore& sc, const TileStore& sd) {
+__device__ __forceinline__ void pk_store_block(const char* patch_c, const char* patch_d, int lane, int i32, const TileStore& sc, const TileStore& sd, int mrem) {
   const int rl = lane >> 3, pc = lane & 7;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + rl;
     const u32x2_t lo = *(const u32x2_t*)(patch_c + patch_rd(row, pc, 0)), hi = *(const u32x2_t*)(patch_c + patch_rd(row, pc, 1));
-    sc.st(i32 + row, pc * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
-    if (TWO) {
-      const u32x2_t lo2 = *(const u32x2_t*)(patch_d + patch_rd(row, pc, 0)), hi2 = *(const u32x2_t*)(patch_d + patch_rd(row, pc, 1));
-      sd.st(i32 + row, pc * 8, (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]});
+    u32x2_t lo2 = lo, hi2 = hi;
+    if (TWO) { lo2 = *(const u32x2_t*)(patch_d + patch_rd(row, pc, 0)); hi2 = *(const u32x2_t*)(patch_d + patch_rd(row, pc, 1)); }
+    if (i32 + row < mrem) {                                  // (rows past M exist only in the last row tile)
+      sc.st(i32 + row, pc * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
+      if (TWO) sd.st(i32 + row, pc * 8, (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]});
     }
   }
 }
 
 // EPK 0: C = bf16(acc + bias)
 __device__ __forceinline__ void pk_epi_plain(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, const float* bias_l,
-                                             int lane, int row0, int col0) {
+                                             int lane, int row0, int col0, int mrem) {
   const int ml = lane & 31, h = lane >> 5;
   TileStore sc;
   sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc);
@@ -88,13 +89,13 @@ __device__ __forceinline__ void pk_epi_plain(const GemmParams& p, const f32x16_t
         const f32x2_t v1 = (f32x2_t){acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} + (f32x2_t){b[2], b[3]};
         *(u32x2_t*)(patch + patch_wr(ml, h, j, q)) = (u32x2_t){pack2bf(v0[0], v0[1]), pack2bf(v1[0], v1[1])};
       }
-    pk_store_block<false>(patch, patch, lane, i * 32, sc, sc);
+    pk_store_block<false>(patch, patch, lane, i * 32, sc, sc, mrem);
   }
 }
 
 // EPK 1: C = GELU(acc + bias), C2 = GELU'(acc + bias), both by the LDS table (see gemm_tile.hpp: epi_fast_block, TAB)
 __device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const EpiBlk<2> blk_, char* patch_c, char* patch_d, const float* bias_l,
-                                                  int lane, int i32, const TileStore& sc, const TileStore& sd, const char* tab) {
+                                                  int lane, int i32, const TileStore& sc, const TileStore& sd, const char* tab, int mrem) {
   const f32x16_t* blk = blk_.t;
   const int ml = lane & 31, h = lane >> 5;
   u16x2_t mx = {0, 0};
@@ -141,11 +142,11 @@ __device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const Epi
         }
       }
   }
-  if (p.C2) pk_store_block<true>(patch_c, patch_d, lane, i32, sc, sd);
-  else pk_store_block<false>(patch_c, patch_d, lane, i32, sc, sd);
+  if (p.C2) pk_store_block<true>(patch_c, patch_d, lane, i32, sc, sd, mrem);
+  else pk_store_block<false>(patch_c, patch_d, lane, i32, sc, sd, mrem);
 }
 __device__ __forceinline__ void pk_epi_gelu(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch_c, char* patch_d, const float* bias_l,
-                                            int lane, int row0, int col0, const char* tab) {
+                                            int lane, int row0, int col0, const char* tab, int mrem) {
   TileStore sc, sd;
   sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc);
   sd.init(p.C2 ? p.C2 + (size_t)row0 * p.ldc2 + col0 : (bf16_t*)p.C, p.ldc2);
@@ -153,7 +154,7 @@ __device__ __forceinline__ void pk_epi_gelu(const GemmParams& p, const f32x16_t 
   for (int i = 0; i < 4; ++i) {          // (unrolled: a single copy of the block's code would need the block moved into place -- 32 more registers)
     EpiBlk<2> b;
     b.t[0] = acc[i][0]; b.t[1] = acc[i][1];
-    pk_epi_gelu_block(p, b, patch_c, patch_d, bias_l, lane, i * 32, sc, sd, tab);
+    pk_epi_gelu_block(p, b, patch_c, patch_d, bias_l, lane, i * 32, sc, sd, tab, mrem);
   }
 }
 
@@ -162,14 +163,15 @@ __device__ __forceinline__ void pk_epi_gelu(const GemmParams& p, const f32x16_t 
 struct PkOperand {
   __amdgpu_buffer_rsrc_t r; int ld;
   __device__ __forceinline__ void init(const bf16_t* ptr, int ld_) { r = __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0xFFFFFFF0u, 0x00020000); ld = ld_; }
-  __device__ __forceinline__ void dma_block(char* buf, int lane, int row0, int col0, int i) const {
+  __device__ __forceinline__ void dma_block(char* buf, int lane, int row0, int col0, int i, int mrem) const {
     const int rl = lane >> 3, pc = lane & 7;
 #pragma unroll
     for (int itr = 0; itr < 4; ++itr) {
       const int r_ = itr * 8 + rl;
       const int m = row0 + i * 32 + r_;
       const int n = col0 + ((pc ^ ((r_ >> 1) & 7)) * 8);
-      const uint32_t off = (uint32_t)(((size_t)m * (size_t)ld + (size_t)n) * 2);
+      uint32_t off = (uint32_t)(((size_t)m * (size_t)ld + (size_t)n) * 2);
+      if (i * 32 + r_ >= mrem) off = 0xFFFFFFF0u;            // a row past M: out of the descriptor's range (zeros)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(buf + itr * 1024), 16, off, 0, 0, AVT_LDP_AUX);
     }
   }
@@ -179,11 +181,11 @@ struct PkOperand {
 // Block 0's operand is already on its way into `buf0` (requested during the last K iteration); blocks 1 and 3 use `buf1`.
 template <int EPK>
 __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, char* buf0, char* buf1,
-                                          const PkOperand& op, float bias_v, int lane, int row0, int col0, int* tkt) {
+                                          const PkOperand& op, float bias_v, int lane, int row0, int col0, int* tkt, int mrem, bool partial) {
   int tk = 0x7fffffff;
   const int ml = lane & 31, h = lane >> 5;
   const int rl = lane >> 3, pc = lane & 7;
-  op.dma_block(buf1, lane, row0, col0, 1);
+  op.dma_block(buf1, lane, row0, col0, 1, mrem);
   f32x4_t bb[2][4];
   if (EPK == 2) {          // the bias strip goes through the (still unused) patch once: lane l holds bias[col0 + l]
     ((float*)patch)[lane] = bias_v;
@@ -208,7 +210,9 @@ __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&
     // i = 0: 4;  i = 1: 8;  i = 2: 12;  i = 3: 8 (one store per row strip)
     // The wave that draws a ticket does so right after the wait of block 0 (one more operation younger than DMA(1): its wait of block 1
     // allows 9; the ticket has two blocks' time to return before the wait of block 2 needs it retired)
-    switch (i) {
+    // In the last row tile a store instruction whose rows all lie past M may not be issued at all: no counting there, wait for everything.
+    if (partial) { wait_vmcnt<0>(); if (i == 0) tk = pk_ticket(tkt, lane); }
+    else switch (i) {
       case 0: wait_vmcnt<4>(); tk = pk_ticket(tkt, lane); break;
       case 1: if (tkt) wait_vmcnt<9>(); else wait_vmcnt<8>(); break;
       case 2: wait_vmcnt<12>(); break;
@@ -223,7 +227,7 @@ __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&
         opv[j][q] = *(const u32x2_t*)(buf + ml * 128 + (((j * 4 + q) ^ ((ml >> 1) & 7)) * 16) + h * 8);
     if (i + 2 < 4) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer's previous contents are in registers
-      op.dma_block((i & 1) ? buf1 : buf0, lane, row0, col0, i + 2);
+      op.dma_block((i & 1) ? buf1 : buf0, lane, row0, col0, i + 2, mrem);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -239,10 +243,12 @@ __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + rl;
       const u32x2_t lo = *(const u32x2_t*)(patch + patch_rd(row, pc, 0)), hi = *(const u32x2_t*)(patch + patch_rd(row, pc, 1));
-      sc.st(i * 32 + row, pc * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
-      if (EPK == 3 && p.colsum) {
-        cs[0] += bflo(lo[0]); cs[1] += bfhi(lo[0]); cs[2] += bflo(lo[1]); cs[3] += bfhi(lo[1]);
-        cs[4] += bflo(hi[0]); cs[5] += bfhi(hi[0]); cs[6] += bflo(hi[1]); cs[7] += bfhi(hi[1]);
+      if (i * 32 + row < mrem) {
+        sc.st(i * 32 + row, pc * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
+        if (EPK == 3 && p.colsum) {
+          cs[0] += bflo(lo[0]); cs[1] += bfhi(lo[0]); cs[2] += bflo(lo[1]); cs[3] += bfhi(lo[1]);
+          cs[4] += bflo(hi[0]); cs[5] += bfhi(hi[0]); cs[6] += bflo(hi[1]); cs[7] += bfhi(hi[1]);
+        }
       }
     }
   }
@@ -266,9 +272,13 @@ __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&
   return tk;
 }
 
+// reciprocals of the tile walk's divisors: q = n / d = (n * mg) >> 32 with mg = floor(2^32 / d) + 1, exact while n * d < 2^32 (n, d < 2^16 here)
+struct PkWalk { uint32_t mg_tn, mg_per, mg_w, mg_wl, per, nfull, wl; };
+__device__ __forceinline__ uint32_t pk_div(uint32_t n, uint32_t d, uint32_t mg) { return d == 1 ? n : __umulhi(n, mg); }
+
 // EPK: 0 = bias | 1 = bias, GELU (+ GELU') by table | 2 = bias, + residual | 3 = * saved derivative (+ column sums)
 template <int EPK>
-__global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, int* __restrict__ sched) {
+__global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_arg, int* __restrict__ sched) {
   constexpr int BK = 64, HALF = PK_HALF;
   constexpr int TABB = (EPK == 1) ? GELU_TAB_BYTES : 0;
   constexpr bool HAS_OP = (EPK == 2 || EPK == 3);
@@ -294,40 +304,45 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, int* __rest
   const int nk = p.K / BK;                               // even, >= 4 (host-checked)
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t ra_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
-  __amdgpu_buffer_rsrc_t rb_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0, 0x00020000);
 
-  // per-lane source offsets of the wave's two DMA instructions per half-tile, relative to the tile's origin and K tile 0.  They (and
-  // the fragment addresses) are re-derived from an opaque copy of the lane id at the start of every tile, so that none of the K
-  // loop's per-lane state stays in registers across the epilogue
-  uint32_t offA[2][2], offB[2][2];
-  int lane_k = lane;
-  auto lane_state = [&]() __attribute__((always_inline)) {
-    lane_k = pk_lane_id();
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int r = j * 64 + wave * 8 + (lane_k >> 3);                         // LDS row of the half-tile
-        const int c = (lane_k & 7) ^ kmajor_swz<BK>(r);
-        offA[h][j] = (uint32_t)(((size_t)(j * 128 + (r & 63) + h * 64) * (size_t)p.lda + (size_t)(c * 8)) * 2);
-        offB[h][j] = (uint32_t)(((size_t)((r >> 5) * 64 + (r & 31) + h * 32) * (size_t)p.ldb + (size_t)(c * 8)) * 2);
-      }
+  // per-lane source offsets of the wave's DMA instructions: LDS row rr = wave * 8 + lane / 8 (+ 64 j) of a half-tile takes the 16-byte chunk
+  // (lane & 7) ^ swizzle(rr) of a source row; the row's place in the tile (half h, instruction j) and the tile / K-tile origin are scalar
+  // terms added per instruction, so two registers hold the per-lane state for the whole kernel.  The row terms stay in the VECTOR
+  // offset (base + scalar sum, one v_add per instruction): the descriptor's bounds check ignores the scalar offset, and rows past M in
+  // the last row tile have to come back as zeros, not as reads past the end of the operand.
+  // (the GELU epilogue needs every register: there the two are re-derived at the start of each tile instead of kept)
+  uint32_t base_a, base_b;
+  auto lane_bases = [&](int l) __attribute__((always_inline)) {
+    const int rr = wave * 8 + (l >> 3);
+    const int c = (l & 7) ^ kmajor_swz<BK>(rr);
+    base_a = (uint32_t)(((size_t)rr * (size_t)p.lda + (size_t)(c * 8)) * 2);
+    base_b = (uint32_t)(((size_t)((rr >> 5) * 64 + (rr & 31)) * (size_t)p.ldb + (size_t)(c * 8)) * 2);
   };
-  lane_state();
+  lane_bases(lane);
+  const uint32_t lda2 = (uint32_t)p.lda * 2u, ldb2 = (uint32_t)p.ldb * 2u;
+  int lane_k = lane;                                       // the fragment addresses hang on this copy, re-derived per tile (pk_lane_id)
   char* const dstw = lds + wave * 8 * (BK * 2);
   constexpr int JSTEP = 8192;
 
   // tile walk (32-bit byte offsets: every operand is below 4 GiB)
   struct Tile { int tm0, tn0; uint32_t a, b; };
-  auto tile_at = [&](int t_) __attribute__((always_inline)) {        // t_ = position in the XCD-ordered walk (see gemm.hip: xcd_remap)
+  // position in the XCD-ordered walk (gemm.hip: xcd_remap) -> tile; the divisions by tiles_n / tiles per strip / strip width go through
+  // host-computed reciprocals (scalar multiply-high): the walk is a dozen scalar instructions between two tiles
+  auto tile_at = [&](int t_) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)     // (re-read from the kernel-argument segment, as the epilogue's arguments are: not kept across the K loop)
+    const __attribute__((address_space(4))) char* kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const PkWalk wk = *(const __attribute__((address_space(4))) PkWalk*)(kp + ((sizeof(GemmParams) + 3) & ~(size_t)3));
+#else
+    const PkWalk wk = wk_arg;
+#endif
     int tm_i, tn_i;
     if (p.strip_w > 0) {
-      const int per = p.tiles_m * p.strip_w;
-      const int strip = t_ / per, r_ = t_ - strip * per;
-      const int w_ = min(p.strip_w, p.tiles_n - strip * p.strip_w);
-      tm_i = r_ / w_; tn_i = strip * p.strip_w + (r_ - tm_i * w_);
-    } else { tm_i = t_ / p.tiles_n; tn_i = t_ - tm_i * p.tiles_n; }
+      const int strip = (int)pk_div((uint32_t)t_, wk.per, wk.mg_per), r_ = t_ - strip * (int)wk.per;
+      const bool lastw = strip >= (int)wk.nfull;
+      const int w_ = lastw ? (int)wk.wl : p.strip_w;
+      tm_i = (int)pk_div((uint32_t)r_, (uint32_t)w_, lastw ? wk.mg_wl : wk.mg_w); tn_i = strip * p.strip_w + (r_ - tm_i * w_);
+    } else { tm_i = (int)pk_div((uint32_t)t_, (uint32_t)p.tiles_n, wk.mg_tn); tn_i = t_ - tm_i * p.tiles_n; }
     Tile t;
     t.tm0 = tm_i * 256; t.tn0 = tn_i * 256;
     t.a = (uint32_t)t.tm0 * (uint32_t)p.lda * 2u; t.b = (uint32_t)t.tn0 * (uint32_t)p.ldb * 2u;
@@ -345,31 +360,29 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, int* __rest
   // the first two tickets
   if (tid == 0) mailbox[0] = __hip_atomic_fetch_add(my_counter, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  const int tk0 = __builtin_amdgcn_readfirstlane(mailbox[0]);
+  const int tk0 = __builtin_amdgcn_readfirstlane(mailbox[0]), tk1 = tk0 + 1;
   __syncthreads();
-  bool has_cur = tk0 < x_cnt, has_next = tk0 + 1 < x_cnt;
+  bool has_cur = tk0 < x_cnt, has_next = tk1 < x_cnt;
   Tile cur = tile_at(x_start + (has_cur ? tk0 : 0)), nxt = cur;
-  if (has_next) nxt = tile_at(x_start + tk0 + 1);
+  if (has_next) nxt = tile_at(x_start + tk1);
 
   // slot index = kind * 2 + (K tile & 1); kinds 0 = A0h, 1 = B0h, 2 = B1h, 3 = A1h.  kt counts the current tile's K tiles; kt == nk is
-  // K tile 0 of the next output tile (zero fill through an empty descriptor when there is none)
+  // K tile 0 of the next output tile (without one, `nxt` = `cur`: the fetch is repeated and never read)
   auto stage_a = [&](int h, int kt) __attribute__((always_inline)) {
     const bool in = kt < nk;
-    const __amdgpu_buffer_rsrc_t r = (in || has_next) ? ra : ra_null;
     const uint32_t adv = in ? cur.a + (uint32_t)kt * (BK * 2) : nxt.a + (uint32_t)(kt - nk) * (BK * 2);
     char* d = dstw + ((h ? 3 : 0) * 2 + (kt & 1)) * HALF;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offA[h][j] + adv, 0, 0, AVT_LDA_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, AVT_LDS_PTR(d + j * JSTEP), 16, base_a + (adv + (uint32_t)(j * 128 + h * 64) * lda2), 0, 0, AVT_LDA_AUX);
   };
   auto stage_b = [&](int h, int kt) __attribute__((always_inline)) {
     const bool in = kt < nk;
-    const __amdgpu_buffer_rsrc_t r = (in || has_next) ? rb : rb_null;
     const uint32_t adv = in ? cur.b + (uint32_t)kt * (BK * 2) : nxt.b + (uint32_t)(kt - nk) * (BK * 2);
     char* d = dstw + ((h ? 2 : 1) * 2 + (kt & 1)) * HALF;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offB[h][j] + adv, 0, 0, AVT_LDB_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, AVT_LDS_PTR(d + j * JSTEP), 16, base_b + (adv + (uint32_t)(j * 128 + h * 32) * ldb2), 0, 0, AVT_LDB_AUX);
   };
   bf16x8_t fa[2][4], fb0[4], fb1[4], fb0n[4];
   auto read_a = [&](bf16x8_t (&f)[2][4], int h, int par) __attribute__((always_inline)) {
@@ -439,6 +452,8 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, int* __rest
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float bias_v = 0.f;
     const int m0_e = cur.tm0 + grp * 128, n0_e = cur.tn0 + wn * 64;
+    const int mrem = p.M - m0_e;                           // valid rows of this wave's strip (>= 128 everywhere but in the last row tile)
+    const bool partial = cur.tm0 + 256 > p.M;
     read_b(fb0, 0, 0);
 #pragma nounroll
     for (int t = 0; t < nk; t += 2) {
@@ -470,7 +485,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, int* __rest
       read_a(fa, 1, 1); P8_PIN();
       if (!last) { stage_a(0, t + 3); wait_vmcnt<6>(); }
       else {
-        if (HAS_OP) op.dma_block(P2, pk_lane_id(), m0_e, n0_e, 0);          // the epilogue's second operand, block 0 -> behind the ring
+        if (HAS_OP) op.dma_block(P2, pk_lane_id(), m0_e, n0_e, 0, mrem);          // the epilogue's second operand, block 0 -> behind the ring
       }
       P8_BARRIER();
       P8_MFMA(fa, fb1, 2, 1); P8_BARRIER();
@@ -486,24 +501,34 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, int* __rest
 #endif
     int tk;
     {
+      // the epilogue's pointers and strides are re-read from the kernel-argument segment for every tile (scalar loads through a
+      // laundered pointer) instead of occupying two dozen scalar registers across the K loop
+#if defined(__HIP_DEVICE_COMPILE__)
+      const __attribute__((address_space(4))) GemmParams* pp = (const __attribute__((address_space(4))) GemmParams*)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(pp));
+      const GemmParams pe = *pp;
+#else
+      const GemmParams pe = p;
+#endif
       const int lane_e = pk_lane_id();
       int* const tkt = (wave == 0 && has_next) ? my_counter : nullptr;       // wave 0 draws the ticket for the tile after next
       if constexpr (EPK == 0) {
         tk = pk_ticket(tkt, lane_e);
         ((float*)P2)[lane_e] = bias_v;
-        pk_epi_plain(p, acc, P1, (const float*)P2, lane_e, m0_e, n0_e);
+        pk_epi_plain(pe, acc, P1, (const float*)P2, lane_e, m0_e, n0_e, mrem);
       } else if constexpr (EPK == 1) {
         tk = pk_ticket(tkt, lane_e);
         ((float*)P2)[lane_e] = bias_v;
-        pk_epi_gelu(p, acc, P1, P1 + 4096, (const float*)P2, lane_e, m0_e, n0_e, smem8);
+        pk_epi_gelu(pe, acc, P1, P1 + 4096, (const float*)P2, lane_e, m0_e, n0_e, smem8, mrem);
       } else {
-        tk = pk_epi_ext<EPK>(p, acc, P1, P2, P1 + 4096, op, bias_v, lane_e, m0_e, n0_e, tkt);
+        tk = pk_epi_ext<EPK>(pe, acc, P1, P2, P1 + 4096, op, bias_v, lane_e, m0_e, n0_e, tkt, mrem, partial);
       }
     }
 #ifdef AVT_LAB
     if (p.dbg) ts_epi = __builtin_readcyclecounter();
 #endif
-    wait_vmcnt<16>();                                      // everything older than the tile's last 16 stores: the next tile's K tile 0, the ticket
+    if (partial) wait_vmcnt<0>();                          // (the last row tile may have issued fewer than 16 stores)
+    else wait_vmcnt<16>();                                 // everything older than the tile's last 16 stores: the next tile's K tile 0, the ticket
     if (wave == 0 && pk_lane_id() == 0) mailbox[0] = tk;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     P8_BARRIER();                                          // ... for every wave's share of it; and every patch has been read back
@@ -516,20 +541,22 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, int* __rest
 #endif
     if (!has_next) break;
     const int tk_v = mailbox[0];                           // (consumed a few hundred cycles later: the read is off the critical path)
-    lane_state();
+    lane_k = pk_lane_id();
+    if (EPK == 1) lane_bases(lane_k);
     cur = nxt;
     const int tkn = __builtin_amdgcn_readfirstlane(tk_v);
     has_next = tkn < x_cnt;
     if (has_next) nxt = tile_at(x_start + tkn);
   }
   }
-  // leave: the last workgroup of the launch zeroes the counters (the next launch on this stream finds them clean)
+  // leave: the last workgroup of the launch zeroes the counters (the next launch on this stream finds them clean).  Relaxed, device-scope
+  // atomics are enough: a workgroup has consumed the results of all its ticket draws before it gets here, so when the leave count says
+  // "everybody else has left" no draw is outstanding (acquire / release here would write back and invalidate the L2 once per workgroup)
   if (tid == 0) {
-    const int gone = __hip_atomic_fetch_add(sched + 8 * 32, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const int gone = __hip_atomic_fetch_add(sched + 8 * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (gone == (int)gridDim.x - 1) {
 #pragma unroll
-      for (int x = 0; x < 8; ++x) __hip_atomic_store(sched + x * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(sched + 8 * 32, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      for (int x = 0; x <= 8; ++x) __hip_atomic_store(sched + x * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 #undef P8_PIN
@@ -566,7 +593,17 @@ int launch_8pp(const GemmParams& p, int grid, hipStream_t s) {
   }
   int* sched = sched_block();
   if (!sched) return 0;                                     // no counter block: the caller's non-persistent kernel does the job
-  hipLaunchKernelGGL((gemm_8pp_kernel<EPK>), dim3(grid), dim3(512), smem, s, p, sched);
+  auto magic = [](uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d + 1); };
+  PkWalk wk{};
+  wk.mg_tn = magic((uint32_t)p.tiles_n);
+  if (p.strip_w > 0) {
+    wk.per = (uint32_t)p.tiles_m * (uint32_t)p.strip_w;
+    wk.nfull = (uint32_t)(p.tiles_n / p.strip_w);           // strips of full width; a narrower last one when tiles_n % strip_w != 0
+    wk.wl = (uint32_t)(p.tiles_n % p.strip_w);
+    if (wk.wl == 0) wk.wl = (uint32_t)p.strip_w;
+    wk.mg_per = magic(wk.per); wk.mg_w = magic((uint32_t)p.strip_w); wk.mg_wl = magic(wk.wl);
+  }
+  hipLaunchKernelGGL((gemm_8pp_kernel<EPK>), dim3(grid), dim3(512), smem, s, p, wk, sched);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 1;
@@ -575,11 +612,11 @@ int launch_8pp(const GemmParams& p, int grid, hipStream_t s) {
 }  // namespace
 
 int avt_gemm_persist(GemmParams& p, int kinds, hipStream_t s) {
-  // covered: full 256x256 tiles, an even number (>= 4) of 64-wide K tiles, bf16 output through 16-byte stores, one of the four epilogues
+  // covered: N a multiple of 256 (any M), an even number (>= 4) of 64-wide K tiles, bf16 output through 16-byte stores, one of the four epilogues
   if (p.splitk != 1 || p.out_f32 || !p.wide_ok || p.drop_thresh || p.res_period) return 0;
-  if (p.M % 256 || p.N % 256 || p.K % 128 || p.K < 256) return 0;
+  if (p.N % 256 || p.K % 128 || p.K < 256) return 0;
   const int ntile = p.tiles_m * p.tiles_n;
-  if (ntile < 512) return 0;                                // fewer than two tiles per CU: nothing to overlap
+  if (ntile < 512 || ntile >= 65536) return 0;              // fewer than two tiles per CU: nothing to overlap; (the walk's reciprocals: n, d < 2^16)
   if ((uint64_t)p.a_bytes + 256ull * p.lda * 2 >= (1ull << 32) || (uint64_t)p.b_bytes + 256ull * p.ldb * 2 >= (1ull << 32)) return 0;
   const int grid = 256;                                     // one workgroup per CU (a multiple of the 8 XCDs)
   if ((kinds & 1) && p.act == 0 && !p.res && !p.colsum && !p.C2) return launch_8pp<0>(p, grid, s);

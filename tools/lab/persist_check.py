@@ -11,7 +11,8 @@ from avt_amd import ops  # noqa: E402
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2560
 kinds = int(sys.argv[2]) if len(sys.argv) > 2 else 15
 M = frames * 197
-M -= M % 256
+if not os.environ.get('PC_RAGGED'):
+    M -= M % 256
 dev = 'cuda'
 g = torch.Generator(device=dev).manual_seed(1)
 
@@ -66,22 +67,28 @@ for name, bit, A, N, kw in cases:
 
     def run():
         a = dict(args)
-        c2 = torch.empty((M, N), device=dev, dtype=torch.bfloat16) if kw.get('c2') else None
+        # outputs with 256 guard rows behind them (a store past row M would show there)
+        outf = torch.full((M + 256, N), 7.0, device=dev, dtype=torch.bfloat16)
+        c2f = torch.full((M + 256, N), 7.0, device=dev, dtype=torch.bfloat16) if kw.get('c2') else None
         cs = torch.zeros(N, device=dev) if kw.get('colsum') else None
-        if c2 is not None:
-            a['c2'] = c2
+        if c2f is not None:
+            a['c2'] = c2f[:M]
         if cs is not None:
             a['colsum'] = cs
-        out = ops.linear_fwd(A, W, **a)
-        return out, c2, cs
+        ops.linear_fwd(A, W, out=outf[:M], **a)
+        return outf, c2f, cs
 
     res = {}
-    for mode in ('0', str(kinds)):
-        os.environ['AVT_GEMM_PERSIST'] = mode
-        out, c2, cs = run()
-        torch.cuda.synchronize()
-        us = timed(lambda: run())
-        res[mode] = (out, c2, cs, us)
+    best = {'0': 1e30, str(kinds): 1e30}
+    for rnd_ in range(4):                      # alternate the kernels (clock / power state drifts over a run): best of 4 rounds each
+        for mode in ('0', str(kinds)):
+            os.environ['AVT_GEMM_PERSIST'] = str(kinds) if mode == 'static' else mode
+            os.environ['AVT_GEMM_PERSIST_STATIC'] = '1' if mode == 'static' else '0'
+            out, c2, cs = run()
+            torch.cuda.synchronize()
+            best[mode] = min(best[mode], timed(lambda: run()))
+            res[mode] = (out, c2, cs, best[mode])
+    os.environ['AVT_GEMM_PERSIST_STATIC'] = '0'
     o0, c0, s0, t0 = res['0']
     o1, c1, s1, t1 = res[str(kinds)]
     same = torch.equal(o0.view(torch.int16), o1.view(torch.int16))
@@ -92,8 +99,8 @@ for name, bit, A, N, kw in cases:
     nbad = (o0.view(torch.int16) != o1.view(torch.int16)).sum().item()
     ok = ok and same
     tf = 2.0 * M * N * K / 1e12
-    print(f'{name:38s} 8p {t0:8.1f} us ({tf / t0 * 1e6 / 1e3:5.3f} PF/s)   persistent {t1:8.1f} us ({tf / t1 * 1e6 / 1e3:5.3f} PF/s)   '
-          f'{(t0 / t1 - 1) * 100:+5.1f} %   bit-equal {same} (diff elems {nbad})', flush=True)
+    print(f'{name:38s} 8p {t0:8.1f} us ({tf / t0 * 1e6 / 1e3:5.3f} PF/s)   persistent {t1:8.1f} us ({tf / t1 * 1e6 / 1e3:5.3f} PF/s) {(t0 / t1 - 1) * 100:+5.1f} %   '
+          f'bit-equal {same} (diff elems {nbad})', flush=True)
     if not same:
         d = (o0.float() - o1.float()).abs()
         idx = torch.nonzero(o0.view(torch.int16) != o1.view(torch.int16))

@@ -26,10 +26,18 @@ for name, A, N, kw in cases:
         dbg.zero_()
         ops.linear_fwd(A, W, **kw)
         torch.cuda.synchronize()
-    d = dbg.view(-1, 8)
-    d = d[d[:, 0] > 0].cpu().double()
+    raw = dbg.view(256, 128, 2, 8).cpu().double()
+    d = raw.view(-1, 8)
+    d = d[d[:, 0] > 0]
     top, loop, epi, nxt, w2, k = d[:, 0], d[:, 1], d[:, 2], d[:, 3], d[:, 4], d[:, 7]
     mid = (k > 0) & (k < k.max())
     f = lambda v: f'{v[mid].mean():8.0f} (sd {v[mid].std():6.0f})'
-    print(f'== {name}: {len(d)} records, tiles per workgroup up to {int(k.max()) + 1}; cycles (100 MHz ticks x clock ratio -- s_memtime units):')
-    print(f'   K loop {f(loop - top)}   epilogue issue {f(epi - loop)}   wait+barrier {f(nxt - epi)}   tile total {f(nxt - top)}   phase-2 wait of iteration 0 {f(w2)}', flush=True)
+    # tile period = start of tile k+1 - start of tile k of the same workgroup and wave group
+    t0 = raw[:, :-1, :, 0]; t1 = raw[:, 1:, :, 0]
+    ok = (t0 > 0) & (t1 > 0)
+    per = (t1 - t0)[ok]
+    gap = (raw[:, 1:, :, 0] - raw[:, :-1, :, 3])[ok]
+    span = (d[:, 3].max() - d[:, 0].min())
+    print(f'== {name}: {len(d)} records, tiles per workgroup up to {int(k.max()) + 1}; cycles:')
+    print(f'   K loop {f(loop - top)}   epilogue issue {f(epi - loop)}   wait+barrier {f(nxt - epi)}   tile total {f(nxt - top)}   phase-2 wait of iteration 0 {f(w2)}')
+    print(f'   tile period {per.mean():8.0f} (sd {per.std():6.0f})   between tiles {gap.mean():6.0f} (sd {gap.std():5.0f})', flush=True)
