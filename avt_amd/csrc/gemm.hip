@@ -670,7 +670,8 @@ int launch_8p(const GemmParams& p, hipStream_t s) {
   return 0;
 }
 
-int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
+// persist: 0 = never (tile 808: gemm_8p_kernel itself), 1 = where gemm_persist.hip covers the shape and measures faster (tile 0), 2 = forced (tile 809)
+int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s, int persist = 0) {
   p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
   const int nk = (p.K + 63) / 64;
   if (splitk <= 0) {
@@ -701,14 +702,15 @@ int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
     int rc = launch_8p<false, false, 2>(p, s);
     return rc ? rc : launch_reduce<4, 2, 2, 4>(p, s);
   }
-  if (epi == 0 && a_kmajor && b_kmajor) {
+  if (persist) {
     // the persistent form (gemm_persist.hip) where it covers the shape and the epilogue: 0 = not covered
     int mask = 0xF;
 #ifdef AVT_LAB
     { const char* e = getenv("AVT_GEMM_PERSIST"); if (e) mask = atoi(e); }
 #endif
-    const int rc = avt_gemm_persist(p, mask, s);
+    const int rc = (epi == 0 && a_kmajor && b_kmajor && splitk == 1) ? avt_gemm_persist(p, mask, persist == 2, s) : 0;
     if (rc != 0) return rc < 0 ? rc : 0;
+    if (persist == 2) { avt_set_error("avt_gemm_bf16: tile 809 (persistent 8-phase kernel) covers bf16 outputs of k-major operands with N %% 256 == 0, K %% 128 == 0, >= 512 tiles and a bias / GELU / residual / saved-derivative epilogue"); return -1; }
   }
   if (epi == 0) {
     // fc1 forward (erf GELU, with or without the derivative output, nothing else in the epilogue): activation by LDS table
@@ -1157,8 +1159,8 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
       bm = (t256 * sk >= 256 && t256 < 4096) ? 256 : 128;
     }
   }
-  if (tile == 0 && bm == 256 && (K % 64 == 0 || (!a_kmajor && !b_kmajor))) bm = 808;       // default big-tile kernel: the 8-phase schedule
-  if (tile == 0 && bm == 808 && epi == 2) bm = 2565;                                          // weight gradients: 4 waves of 128x128 (+2-3 % over the 8-phase kernel)
+  if (tile == 0 && bm == 256 && (K % 64 == 0 || (!a_kmajor && !b_kmajor))) bm = 8080;      // default big-tile kernel: the 8-phase schedule, persistent where that is faster
+  if (tile == 0 && bm == 8080 && epi == 2) bm = 2565;                                          // weight gradients: 4 waves of 128x128 (+2-3 % over the 8-phase kernel)
   if (tile == 0 && bm == 64 && epi == 0 && a_kmajor && b_kmajor) bm = 643;                   // all-k-major small outputs: 3-deep ring (+15-25 % on the head's data gradients)
   int nslots = 0;
   if (colsum && part) {
@@ -1196,8 +1198,9 @@ static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kma
     case 2565:                                                                                    // 4-wave weight-gradient kernel (128x128 wave tiles, AGPR accumulators)
       if (epi != 2) { avt_set_error("avt_gemm: tile 2565 is the deterministic weight-gradient kernel (avt_gemm_accum_bf16 only)"); return -1; }
       return dispatch_w4(p, a_kmajor, b_kmajor, splitk, s);                                  // 4 waves, 256x128x32, two workgroups per CU
-    case 808:                                                                                     // 8-phase schedule (needs K % 64 == 0 for k-major operands)
-      if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_8p(p, epi, a_kmajor, b_kmajor, splitk, s);
+    case 808: case 8080: case 809:                                                                // 8-phase schedule (needs K % 64 == 0 for k-major operands)
+      if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_8p(p, epi, a_kmajor, b_kmajor, splitk, s, bm == 808 ? 0 : (bm == 809 ? 2 : 1));
+      if (bm == 809) { avt_set_error("avt_gemm_bf16: tile 809 needs K %% 64 == 0"); return -1; }
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
 #ifdef AVT_LAB
     // two independent 4-wave workgroups per CU (<= 80 KB LDS, <= 256 registers each), optionally started half a tile apart
@@ -1210,7 +1213,7 @@ static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kma
 #endif
     default: break;
   }
-  avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 64, 128, 643, 256 / 2568 (one barrier per K tile) or 808 (8-phase) (got %d)", bm);
+  avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 64, 128, 643, 256 / 2568 (one barrier per K tile), 808 (8-phase) or 809 (8-phase, persistent) (got %d)", bm);
   return -1;
 }
 

@@ -33,6 +33,11 @@
 namespace {
 
 constexpr int PK_HALF = 128 * 64 * 2;                      // one half-tile slot of the ring: 16 KB
+// Longer reductions stay with gemm_8p_kernel unless the caller forces tile 809: what the persistent form removes is per-TILE time (fill,
+// store drain, workgroup turn-over: 12-20 % of a K = 768 tile, 2-4 % of a K = 3072 tile), and the step runs at the board's power limit --
+// at K >= 2304 the busier matrix pipe costs as much clock as the removed idle time is worth (measured, 256 clips, same box:
+// 907.4 clips/s without, 920.1 with every shape persistent, 924.1 with K <= 1024 only; profiles/r04_persistent_gemm.txt)
+constexpr int PK_KMAX = 1024;
 
 // swizzled wave-private patch [32 rows][128 B]: the 8-byte position q8 (0..15) of row r lives at position q8 ^ (r & 15).
 // Writes (accumulator layout: lane = row, 8 B per (j, q)): the 32 lanes of a half-wave hit 16 positions x 2 rows each = every
@@ -611,10 +616,15 @@ int launch_8pp(const GemmParams& p, int grid, hipStream_t s) {
 
 }  // namespace
 
-int avt_gemm_persist(GemmParams& p, int kinds, hipStream_t s) {
+int avt_gemm_persist(GemmParams& p, int kinds, bool force, hipStream_t s) {
   // covered: N a multiple of 256 (any M), an even number (>= 4) of 64-wide K tiles, bf16 output through 16-byte stores, one of the four epilogues
   if (p.splitk != 1 || p.out_f32 || !p.wide_ok || p.drop_thresh || p.res_period) return 0;
   if (p.N % 256 || p.K % 128 || p.K < 256) return 0;
+  int kmax = PK_KMAX;
+#ifdef AVT_LAB
+  { const char* e = getenv("AVT_GEMM_PERSIST_KMAX"); if (e) kmax = atoi(e); }
+#endif
+  if (p.K > kmax && !force) return 0;
   const int ntile = p.tiles_m * p.tiles_n;
   if (ntile < 512 || ntile >= 65536) return 0;              // fewer than two tiles per CU: nothing to overlap; (the walk's reciprocals: n, d < 2^16)
   if ((uint64_t)p.a_bytes + 256ull * p.lda * 2 >= (1ull << 32) || (uint64_t)p.b_bytes + 256ull * p.ldb * 2 >= (1ull << 32)) return 0;

@@ -34,8 +34,9 @@ struct GemmParams {
 // gemm_persist.hip: the persistent form of the 8-phase kernel (one workgroup per CU walks a queue of output tiles and keeps the
 // next tile's first operand half-tiles in flight while it converts and stores the current one).  Returns 1 = launched,
 // 0 = this shape / epilogue is not covered (the caller falls back to gemm_8p_kernel), < 0 = error (avt_set_error called).
-// `kinds` = bit mask of the epilogue kinds (EPK 0..3) the caller allows (the product allows all; the lab build's A/B switch).
-int avt_gemm_persist(GemmParams& p, int kinds, hipStream_t s);
+// `kinds` = bit mask of the epilogue kinds (EPK 0..3) the caller allows (the product allows all; the lab build's A/B switch);
+// `force`: also take reductions longer than the range where the persistent form measured faster (tile 809).
+int avt_gemm_persist(GemmParams& p, int kinds, bool force, hipStream_t s);
 
 namespace {
 

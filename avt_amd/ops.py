@@ -21,7 +21,10 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile):
+PERSIST_KMAX = 1024      # mirrors PK_KMAX in csrc/gemm_persist.hip
+
+
+def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False):
     """Mirror of the tile choice in avt_gemm_bf16 (csrc/gemm.hip): names the kernel template a call lands on."""
     epi = 1 if out_mode == OUT_ACCUM_F32 else 0
     bm = tile
@@ -35,13 +38,19 @@ def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile):
             bm = 256 if (t256 * sk >= 256 and t256 < 4096) else 128
         if bm == 256 and (K % 64 == 0 or (not a_kmajor and not b_kmajor)):
             bm = 808
+            t256 = ((M + 255) // 256) * ((N + 255) // 256)
+            if (epi == 0 and a_kmajor and b_kmajor and epilogue_ok and N % 256 == 0 and K % 128 == 0 and 256 <= K <= PERSIST_KMAX
+                    and 512 <= t256 < 65536):
+                bm = 809          # the persistent form (csrc/gemm_persist.hip: avt_gemm_persist)
         if bm == 64 and epi == 0 and a_kmajor and b_kmajor:
             bm = 643
-    shape = {2564: '4w', 64: '64,64,2,2,64,2,0', 128: '128,128,2,2,64,2,0', 256: '256,256,2,4,64,2,1', 512: 'pp', 258: 'deepa', 2568: '256,256,2,4,64,2,1,l8', 808: '8p', 643: '64,64,2,2,64,3,0'}[bm]
+    shape = {2564: '4w', 64: '64,64,2,2,64,2,0', 128: '128,128,2,2,64,2,0', 256: '256,256,2,4,64,2,1', 512: 'pp', 258: 'deepa', 2568: '256,256,2,4,64,2,1,l8', 808: '8p', 809: '8pp', 643: '64,64,2,2,64,3,0'}[bm]
     if bm == 2564:
         return f'gemm_4w_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))}>'
     if bm == 808:
         return f'gemm_8p_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
+    if bm == 809:
+        return 'gemm_8pp_kernel'
     if bm == 258:
         return f'gemm_deepa_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
     if bm == 512:
@@ -106,7 +115,12 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
               out_mode, splitk, tile, part, part_bytes, _stream())
     if trace is not None:
         ev1.record()
-        trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile), 2.0 * M * N * K, ev0, ev1, (M, N, K)))
+        # (the epilogues the persistent kernel covers: bias | erf-GELU (+ derivative) | bias + residual | saved derivative (+ column sums))
+        ep_ok = (out_mode == OUT_BF16 and drop_p == 0.0 and res_period == 0 and
+                 ((act == ACT_NONE and c2 is None and colsum is None and aux is None) or
+                  (act == ACT_GELU_ERF and res is None and colsum is None) or
+                  (act == ACT_MUL_AUX and aux is not None and res is None and bias is None and c2 is None)))
+        trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, ep_ok), 2.0 * M * N * K, ev0, ev1, (M, N, K)))
     return out
 
 

@@ -48,7 +48,10 @@ int avt_abi_version(void);
  *     v += res[(res_period ? m % res_period : m), n];  colsum[n] += v (over the bf16-rounded values when C is bf16; see "partials" below);  C[m,n] = v
  * out_mode 2: C (fp32) += acc with atomics, no epilogue; splitk > 1 splits the reduction over workgroups
  *             (splitk <= 0 picks a factor that fills the chip).  Used for weight gradients.
- * tile: 0 = choose; 64 | 128 | 256 | 808 (256x256 tile, 8-phase schedule) | 2564 (256x128 tile, 4 waves, two workgroups per CU: k-major
+ * tile: 0 = choose; 64 | 128 | 256 | 808 (256x256 tile, 8-phase schedule, one tile per workgroup) | 809 (the same schedule as a persistent
+ * kernel: one workgroup per CU draws tiles from a queue and fetches the next tile's first K tile under its epilogue; bit-identical to 808;
+ * k-major operands, N % 256 == 0, K % 128 == 0, >= 512 tiles, bf16 output, bias | GELU | bias + residual | saved-derivative epilogue --
+ * an error otherwise; the automatic choice takes it for K <= 1024) | 2564 (256x128 tile, 4 waves, two workgroups per CU: k-major
  * operands, K % 32 == 0; bit-identical to 808, measured slower -- kept for experiments) force a kernel.  The automatic choice walks the
  * tiles of an activation GEMM whose B operand exceeds an XCD's 4-MB L2 (N*K*2 > 4 MB, e.g. the fc1 weight) in column strips, so that
  * the strip of B stays L2-resident (results do not depend on the tile order).  Requirements: 16-B aligned pointers, lda/ldb % 8 == 0,

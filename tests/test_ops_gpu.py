@@ -246,6 +246,52 @@ def test_big_tile_gemm_and_attention_bit_reproducible(ops):
         assert torch.equal(ops.vit_attn_bwd(qkv, o0, o0, l0, frames, S, H), d0)
 
 
+@pytest.mark.parametrize('M', [140 * 1024, 137900])          # 560 full row tiles; 538.67 (a partial last row tile, rows past M must stay untouched)
+def test_persistent_gemm_bit_equal_to_one_tile_per_workgroup(ops, M):
+    """gemm_persist.hip (tile 809; the automatic choice for K <= 1024) against gemm_8p_kernel (tile 808) on the four epilogues it covers:
+    same bits in every output (incl. the GELU' second output and the column sums), nothing written past row M, and a repeated call
+    gives the same bits (its tile tickets are drawn dynamically: the order of tiles differs from call to call)."""
+    K = 768
+    a = rnd((M, K), 0.5, 41)
+    for name, N, kw in [('bias', 768, dict(bias=True)),
+                        ('gelu', 1024, dict(bias=True, act=ops.ACT_GELU_ERF, c2=True)),
+                        ('bias_res', 768, dict(bias=True, res=True)),
+                        ('mul_aux_colsum', 1024, dict(act=ops.ACT_MUL_AUX, aux=True, colsum=True))]:
+        b = rnd((N, K), 0.05, 42)
+        extra = {}
+        if kw.get('bias'):
+            extra['bias'] = rnd((N,), 1.0, 43, torch.float32)
+        if 'act' in kw:
+            extra['act'] = kw['act']
+        if kw.get('res'):
+            extra['res'] = rnd((M, N), 1.0, 44)
+        if kw.get('aux'):
+            extra['aux'] = rnd((M, N), 1.0, 45)
+        outs = {}
+        for tile in (808, 809, 809, 0):
+            full = torch.full((M + 256, N), 7.0, device='cuda', dtype=torch.bfloat16)
+            c2 = torch.full((M + 256, N), 7.0, device='cuda', dtype=torch.bfloat16) if kw.get('c2') else None
+            cs = torch.zeros(N, device='cuda') if kw.get('colsum') else None
+            call = dict(extra)
+            if c2 is not None:
+                call['c2'] = c2[:M]
+            if cs is not None:
+                call['colsum'] = cs
+            ops.gemm(a, b, M, N, K, out=full[:M], tile=tile, **call)
+            got = (full, c2, cs)
+            assert float(full[M:].float().min()) == 7.0 and float(full[M:].float().max()) == 7.0, (name, tile)
+            if tile == 808:
+                outs = got
+                if name == 'bias':
+                    assert relerr(full[:M], a.float() @ b.float().t() + extra['bias']) < 1e-2
+                continue
+            for x, y in zip(got, outs):
+                if x is not None:
+                    assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y), (name, tile)
+    with pytest.raises(Exception):
+        ops.gemm(a, rnd((776, K), 0.05, 46), M, 776, K, tile=809)        # N % 256 != 0: not covered, and 809 does not fall back
+
+
 def test_column_sum_reductions_are_bit_reproducible(ops):
     """Every many-workgroups -> one fp32 vector reduction (GEMM colsum at each tile shape incl. ragged edges, LayerNorm backward,
     ViT attention dbias, colsum, patch-embed reduce) gives the same BITS on repeated calls with the partials workspace, and agrees
