@@ -370,6 +370,8 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
   bool has_cur = tk0 < x_cnt, has_next = tk1 < x_cnt;
   Tile cur = tile_at(x_start + (has_cur ? tk0 : 0)), nxt = cur;
   if (has_next) nxt = tile_at(x_start + tk1);
+  int tkn = 0;
+  bool walk_pending = false;
 
   // slot index = kind * 2 + (K tile & 1); kinds 0 = A0h, 1 = B0h, 2 = B1h, 3 = A1h.  kt counts the current tile's K tiles; kt == nk is
   // K tile 0 of the next output tile (without one, `nxt` = `cur`: the fetch is repeated and never read)
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
     for (int ks = 0; ks < 4; ++ks) f[ks] = frag_kmajor<BK>(slot + wn * 32 * (BK * 2), 0, ks, lane_k);
   };
 
+  const bool two_outputs = p.C2 != nullptr;
   PkOperand op;
   if (HAS_OP) op.init(EPK == 3 ? p.aux : p.res, EPK == 3 ? p.ldaux : p.ldres);
 
@@ -482,6 +485,11 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
       P8_MFMA0(fa, fb0, 2, 0); P8_BARRIER();
       // ---- odd K tile t+1 (slot parity 1).  In the last iteration the stages of "K tile nk" fetch the next output tile's K tile 0;
       //      those of K tile nk + 1 are left out (their slots become the epilogue's) ----
+      if (walk_pending) {                                   // (first iteration of every tile but the workgroup's first)
+        walk_pending = false;
+        has_next = tkn < x_cnt;
+        if (has_next) nxt = tile_at(x_start + tkn);
+      }
       if (last && (EPK == 0 || EPK == 1 || EPK == 2) && p.bias) bias_v = p.bias[n0_e + pk_lane_id()];   // used two phases later at the earliest
       read_a(fa, 0, 1); P8_PIN(); stage_b(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb0n, 0, 0); P8_BARRIER();
@@ -533,6 +541,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
     if (p.dbg) ts_epi = __builtin_readcyclecounter();
 #endif
     if (partial) wait_vmcnt<0>();                          // (the last row tile may have issued fewer than 16 stores)
+    else if (EPK == 1 && two_outputs) wait_vmcnt<32>();    // (GELU + GELU': 32 stores per wave and tile)
     else wait_vmcnt<16>();                                 // everything older than the tile's last 16 stores: the next tile's K tile 0, the ticket
     if (wave == 0 && pk_lane_id() == 0) mailbox[0] = tk;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -545,13 +554,11 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
     ++tile_k;
 #endif
     if (!has_next) break;
-    const int tk_v = mailbox[0];                           // (consumed a few hundred cycles later: the read is off the critical path)
-    lane_k = pk_lane_id();
+    tkn = __builtin_amdgcn_readfirstlane(mailbox[0]);      // the ticket of the tile after the one that starts now: turned into a tile under
+    lane_k = pk_lane_id();                                 // the first iteration of the K loop (needed in its last one)
     if (EPK == 1) lane_bases(lane_k);
     cur = nxt;
-    const int tkn = __builtin_amdgcn_readfirstlane(tk_v);
-    has_next = tkn < x_cnt;
-    if (has_next) nxt = tile_at(x_start + tkn);
+    walk_pending = true;
   }
   }
   // leave: the last workgroup of the launch zeroes the counters (the next launch on this stream finds them clean).  Relaxed, device-scope
