@@ -59,9 +59,28 @@ __device__ __forceinline__ int pk_ticket(int* tkt, int lane) {
   return tk;
 }
 
+// 16-byte row-strip stores of a wave tile (lane = row rl = lane / 8 of an 8-row group, columns (lane & 7) * 8 ..): the per-lane part of the
+// address is one register for the whole tile, the row group a scalar added per store (no 64-bit multiply-add, whose don't-care high half
+// the register allocator once paired with a register still waiting for memory: an s_waitcnt vmcnt(0) after every store)
+struct PkStore {
+  __amdgpu_buffer_rsrc_t r; uint32_t voff, ld2;
+  // `rows` = rows of the wave's 128-row strip that exist (>= 128 everywhere but in the last row tile): the descriptor ends behind them, so
+  // a store to a row past M is dropped by the bounds check -- no predicate, no branch, and every wave issues the same number of stores
+  // (the counted waits of the epilogue rely on that)
+  __device__ __forceinline__ void init(bf16_t* origin, int ld, int lane, int rows) {
+    ld2 = (uint32_t)ld * 2u;
+    const uint32_t nrec = (uint32_t)(rows < 0 ? 0 : (rows > 128 ? 128 : rows)) * ld2;
+    r = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, nrec, 0x00020000);
+    voff = (uint32_t)(lane >> 3) * ld2 + (uint32_t)(lane & 7) * 16u;
+  }
+  __device__ __forceinline__ void st(int row8, u32x4_t v) const {      // row8 = first row of the 8-row group (wave-uniform)
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + (uint32_t)row8 * ld2, 0, AVT_ST_AUX);
+  }
+};
+
 // row-strip side of a block: read the lane's 16 bytes of rows it*8 + rl back and store them
 template <bool TWO>
-__device__ __forceinline__ void pk_store_block(const char* patch_c, const char* patch_d, int lane, int i32, const TileStore& sc, const TileStore& sd, int mrem) {
+__device__ __forceinline__ void pk_store_block(const char* patch_c, const char* patch_d, int lane, int i32, const PkStore& sc, const PkStore& sd) {
   const int rl = lane >> 3, pc = lane & 7;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
@@ -69,10 +88,8 @@ __device__ __forceinline__ void pk_store_block(const char* patch_c, const char* 
     const u32x2_t lo = *(const u32x2_t*)(patch_c + patch_rd(row, pc, 0)), hi = *(const u32x2_t*)(patch_c + patch_rd(row, pc, 1));
     u32x2_t lo2 = lo, hi2 = hi;
     if (TWO) { lo2 = *(const u32x2_t*)(patch_d + patch_rd(row, pc, 0)); hi2 = *(const u32x2_t*)(patch_d + patch_rd(row, pc, 1)); }
-    if (i32 + row < mrem) {                                  // (rows past M exist only in the last row tile)
-      sc.st(i32 + row, pc * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
-      if (TWO) sd.st(i32 + row, pc * 8, (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]});
-    }
+    sc.st(i32 + it * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
+    if (TWO) sd.st(i32 + it * 8, (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]});
   }
 }
 
@@ -80,8 +97,8 @@ __device__ __forceinline__ void pk_store_block(const char* patch_c, const char* 
 __device__ __forceinline__ void pk_epi_plain(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, const float* bias_l,
                                              int lane, int row0, int col0, int mrem) {
   const int ml = lane & 31, h = lane >> 5;
-  TileStore sc;
-  sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc);
+  PkStore sc;
+  sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc, lane, mrem);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -94,16 +111,36 @@ __device__ __forceinline__ void pk_epi_plain(const GemmParams& p, const f32x16_t
         const f32x2_t v1 = (f32x2_t){acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} + (f32x2_t){b[2], b[3]};
         *(u32x2_t*)(patch + patch_wr(ml, h, j, q)) = (u32x2_t){pack2bf(v0[0], v0[1]), pack2bf(v1[0], v1[1])};
       }
-    pk_store_block<false>(patch, patch, lane, i * 32, sc, sc, mrem);
+    pk_store_block<false>(patch, patch, lane, i * 32, sc, sc);
   }
 }
 
+// exact values for the elements of a block that lie above the table (|x| >= 2^8, inf, NaN): WHICH = 0 writes GELU, 1 writes GELU'
+template <int WHICH>
+__device__ __forceinline__ void pk_gelu_fix(const f32x16_t* blk, const float* bias_l, char* patch, int ml, int h) {
+#pragma unroll 1
+  for (int j = 0; j < 2; ++j)
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      const int nl = j * 32 + 8 * q + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = bf2f(f2bf(blk[j][4 * q + e] + bias_l[nl + e]));       // the bf16-rounded pre-activation, as in the look-up
+        if (!(fabsf(x) < GELU_TAB_TOP)) {
+          bf16_t hb, db; gelu_big(x, hb, db);
+          *(bf16_t*)(patch + patch_wr(ml, h, j, q) + e * 2) = WHICH ? db : hb;
+        }
+      }
+    }
+}
 // EPK 1: C = GELU(acc + bias), C2 = GELU'(acc + bias), both by the LDS table (see gemm_tile.hpp: epi_fast_block, TAB)
-__device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const EpiBlk<2> blk_, char* patch_c, char* patch_d, const float* bias_l,
-                                                  int lane, int i32, const TileStore& sc, const TileStore& sd, const char* tab, int mrem) {
+// (one patch, used twice: GELU rows out, then GELU' rows out)
+__device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const EpiBlk<2> blk_, char* patch, const float* bias_l,
+                                                  int lane, int i32, const PkStore& sc, const PkStore& sd, const char* tab) {
   const f32x16_t* blk = blk_.t;
   const int ml = lane & 31, h = lane >> 5;
   u16x2_t mx = {0, 0};
+  u32x2_t dd[2][4];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     uint32_t off[8], e[16];
@@ -125,41 +162,33 @@ __device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const Epi
     for (int q = 0; q < 4; ++q) {
       const uint32_t h0 = __builtin_amdgcn_perm(e[4 * q + 1], e[4 * q], 0x05040100u), d0 = __builtin_amdgcn_perm(e[4 * q + 1], e[4 * q], 0x07060302u);
       const uint32_t h1 = __builtin_amdgcn_perm(e[4 * q + 3], e[4 * q + 2], 0x05040100u), d1 = __builtin_amdgcn_perm(e[4 * q + 3], e[4 * q + 2], 0x07060302u);
-      *(u32x2_t*)(patch_d + patch_wr(ml, h, j, q)) = (u32x2_t){d0, d1};
-      *(u32x2_t*)(patch_c + patch_wr(ml, h, j, q)) = (u32x2_t){h0, h1};
+      dd[j][q] = (u32x2_t){d0, d1};
+      *(u32x2_t*)(patch + patch_wr(ml, h, j, q)) = (u32x2_t){h0, h1};
     }
   }
   constexpr unsigned short HI = ((GELU_TAB_ELO + GELU_TAB_NEXP) << 7) - 1;
-  if (__builtin_expect(__any((mx[0] > HI) | (mx[1] > HI)), 0)) {          // some value of this block lies above the table: patch those elements
-#pragma unroll 1
-    for (int j = 0; j < 2; ++j)
-#pragma unroll 1
-      for (int q = 0; q < 4; ++q) {
-        const int nl = j * 32 + 8 * q + 4 * h;
+  const bool big = __any((mx[0] > HI) | (mx[1] > HI));          // some value of this block lies above the table: patch those elements
+  if (__builtin_expect(big, 0)) pk_gelu_fix<0>(blk, bias_l, patch, ml, h);
+  pk_store_block<false>(patch, patch, lane, i32, sc, sc);
+  if (p.C2) {                                                    // the same patch again for the derivative (the LDS pipe runs a wave's operations in order)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = bf2f(f2bf(blk[j][4 * q + e] + bias_l[nl + e]));
-          if (!(fabsf(x) < GELU_TAB_TOP)) {
-            bf16_t hb, db; gelu_big(x, hb, db);
-            *(bf16_t*)(patch_c + patch_wr(ml, h, j, q) + e * 2) = hb;
-            *(bf16_t*)(patch_d + patch_wr(ml, h, j, q) + e * 2) = db;
-          }
-        }
-      }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(u32x2_t*)(patch + patch_wr(ml, h, j, q)) = dd[j][q];
+    if (__builtin_expect(big, 0)) pk_gelu_fix<1>(blk, bias_l, patch, ml, h);
+    pk_store_block<false>(patch, patch, lane, i32, sd, sd);
   }
-  if (p.C2) pk_store_block<true>(patch_c, patch_d, lane, i32, sc, sd, mrem);
-  else pk_store_block<false>(patch_c, patch_d, lane, i32, sc, sd, mrem);
 }
-__device__ __forceinline__ void pk_epi_gelu(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch_c, char* patch_d, const float* bias_l,
+__device__ __forceinline__ void pk_epi_gelu(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, const float* bias_l,
                                             int lane, int row0, int col0, const char* tab, int mrem) {
-  TileStore sc, sd;
-  sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc);
-  sd.init(p.C2 ? p.C2 + (size_t)row0 * p.ldc2 + col0 : (bf16_t*)p.C, p.ldc2);
+  PkStore sc, sd;
+  sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc, lane, mrem);
+  sd.init(p.C2 ? p.C2 + (size_t)row0 * p.ldc2 + col0 : (bf16_t*)p.C, p.ldc2, lane, mrem);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {          // (unrolled: a single copy of the block's code would need the block moved into place -- 32 more registers)
     EpiBlk<2> b;
     b.t[0] = acc[i][0]; b.t[1] = acc[i][1];
-    pk_epi_gelu_block(p, b, patch_c, patch_d, bias_l, lane, i * 32, sc, sd, tab, mrem);
+    pk_epi_gelu_block(p, b, patch, bias_l, lane, i * 32, sc, sd, tab);
   }
 }
 
@@ -186,7 +215,7 @@ struct PkOperand {
 // Block 0's operand is already on its way into `buf0` (requested during the last K iteration); blocks 1 and 3 use `buf1`.
 template <int EPK>
 __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, char* buf0, char* buf1,
-                                          const PkOperand& op, float bias_v, int lane, int row0, int col0, int* tkt, int mrem, bool partial) {
+                                          const PkOperand& op, float bias_v, int lane, int row0, int col0, int* tkt, int mrem) {
   int tk = 0x7fffffff;
   const int ml = lane & 31, h = lane >> 5;
   const int rl = lane >> 3, pc = lane & 7;
@@ -204,8 +233,8 @@ __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&
 #pragma unroll
       for (int q = 0; q < 4; ++q) bb[j][q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
-  TileStore sc;
-  sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc);
+  PkStore sc;
+  sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc, lane, mrem);
   float cs[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) cs[k] = 0.f;
@@ -215,9 +244,7 @@ __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&
     // i = 0: 4;  i = 1: 8;  i = 2: 12;  i = 3: 8 (one store per row strip)
     // The wave that draws a ticket does so right after the wait of block 0 (one more operation younger than DMA(1): its wait of block 1
     // allows 9; the ticket has two blocks' time to return before the wait of block 2 needs it retired)
-    // In the last row tile a store instruction whose rows all lie past M may not be issued at all: no counting there, wait for everything.
-    if (partial) { wait_vmcnt<0>(); if (i == 0) tk = pk_ticket(tkt, lane); }
-    else switch (i) {
+    switch (i) {
       case 0: wait_vmcnt<4>(); tk = pk_ticket(tkt, lane); break;
       case 1: if (tkt) wait_vmcnt<9>(); else wait_vmcnt<8>(); break;
       case 2: wait_vmcnt<12>(); break;
@@ -248,12 +275,11 @@ __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + rl;
       const u32x2_t lo = *(const u32x2_t*)(patch + patch_rd(row, pc, 0)), hi = *(const u32x2_t*)(patch + patch_rd(row, pc, 1));
-      if (i * 32 + row < mrem) {
-        sc.st(i * 32 + row, pc * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
-        if (EPK == 3 && p.colsum) {
-          cs[0] += bflo(lo[0]); cs[1] += bfhi(lo[0]); cs[2] += bflo(lo[1]); cs[3] += bfhi(lo[1]);
-          cs[4] += bflo(hi[0]); cs[5] += bfhi(hi[0]); cs[6] += bflo(hi[1]); cs[7] += bfhi(hi[1]);
-        }
+      sc.st(i * 32 + it * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
+      if (EPK == 3 && p.colsum) {                            // (a row past M adds nothing: selected, not branched around)
+        const float live = (i * 32 + row < mrem) ? 1.f : 0.f;
+        cs[0] += live * bflo(lo[0]); cs[1] += live * bfhi(lo[0]); cs[2] += live * bflo(lo[1]); cs[3] += live * bfhi(lo[1]);
+        cs[4] += live * bflo(hi[0]); cs[5] += live * bfhi(hi[0]); cs[6] += live * bflo(hi[1]); cs[7] += live * bfhi(hi[1]);
       }
     }
   }
@@ -287,6 +313,11 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
   constexpr int BK = 64, HALF = PK_HALF;
   constexpr int TABB = (EPK == 1) ? GELU_TAB_BYTES : 0;
   constexpr bool HAS_OP = (EPK == 2 || EPK == 3);
+  // EPK 0 / 1 (no second operand): the epilogue fits the two parity-1 slots of the B1h / A1h kinds (4 KB per wave) plus the space behind the
+  // ring, so the next tile's K tile 1 halves A0h / B0h are fetched before the epilogue too -- the K loop is then the uninterrupted stream of
+  // gemm_8p_kernel, and a tile starts with six stages resident instead of four (measured before: iteration 0 of a tile took 6.3-7.3 k
+  // cycles against 4.8 k in steady state, waiting for the two stages issued after the epilogue)
+  constexpr bool FULLPF = !HAS_OP;
   extern __shared__ __attribute__((aligned(16))) char smem8[];
   char* const lds = smem8 + TABB;                       // the ring: 8 half-tile slots (kind x K-tile parity), as in gemm_8p_kernel
   char* const ext = lds + 8 * HALF;                     // behind the ring: 32 KB (8 KB next to the table), idle during the K loop
@@ -302,7 +333,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
                                                (uint32_t)((wave * (GELU_TAB_BYTES / 8192) + i) * 1024 + lane * 16), 0, 0, 0);
   }
   // the wave's epilogue space: 8 KB in a parity-1 slot (two waves per slot), and its share of the space behind the ring
-  char* const P1 = lds + (2 * wn + 1) * HALF + grp * 8192;
+  char* const P1 = FULLPF ? lds + (wave < 4 ? 5 : 7) * HALF + (wave & 3) * 4096 : lds + (2 * wn + 1) * HALF + grp * 8192;
   char* const P2 = ext + wave * (EPK == 1 ? 1024 : 4096);
 
   const int ntile = p.tiles_m * p.tiles_n;
@@ -315,7 +346,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
   // terms added per instruction, so two registers hold the per-lane state for the whole kernel.  The row terms stay in the VECTOR
   // offset (base + scalar sum, one v_add per instruction): the descriptor's bounds check ignores the scalar offset, and rows past M in
   // the last row tile have to come back as zeros, not as reads past the end of the operand.
-  // (the GELU epilogue needs every register: there the two are re-derived at the start of each tile instead of kept)
+  // (every epilogue but the plain one needs all registers: there the two are re-derived at the start of each tile instead of kept)
   uint32_t base_a, base_b;
   auto lane_bases = [&](int l) __attribute__((always_inline)) {
     const int rr = wave * 8 + (l >> 3);
@@ -442,6 +473,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
   // first tile: its K tile 0 (the later tiles find theirs in the ring when they start)
   if (has_cur) {
   stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
+  if (FULLPF) { stage_a(0, 1); stage_b(0, 1); }
   wait_vmcnt<0>();
   P8_BARRIER();
 
@@ -453,19 +485,22 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
     long long ts_top = 0, ts_loop = 0, ts_epi = 0, ts_w2 = 0;
     if (p.dbg) ts_top = __builtin_readcyclecounter();
 #endif
-    // here: the four parity-0 slots hold K tile 0 of `cur`, every other slot is free, nothing but stores is in flight
-    stage_a(0, 1); stage_b(0, 1);
+    // here: the four parity-0 slots hold K tile 0 of `cur` (FULLPF: slots 1 and 3 its K tile 1 halves A0h, B0h), every other slot is free,
+    // nothing but stores is in flight
+    if (!FULLPF) { stage_a(0, 1); stage_b(0, 1); }
     if (grp == 1) P8_BARRIER();
     f32x16_t acc[4][2];                                     // (first written by the zero-operand MFMAs of iteration 0)
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float bias_v = 0.f;
     const int m0_e = cur.tm0 + grp * 128, n0_e = cur.tn0 + wn * 64;
     const int mrem = p.M - m0_e;                           // valid rows of this wave's strip (>= 128 everywhere but in the last row tile)
-    const bool partial = cur.tm0 + 256 > p.M;
     read_b(fb0, 0, 0);
 #pragma nounroll
     for (int t = 0; t < nk; t += 2) {
       const bool last = t + 2 >= nk;
+#ifdef AVT_LAB
+      if (p.dbg && (tid == 0) && tile_k == 3 && t < 16) p.dbg[(size_t)256 * 128 * 2 * 8 + (size_t)blockIdx.x * 16 + (t >> 1)] = __builtin_readcyclecounter();
+#endif
       // ---- even K tile t (slot parity 0).  t == 0: B1h / A1h of K tile 0 landed before the epilogue's barrier -- no counted wait
       //      (a vmcnt(8) there would wait for the previous tile's stores) ----
       read_a(fa, 0, 0); P8_PIN(); stage_b(1, t + 1); if (t) wait_vmcnt<8>(); P8_BARRIER();
@@ -476,12 +511,12 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
       long long tw0 = 0;
       if (p.dbg && t == 0) tw0 = __builtin_readcyclecounter();
 #endif
-      read_a(fa, 1, 0); P8_PIN(); stage_a(0, t + 2); wait_vmcnt<6>(); P8_BARRIER();
+      read_a(fa, 1, 0); P8_PIN(); stage_a(0, t + 2); if (t || !FULLPF) wait_vmcnt<6>(); P8_BARRIER();
 #ifdef AVT_LAB
       if (p.dbg && t == 0) ts_w2 = __builtin_readcyclecounter() - tw0;
 #endif
       P8_MFMA0(fa, fb1, 2, 1); P8_BARRIER();
-      read_b(fb0n, 0, 1); P8_PIN(); stage_b(0, t + 2); wait_vmcnt<8>(); P8_BARRIER();
+      read_b(fb0n, 0, 1); P8_PIN(); stage_b(0, t + 2); if (t || !FULLPF) wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA0(fa, fb0, 2, 0); P8_BARRIER();
       // ---- odd K tile t+1 (slot parity 1).  In the last iteration the stages of "K tile nk" fetch the next output tile's K tile 0;
       //      those of K tile nk + 1 are left out (their slots become the epilogue's) ----
@@ -496,13 +531,14 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
       read_b(fb1, 1, 1); P8_PIN(); stage_a(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb1, 0, 1); P8_BARRIER();
       read_a(fa, 1, 1); P8_PIN();
-      if (!last) { stage_a(0, t + 3); wait_vmcnt<6>(); }
+      if (!last || FULLPF) { stage_a(0, t + 3); wait_vmcnt<6>(); }
       else {
         if (HAS_OP) op.dma_block(P2, pk_lane_id(), m0_e, n0_e, 0, mrem);          // the epilogue's second operand, block 0 -> behind the ring
       }
       P8_BARRIER();
       P8_MFMA(fa, fb1, 2, 1); P8_BARRIER();
       if (!last) { read_b(fb0, 0, 0); P8_PIN(); stage_b(0, t + 3); wait_vmcnt<8>(); }
+      else if (FULLPF) { stage_b(0, t + 3); wait_vmcnt<8>(); }
       P8_BARRIER();
       P8_MFMA(fa, fb0n, 2, 0); P8_BARRIER();
     }
@@ -511,6 +547,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
     P8_BARRIER();                                          // every fragment read retired: the parity-1 slots are free
 #ifdef AVT_LAB
     if (p.dbg) ts_loop = __builtin_readcyclecounter();
+    if (p.dbg && (tid == 0) && tile_k == 3) p.dbg[(size_t)256 * 128 * 2 * 8 + (size_t)blockIdx.x * 16 + 8] = ts_loop, p.dbg[(size_t)256 * 128 * 2 * 8 + (size_t)blockIdx.x * 16 + 9] = ts_top;
 #endif
     int tk;
     {
@@ -532,17 +569,18 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
       } else if constexpr (EPK == 1) {
         tk = pk_ticket(tkt, lane_e);
         ((float*)P2)[lane_e] = bias_v;
-        pk_epi_gelu(pe, acc, P1, P1 + 4096, (const float*)P2, lane_e, m0_e, n0_e, smem8, mrem);
+        pk_epi_gelu(pe, acc, P1, (const float*)P2, lane_e, m0_e, n0_e, smem8, mrem);
       } else {
-        tk = pk_epi_ext<EPK>(pe, acc, P1, P2, P1 + 4096, op, bias_v, lane_e, m0_e, n0_e, tkt, mrem, partial);
+        tk = pk_epi_ext<EPK>(pe, acc, P1, P2, P1 + 4096, op, bias_v, lane_e, m0_e, n0_e, tkt, mrem);
       }
     }
 #ifdef AVT_LAB
     if (p.dbg) ts_epi = __builtin_readcyclecounter();
 #endif
-    if (partial) wait_vmcnt<0>();                          // (the last row tile may have issued fewer than 16 stores)
-    else if (EPK == 1 && two_outputs) wait_vmcnt<32>();    // (GELU + GELU': 32 stores per wave and tile)
+    if (EPK == 1 && two_outputs) wait_vmcnt<32>();    // (GELU + GELU': 32 stores per wave and tile)
     else wait_vmcnt<16>();                                 // everything older than the tile's last 16 stores: the next tile's K tile 0, the ticket
+    asm volatile("" :: "v"(tk));                           // (every wave "uses" the ticket here: the compiler's own bookkeeping of the atomic ends at this
+                                                           //  point on every path, not only inside wave 0's branch below)
     if (wave == 0 && pk_lane_id() == 0) mailbox[0] = tk;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     P8_BARRIER();                                          // ... for every wave's share of it; and every patch has been read back
@@ -556,7 +594,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
     if (!has_next) break;
     tkn = __builtin_amdgcn_readfirstlane(mailbox[0]);      // the ticket of the tile after the one that starts now: turned into a tile under
     lane_k = pk_lane_id();                                 // the first iteration of the K loop (needed in its last one)
-    if (EPK == 1) lane_bases(lane_k);
+    if (EPK != 0) lane_bases(lane_k);
     cur = nxt;
     walk_pending = true;
   }

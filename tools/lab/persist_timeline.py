@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch
 os.environ.setdefault('AVT_HIP_LIB', os.path.join(ROOT, 'avt_amd', 'libavt_hip_lab.so'))
-dbg = torch.zeros(256 * 128 * 2 * 8, device='cuda', dtype=torch.int64)
+dbg = torch.zeros(256 * 128 * 2 * 8 + 256 * 16, device='cuda', dtype=torch.int64)
 os.environ['AVT_GEMM_DBG_PTR'] = hex(dbg.data_ptr())
 from avt_amd import ops
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2560
@@ -26,7 +26,8 @@ for name, A, N, kw in cases:
         dbg.zero_()
         ops.linear_fwd(A, W, **kw)
         torch.cuda.synchronize()
-    raw = dbg.view(256, 128, 2, 8).cpu().double()
+    itr = dbg[256 * 128 * 2 * 8:].view(256, 16).cpu().double()
+    raw = dbg[:256 * 128 * 2 * 8].view(256, 128, 2, 8).cpu().double()
     d = raw.view(-1, 8)
     d = d[d[:, 0] > 0]
     top, loop, epi, nxt, w2, k = d[:, 0], d[:, 1], d[:, 2], d[:, 3], d[:, 4], d[:, 7]
@@ -40,4 +41,10 @@ for name, A, N, kw in cases:
     span = (d[:, 3].max() - d[:, 0].min())
     print(f'== {name}: {len(d)} records, tiles per workgroup up to {int(k.max()) + 1}; cycles:')
     print(f'   K loop {f(loop - top)}   epilogue issue {f(epi - loop)}   wait+barrier {f(nxt - epi)}   tile total {f(nxt - top)}   phase-2 wait of iteration 0 {f(w2)}')
+    ok_i = itr[:, 0] > 0
+    if ok_i.any() and K == 768:
+        it = itr[ok_i]
+        seq = torch.cat([it[:, 9:10], it[:, 0:6], it[:, 8:9]], 1)          # tile top, iteration starts 0..5, end of loop
+        dd = (seq[:, 1:] - seq[:, :-1]).mean(0)
+        print('   4th tile of each workgroup: top -> it0 ' + ' '.join(f'{v:6.0f}' for v in dd.tolist()) + '   (iteration 0..5 durations; the last = it5 + end-of-loop barriers)')
     print(f'   tile period {per.mean():8.0f} (sd {per.std():6.0f})   between tiles {gap.mean():6.0f} (sd {gap.std():5.0f})', flush=True)
