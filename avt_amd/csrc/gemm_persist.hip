@@ -32,6 +32,13 @@
 
 namespace {
 
+// PK_FULLPF = 1: the epilogues without a second operand (bias, GELU) run in two slots + the space behind the ring, and the next tile's
+// K tile 1 halves A0h / B0h are fetched before the epilogue as well (six stages resident when a tile starts instead of four).  Built and
+// measured (256 clips, one box, whole step): 906.9 clips/s against 911.5 with the four-slot layout (off: 900.6) -- a tile's first K-loop
+// iteration stays 1.4x as long as the others either way (6.7 k against 4.9 k cycles), so that time is not the wait for those two stages.
+#ifndef PK_FULLPF
+#define PK_FULLPF 0
+#endif
 constexpr int PK_HALF = 128 * 64 * 2;                      // one half-tile slot of the ring: 16 KB
 // Longer reductions stay with gemm_8p_kernel unless the caller forces tile 809: what the persistent form removes is per-TILE time (fill,
 // store drain, workgroup turn-over: 12-20 % of a K = 768 tile, 2-4 % of a K = 3072 tile), and the step runs at the board's power limit --
@@ -313,11 +320,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
   constexpr int BK = 64, HALF = PK_HALF;
   constexpr int TABB = (EPK == 1) ? GELU_TAB_BYTES : 0;
   constexpr bool HAS_OP = (EPK == 2 || EPK == 3);
-  // EPK 0 / 1 (no second operand): the epilogue fits the two parity-1 slots of the B1h / A1h kinds (4 KB per wave) plus the space behind the
-  // ring, so the next tile's K tile 1 halves A0h / B0h are fetched before the epilogue too -- the K loop is then the uninterrupted stream of
-  // gemm_8p_kernel, and a tile starts with six stages resident instead of four (measured before: iteration 0 of a tile took 6.3-7.3 k
-  // cycles against 4.8 k in steady state, waiting for the two stages issued after the epilogue)
-  constexpr bool FULLPF = !HAS_OP;
+  constexpr bool FULLPF = !HAS_OP && PK_FULLPF;
   extern __shared__ __attribute__((aligned(16))) char smem8[];
   char* const lds = smem8 + TABB;                       // the ring: 8 half-tile slots (kind x K-tile parity), as in gemm_8p_kernel
   char* const ext = lds + 8 * HALF;                     // behind the ring: 32 KB (8 KB next to the table), idle during the K loop
