@@ -365,3 +365,19 @@ def test_gpu_clip_transform_draws_follow_the_reference_rules():
     assert GpuClipTransform(248, -1, 224, train=False, color_jitter_hue=0.1).draw_jitter() == []
     with pytest.raises(ValueError):
         GpuClipTransform(248, -1, 224, train=True, color_jitter_hue=0.7)
+
+
+def test_gemm_variant_names_mirror_the_library_routing():
+    """ops.gemm_variant names the kernel a GEMM lands on (the bench's per-kernel rows): the persistent 8-phase kernel for the big k-major
+    contractions with K <= 1024 and a covered epilogue (csrc/gemm_persist.hip: avt_gemm_persist), gemm_8p_kernel for longer reductions,
+    uncovered epilogues and other layouts."""
+    from avt_amd import ops
+    M = 2560 * 197
+    assert ops.gemm_variant(M, 2304, 768, True, True, ops.OUT_BF16, 0, True) == 'gemm_8pp_kernel'            # qkv forward
+    assert ops.gemm_variant(M, 3072, 768, True, True, ops.OUT_BF16, 0, True) == 'gemm_8pp_kernel'            # fc1 forward / fc2 data gradient
+    assert ops.gemm_variant(M, 768, 3072, True, True, ops.OUT_BF16, 0, True).startswith('gemm_8p_kernel')    # K > 1024
+    assert ops.gemm_variant(M, 768, 768, True, True, ops.OUT_BF16, 0, False).startswith('gemm_8p_kernel')    # epilogue not covered
+    assert ops.gemm_variant(M, 768, 768, True, False, ops.OUT_BF16, 0, True).startswith('gemm_8p_kernel')    # B not k-major
+    assert ops.gemm_variant(M, 776, 768, True, True, ops.OUT_BF16, 0, True).startswith('gemm_8p_kernel')     # N % 256 != 0
+    assert ops.gemm_variant(3940, 768, 768, True, True, ops.OUT_BF16, 0, True) != 'gemm_8pp_kernel'          # too few tiles
+    assert ops.gemm_variant(M, 2304, 768, True, True, ops.OUT_BF16, 808, True).startswith('gemm_8p_kernel')  # forced one-tile-per-workgroup
