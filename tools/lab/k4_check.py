@@ -1,5 +1,7 @@
 """4-wave k-major GEMM (gemm_k4.hip, tile 2566) against gemm_8p_kernel (tile 808): bit equality (incl. guard rows behind a ragged M) and time.
-usage: python tools/lab/k4_check.py [frames=2560]"""
+usage: python tools/lab/k4_check.py [frames=2560]
+(Historical: tile 2566 exists only when tools/lab/attic/gemm_k4*.hip.txt is put back as avt_amd/csrc/gemm_k4.hip with its dispatch hook -- the kernels
+measured slower and were removed; profiles/r04_persistent_gemm.txt section 6.)"""
 import os, sys
 import torch
 sys.path.insert(0, '.')
