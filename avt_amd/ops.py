@@ -24,8 +24,32 @@ def _stream():
 PERSIST_KMAX = 1024      # mirrors PK_KMAX in csrc/gemm_persist.hip
 
 
+# Every kernel-template prefix the router below can return for an output tile of 128 rows or more: what bench.py's GEMM-family /
+# dominant-kernel numbers aggregate over (a CPU test checks that each name gemm_variant produces for such a tile is caught).
+LARGE_TILE_KERNELS = ('gemm_kernel<128', 'gemm_kernel<256', 'gemm_8pp_kernel', 'gemm_8p_kernel', 'gemm_w4_kernel', 'gemm_4w_kernel',
+                      'gemm_deepa_kernel', 'gemm_pp_kernel')
+
+
+def persist_epilogue_kind(out_mode, act, has_bias, has_res, has_aux, has_c2, has_colsum, drop_p=0.0, res_period=0):
+    """The epilogue kind (EPK 0..3) of csrc/gemm_persist.hip that covers this call, or None (mirror of avt_gemm_persist's dispatch)."""
+    if out_mode != OUT_BF16 or drop_p != 0.0 or res_period != 0:
+        return None
+    if act == ACT_NONE and not has_res and not has_colsum and not has_c2 and not has_aux:
+        return 0
+    if act == ACT_GELU_ERF and not has_res and not has_colsum:
+        return 1
+    if act == ACT_NONE and has_res and not has_colsum and not has_c2 and not has_aux:
+        return 2
+    if act == ACT_MUL_AUX and has_aux and not has_res and not has_bias and not has_c2:
+        return 3
+    return None
+
+
 def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False):
-    """Mirror of the tile choice in avt_gemm_bf16 (csrc/gemm.hip): names the kernel template a call lands on."""
+    """Mirror of the tile choice in avt_gemm_bf16 (csrc/gemm.hip): names the kernel template a call lands on.
+    ``epilogue_ok``: False / None = the persistent kernel does not cover the epilogue; True or an int = it does (an int names the kind)."""
+    epk = None if (epilogue_ok is False or epilogue_ok is None) else (epilogue_ok if type(epilogue_ok) is int else -1)
+    epilogue_ok = epk is not None
     epi = 1 if out_mode == OUT_ACCUM_F32 else 0
     bm = tile
     if bm == 0:
@@ -50,7 +74,7 @@ def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False)
     if bm == 808:
         return f'gemm_8p_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
     if bm == 809:
-        return 'gemm_8pp_kernel'
+        return 'gemm_8pp_kernel' if epk is None or epk < 0 else f'gemm_8pp_kernel<{epk}>'
     if bm == 258:
         return f'gemm_deepa_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
     if bm == 512:
@@ -116,10 +140,8 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
     if trace is not None:
         ev1.record()
         # (the epilogues the persistent kernel covers: bias | erf-GELU (+ derivative) | bias + residual | saved derivative (+ column sums))
-        ep_ok = (out_mode == OUT_BF16 and drop_p == 0.0 and res_period == 0 and
-                 ((act == ACT_NONE and c2 is None and colsum is None and aux is None) or
-                  (act == ACT_GELU_ERF and res is None and colsum is None) or
-                  (act == ACT_MUL_AUX and aux is not None and res is None and bias is None and c2 is None)))
+        ep_ok = persist_epilogue_kind(out_mode, act, bias is not None, res is not None, aux is not None, c2 is not None, colsum is not None,
+                                      drop_p, res_period)
         trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, ep_ok), 2.0 * M * N * K, ev0, ev1, (M, N, K)))
     return out
 

@@ -35,6 +35,10 @@ def test_abi_library_exports_every_declared_symbol():
         args = [a for a in m.group(1).split(',') if a.strip() and a.strip() != 'void']
         assert len(args) == len(lib.SIZE_QUERIES[name]), (name, len(args))
         assert getattr(l, name)(*([64] * len(args))) > 0
+    # ... and nothing but the declared C symbols leaves the library (csrc/exports.map): no mangled internals, no toolchain markers
+    nm = subprocess.run(['nm', '-D', '--defined-only', lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.strip()}
+    assert exported == declared | {'avt_abi_version'} or exported == declared, exported ^ declared
 
 
 def test_host_side_validation_rejects_bad_calls_without_a_gpu():
@@ -381,3 +385,40 @@ def test_gemm_variant_names_mirror_the_library_routing():
     assert ops.gemm_variant(M, 776, 768, True, True, ops.OUT_BF16, 0, True).startswith('gemm_8p_kernel')     # N % 256 != 0
     assert ops.gemm_variant(3940, 768, 768, True, True, ops.OUT_BF16, 0, True) != 'gemm_8pp_kernel'          # too few tiles
     assert ops.gemm_variant(M, 2304, 768, True, True, ops.OUT_BF16, 808, True).startswith('gemm_8p_kernel')  # forced one-tile-per-workgroup
+    # the epilogue kind is part of the persistent kernel's name (rocprof shows gemm_8pp_kernel<EPK>)
+    ek = ops.persist_epilogue_kind
+    assert ek(ops.OUT_BF16, ops.ACT_NONE, True, False, False, False, False) == 0
+    assert ek(ops.OUT_BF16, ops.ACT_GELU_ERF, True, False, False, True, False) == 1
+    assert ek(ops.OUT_BF16, ops.ACT_NONE, True, True, False, False, False) == 2
+    assert ek(ops.OUT_BF16, ops.ACT_MUL_AUX, False, False, True, False, True) == 3
+    assert ek(ops.OUT_F32, ops.ACT_NONE, True, False, False, False, False) is None
+    assert ek(ops.OUT_BF16, ops.ACT_NONE, True, True, False, False, False, res_period=197) is None
+    assert ops.gemm_variant(M, 3072, 768, True, True, ops.OUT_BF16, 0, 1) == 'gemm_8pp_kernel<1>'
+
+
+def test_bench_gemm_family_filter_catches_every_large_tile_kernel_the_router_can_return():
+    """bench.py aggregates roofline.dominant_kernel / gemm_family / worst_large_gemm_row over ops.LARGE_TILE_KERNELS (round 4: the
+    persistent kernel's name was missing from the bench's own tuple and 56 launches per step fell out of the numbers).  Every name
+    gemm_variant can produce for a tile of >= 128 rows -- automatic routing over the step's shapes and every forced tile -- must match,
+    and the small-tile names must not."""
+    import itertools
+    import re
+    from avt_amd import ops
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    assert 'BIG = ops.LARGE_TILE_KERNELS' in src and src.count('startswith(BIG)') >= 3
+    big = ops.LARGE_TILE_KERNELS
+    M = 2560 * 197
+    shapes = [(M, 2304, 768), (M, 3072, 768), (M, 768, 3072), (M, 768, 768), (M, 768, 2304), (2304, 768, M), (3072, 768, M), (768, 3072, M),
+              (768, 768, M), (2560, 2048, 8192), (2560, 8192, 2048), (2560, 6144, 2048), (2048, 8192, 2560), (2560, 3840, 2048), (96 * 197 * 10, 4096, 1024)]
+    seen = set()
+    for (m, n, k), ak, bk, mode, epk in itertools.product(shapes, (True, False), (True, False), (ops.OUT_BF16, ops.OUT_F32, ops.OUT_ACCUM_F32),
+                                                         (None, 0, 1, 2, 3)):
+        for tile in (0, 128, 256, 808, 809, 2564, 258, 512, 2568):
+            name = ops.gemm_variant(m, n, k, ak, bk, mode, tile, epk)
+            seen.add(name.split('<')[0])
+            rows = re.match(r'gemm_kernel<(\d+),', name)
+            if rows is None or int(rows.group(1)) >= 128:
+                assert name.startswith(big), name
+    assert {'gemm_8pp_kernel', 'gemm_8p_kernel', 'gemm_kernel', 'gemm_4w_kernel'} <= seen
+    for tile in (64, 643):
+        assert not ops.gemm_variant(3940, 768, 768, True, True, ops.OUT_BF16, tile, None).startswith(big)
