@@ -23,11 +23,15 @@
 // not fit an L2), handed out dynamically: one ticket counter per XCD in device memory, a workgroup (which reads its XCC_ID) draws the
 // next tile of its XCD's range.  A workgroup that finds a CU only late -- the collectives of a data-parallel step occupy CUs while
 // the backward GEMMs run -- draws what is left or nothing; a static assignment would make such a launch take twice as long.
+// When its own range is exhausted a workgroup goes on with the ranges of XCDs xcc + 1, xcc + 2, ... (mod 8): every tile is computed
+// wherever the workgroups land -- a partitioned device, a CU mask that empties an XCD, or any part whose XCC_ID does not span 0..7
+// (round-4 advisor finding: the static split left such ranges unwritten).  In the normal case that is the launch's tail balancing itself.
 // The ticket for the tile after next is requested by wave 0 during the epilogue (a returning atomic issued before the tile's stores,
 // so that in-order retirement has it back by the counted wait at the epilogue's end) and reaches the other waves through LDS at the
 // barrier that ends the epilogue; the last workgroup to leave zeroes the counters for the next launch on the stream.
 // (Built with -mllvm -amdgpu-atomic-optimizer-strategy=None: the optimizer would turn the one-lane atomic into a wave reduction
 // followed by an immediate s_waitcnt vmcnt(0).)
+#include <mutex>
 #include "gemm_tile.hpp"
 
 namespace {
@@ -64,6 +68,15 @@ __device__ __forceinline__ int pk_ticket(int* tkt, int lane) {
   int tk = 0x7fffffff;
   if (tkt && lane == 0) tk = __hip_atomic_fetch_add(tkt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return tk;
+}
+
+// one synchronous device-scope ticket draw, issued through inline assembly: the compiler's wait-count bookkeeping never sees it (a returning
+// atomic that it tracks, inside control flow, made it put an s_waitcnt vmcnt(0) behind the stores and LDS-DMA requests of every path: 13 -> 78
+// such waits in this file).  Only used where the wave has nothing else to do: the launch's first draw and the move to another XCD's range.
+__device__ __forceinline__ int pk_draw_sync(int* ctr) {
+  int r;
+  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(r) : "v"(ctr), "v"(1) : "memory");
+  return r;
 }
 
 // 16-byte row-strip stores of a wave tile (lane = row rl = lane / 8 of an 8-row group, columns (lane & 7) * 8 ..): the per-lane part of the
@@ -392,18 +405,40 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
   xcc &= 7u;
   const int xq = ntile >> 3, xr = ntile & 7;
-  const int x_start = ((int)xcc < xr) ? (int)xcc * (xq + 1) : xr * (xq + 1) + ((int)xcc - xr) * xq;
-  const int x_cnt = xq + (((int)xcc < xr) ? 1 : 0);
-  int* const my_counter = sched + xcc * 32;
+  // range r of the walk (the tiles XCD r would own): first position, number of tiles, ticket counter (one 128-byte line each;
+  // sched[8 * 32] counts the workgroups that have left)
+  auto rng_start = [&](int r) __attribute__((always_inline)) { return (r < xr) ? r * (xq + 1) : xr * (xq + 1) + (r - xr) * xq; };
+  auto rng_cnt = [&](int r) __attribute__((always_inline)) { return xq + ((r < xr) ? 1 : 0); };
+  // `vic` = how many ranges this workgroup has moved past (0 = it still draws from its own XCD's range); uniform, changes only at barriers
+  int vic = 0;
+  // thread 0 only: the next position of the walk, drawn synchronously, moving on to the next range when one is exhausted
+  auto draw_sync = [&](int& v) __attribute__((always_inline)) {
+#pragma nounroll
+    for (; v < 8; ++v) {
+      const int r = (int)((xcc + (uint32_t)v) & 7u);
+      const int t_ = pk_draw_sync(sched + r * 32);
+      if (t_ < rng_cnt(r)) return rng_start(r) + t_;
+    }
+    return 0x7fffffff;
+  };
   int* const mailbox = (int*)(ext + 512);                 // free at both times it is used (start of the kernel, end of an epilogue)
-  // the first two tickets
-  if (tid == 0) mailbox[0] = __hip_atomic_fetch_add(my_counter, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // the first two positions
+  if (tid == 0) {
+    const int own = (int)xcc, oc = rng_cnt(own);
+    const int t0_ = __hip_atomic_fetch_add(sched + own * 32, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int v = 0, g0, g1;
+    if (t0_ + 1 < oc) { g0 = rng_start(own) + t0_; g1 = g0 + 1; }
+    else if (t0_ < oc) { g0 = rng_start(own) + t0_; v = 1; g1 = draw_sync(v); }
+    else { v = 1; g0 = draw_sync(v); g1 = (g0 == 0x7fffffff) ? g0 : draw_sync(v); }
+    mailbox[0] = g0; mailbox[1] = g1; mailbox[2] = v;
+  }
   __syncthreads();
-  const int tk0 = __builtin_amdgcn_readfirstlane(mailbox[0]), tk1 = tk0 + 1;
+  const int gp0 = __builtin_amdgcn_readfirstlane(mailbox[0]), gp1 = __builtin_amdgcn_readfirstlane(mailbox[1]);
+  vic = __builtin_amdgcn_readfirstlane(mailbox[2]);
   __syncthreads();
-  bool has_cur = tk0 < x_cnt, has_next = tk1 < x_cnt;
-  Tile cur = tile_at(x_start + (has_cur ? tk0 : 0)), nxt = cur;
-  if (has_next) nxt = tile_at(x_start + tk1);
+  bool has_cur = gp0 != 0x7fffffff, has_next = gp1 != 0x7fffffff;
+  Tile cur = tile_at(has_cur ? gp0 : 0), nxt = cur;
+  if (has_next) nxt = tile_at(gp1);
   int tkn = 0;
   bool walk_pending = false;
 
@@ -525,8 +560,8 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
       //      those of K tile nk + 1 are left out (their slots become the epilogue's) ----
       if (walk_pending) {                                   // (first iteration of every tile but the workgroup's first)
         walk_pending = false;
-        has_next = tkn < x_cnt;
-        if (has_next) nxt = tile_at(x_start + tkn);
+        has_next = tkn != 0x7fffffff;
+        if (has_next) nxt = tile_at(tkn);
       }
       if (last && (EPK == 0 || EPK == 1 || EPK == 2) && p.bias) bias_v = p.bias[n0_e + pk_lane_id()];   // used two phases later at the earliest
       read_a(fa, 0, 1); P8_PIN(); stage_b(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
@@ -564,7 +599,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
       const GemmParams pe = p;
 #endif
       const int lane_e = pk_lane_id();
-      int* const tkt = (wave == 0 && has_next) ? my_counter : nullptr;       // wave 0 draws the ticket for the tile after next
+      int* const tkt = (wave == 0 && has_next && vic < 8) ? sched + ((xcc + (uint32_t)vic) & 7u) * 32 : nullptr;   // wave 0 draws the ticket for the tile after next
       if constexpr (EPK == 0) {
         tk = pk_ticket(tkt, lane_e);
         ((float*)P2)[lane_e] = bias_v;
@@ -584,7 +619,17 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
     else wait_vmcnt<16>();                                 // everything older than the tile's last 16 stores: the next tile's K tile 0, the ticket
     asm volatile("" :: "v"(tk));                           // (every wave "uses" the ticket here: the compiler's own bookkeeping of the atomic ends at this
                                                            //  point on every path, not only inside wave 0's branch below)
-    if (wave == 0 && pk_lane_id() == 0) mailbox[0] = tk;
+    if (wave == 0 && pk_lane_id() == 0) {
+      // ticket -> position of the walk; a ticket past the end of the range it was drawn from means that range is exhausted: go on with the
+      // next ranges, synchronously (this happens once per range and workgroup, at the launch's tail)
+      int gpos = 0x7fffffff, v = vic;
+      if (has_next && v < 8) {
+        const int r = (int)((xcc + (uint32_t)v) & 7u);
+        if (tk < rng_cnt(r)) gpos = rng_start(r) + tk;
+        else { ++v; gpos = draw_sync(v); }
+      }
+      mailbox[0] = gpos; mailbox[1] = v;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     P8_BARRIER();                                          // ... for every wave's share of it; and every patch has been read back
 #ifdef AVT_LAB
@@ -595,9 +640,10 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
     ++tile_k;
 #endif
     if (!has_next) break;
-    tkn = __builtin_amdgcn_readfirstlane(mailbox[0]);      // the ticket of the tile after the one that starts now: turned into a tile under
+    vic = __builtin_amdgcn_readfirstlane(mailbox[1]);
+    tkn = __builtin_amdgcn_readfirstlane(mailbox[0]);      // the position of the tile after the one that starts now: turned into a tile under
     lane_k = pk_lane_id();                                 // the first iteration of the K loop (needed in its last one)
-    if (EPK != 0) lane_bases(lane_k);
+    lane_bases(lane_k);                                    // (re-derived per tile in every variant: kept across the epilogue they cost the plain one two spilled registers)
     cur = nxt;
     walk_pending = true;
   }
@@ -618,21 +664,34 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
 #undef P8_BARRIER
 }
 
-// ticket counters: a ring of blocks (8 counters + the leave count, a 128-byte line each) per device, zeroed once; every launch
-// leaves its block zeroed.  Launches on one stream are ordered; launches on different streams draw different blocks.
+// ticket counters: one block (8 counters + the leave count, a 128-byte line each) per (device, stream), zeroed once; every launch leaves
+// its block zeroed.  Launches on one stream are ordered, so they can share a block whatever the depth of the launch queue; launches on
+// different streams (the forward thread and the autograd thread call in here concurrently) never share one.  The table is guarded by a
+// mutex; a 65th stream on a device gets no block and its GEMMs take the one-tile-per-workgroup kernel.  (The first call on a device
+// allocates: warm the library up before capturing a stream into a graph.)
 constexpr int PK_SCHED_INTS = 9 * 32, PK_SCHED_BLOCKS = 64;
-int* sched_block() {
+int* sched_block(hipStream_t s) {
+  static std::mutex mu;
   static int* base[16] = {};
-  static unsigned next_block = 0;
+  static hipStream_t owner[16][PK_SCHED_BLOCKS] = {};
+  static int nown[16] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
   if (!base[dev]) {
     int* ptr = nullptr;
     if (hipMalloc(&ptr, (size_t)PK_SCHED_BLOCKS * PK_SCHED_INTS * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (hipMemset(ptr, 0, (size_t)PK_SCHED_BLOCKS * PK_SCHED_INTS * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); return nullptr; }
     base[dev] = ptr;
   }
-  return base[dev] + (size_t)(next_block++ % PK_SCHED_BLOCKS) * PK_SCHED_INTS;
+  int idx = -1;
+  for (int i = 0; i < nown[dev]; ++i) if (owner[dev][i] == s) { idx = i; break; }
+  if (idx < 0) {
+    if (nown[dev] >= PK_SCHED_BLOCKS) return nullptr;
+    idx = nown[dev]++;
+    owner[dev][idx] = s;
+  }
+  return base[dev] + (size_t)idx * PK_SCHED_INTS;
 }
 
 template <int EPK>
@@ -644,7 +703,7 @@ int launch_8pp(const GemmParams& p, int grid, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gemm_8pp_kernel<EPK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  int* sched = sched_block();
+  int* sched = sched_block(s);
   if (!sched) return 0;                                     // no counter block: the caller's non-persistent kernel does the job
   auto magic = [](uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d + 1); };
   PkWalk wk{};

@@ -43,7 +43,9 @@ class GradReducer:
         # small: as soon as the not-yet-produced head of the buffer is at most ``tail_bytes`` (default: half a bucket -- at 64 MiB that
         # is the ViT's patch embedding + block 0, 31.5 MB), everything produced so far goes out at once instead of waiting for a
         # full bucket, so finish() only has that head left.
-        self.tail_elems = (bucket_bytes // 2 if tail_bytes is None else tail_bytes) // 4
+        # (never more than a bucket: with a 'single bucket' setting the default would otherwise turn every segment into its own collective)
+        self.tail_elems = min((bucket_bytes // 2 if tail_bytes is None else tail_bytes) // 4, self.bucket_elems)
+        self._tail_sent = False             # the early tail flush happens ONCE per step
         self.overlap = overlap
         self.paused = False                 # True: no exchange at all (bench: the same step without collectives in flight)
         self.comm_stream = torch.cuda.Stream() if self.arena.grad.is_cuda else None
@@ -74,6 +76,17 @@ class GradReducer:
         dist.broadcast(arena.master, src=src)
         arena.refresh_shadow(force=True)
 
+    @staticmethod
+    def broadcast_optimizer_state(optimizer, src=0):
+        """Every rank continues from rank ``src``'s momentum buffers (after steps in which the replicas were allowed to drift apart)."""
+        buf = getattr(optimizer, 'momentum_buf', None)             # avt_amd.optim.FusedSGD: one flat buffer
+        if torch.is_tensor(buf):
+            dist.broadcast(buf, src=src)
+        for st in getattr(optimizer, 'state', {}).values():        # a torch optimizer: per-parameter state tensors
+            for v in (st.values() if isinstance(st, dict) else ()):
+                if torch.is_tensor(v) and v.numel() > 1:
+                    dist.broadcast(v, src=src)
+
     def start_step(self):
         self._lo = self._sent = self.arena.total
         self._handles = []
@@ -81,6 +94,7 @@ class GradReducer:
         self._fwd_calls = {}
         self.launched = 0
         self.bytes_on_wire = 0
+        self._tail_sent = False
 
     def _segment_ready(self, module, first_param, last_param):
         """A fused node finished writing the gradients of [first_param, last_param].  A module that ran forward k times
@@ -96,11 +110,14 @@ class GradReducer:
         if (self.world > 1 or self.always) and self.overlap and not self.paused:
             while self._sent - self._lo >= self.bucket_elems:
                 self._launch(self._sent - self.bucket_elems, self._sent)
-            if 0 < self._lo <= self.tail_elems and self._sent > self._lo:
+            if not self._tail_sent and 0 < self._lo <= self.tail_elems and self._sent > self._lo:
+                # one early flush per step (round-4 advisor finding: without the flag every later segment launched its own small collective,
+                # each with an event and a stream wait); what is produced after it goes out with finish()
                 quantum = 64 * max(self.world, 1)
                 lo = (self._lo + quantum - 1) // quantum * quantum          # keep bucket edges on shard boundaries (rs_ag)
                 if lo < self._sent:
                     self._launch(lo, self._sent)
+                    self._tail_sent = True
 
     def _launch(self, s, e):
         a = self.arena
@@ -129,9 +146,9 @@ class GradReducer:
         n = buf.numel()
         self.bytes_on_wire += n * buf.element_size()
         if self.mode == 'rs_ag' and n % self.world == 0:
-            # (bucket edges are multiples of 64 * world; only the tail bucket [0, _sent) that finish() sends can fail to divide
-            #  -- the arena's size is a multiple of 64, not of 64 * world, e.g. on 3, 5, 6 or 7 ranks -- and goes out as a plain
-            #  all-reduce below: the same sum)
+            # (bucket edges are multiples of 64 * world, so finish()'s bucket [0, lo) and every full bucket divide; the bucket that can fail
+            #  to is the one whose upper end is the arena's end -- the first full bucket or the early-tail bucket [lo, total): the arena's size
+            #  is a multiple of 64, not of 64 * world, e.g. on 3, 5, 6 or 7 ranks -- and it goes out as a plain all-reduce below: the same sum)
             shard = buf.view(self.world, n // self.world)[dist.get_rank(self.group)]       # in place: the rank's own chunk
             dist.reduce_scatter_tensor(shard, buf, op=dist.ReduceOp.SUM, group=self.group)
             src = shard if dist.get_backend(self.group) == 'nccl' else shard.clone()       # only RCCL gathers in place

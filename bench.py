@@ -241,6 +241,7 @@ def main(argv=None):
             trainer.reducer.paused = False
             no_comm = tr
             trainer.reducer.broadcast_parameters(trainer.model)
+            trainer.reducer.broadcast_optimizer_state(trainer.optimizer)      # (the momentum drifted apart as well)
             trainer.step(data)
             sync()
         calls0 = _abi.N_CALLS
@@ -279,6 +280,16 @@ def main(argv=None):
     if dist_on:
         comm_all = [None] * world
         dist.all_gather_object(comm_all, comm)
+    # who took part: a device-side sum of ones over the job's communicator (with backend nccl = RCCL: the ranks RCCL actually connected)
+    # and each rank's device identity (N ranks on N distinct devices, or -- gloo functional check -- sharing some)
+    ranks_seen, devices_seen = 1, None
+    if dist_on:
+        one = torch.ones(1, device=device, dtype=torch.float32)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        devices_seen = [None] * world
+        pr = torch.cuda.get_device_properties(device)
+        dist.all_gather_object(devices_seen, f'{pr.name} #{local} pci {getattr(pr, "pci_bus_id", "?")}:{getattr(pr, "pci_device_id", "?")}')
     t = torch.tensor([elapsed_local], device=device, dtype=torch.float64)
     per_rank = [t.clone() for _ in range(world)]
     if dist_on:
@@ -379,7 +390,7 @@ def main(argv=None):
                         'note': 'rank 0: C-ABI calls (1-2 kernel launches each) and Python time to enqueue one step; enqueue >= ms_per_step means the step is host-bound'},
                'roofline': roof}
         if comm_all[0] is not None:
-            out['comm'] = {'per_rank': comm_all, 'note': 'comm_exposed_ms = time the optimizer waited for the gradient exchange after backward had finished',
+            out['comm'] = {'rccl_ranks_seen': ranks_seen, 'backend': args.backend, 'devices': devices_seen, 'per_rank': comm_all, 'note': 'comm_exposed_ms = time the optimizer waited for the gradient exchange after backward had finished',
                            'env': {k: v for k, v in os.environ.items() if k.startswith(('NCCL_', 'RCCL_', 'HSA_ENABLE_IPC'))}}
             if m['no_comm_trace'] and tm > 0:
                 nc = [r for r in gemm_rows(m['no_comm_trace'], 3, step_s) if r['kernel'].startswith(BIG)]

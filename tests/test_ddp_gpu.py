@@ -20,10 +20,15 @@ from avt_amd.func.train import Trainer
 from avt_amd.func.train_eval_ops import Basic
 from avt_amd.optim import FusedSGD
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+backend = os.environ.get('AVT_TEST_BACKEND', 'gloo')
+if backend == 'nccl':                      # RCCL: one device per rank
+    assert torch.cuda.device_count() >= world
+    torch.cuda.set_device(rank)
 if world > 1:
-    dist.init_process_group('gloo', init_method='env://', rank=rank, world_size=world)
+    dist.init_process_group(backend, init_method='env://', rank=rank, world_size=world)
+    assert dist.get_backend() == backend
 torch.manual_seed(0)                       # identical init on every rank (broadcast must be a no-op then)
-model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
+model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32), device=torch.device('cuda', torch.cuda.current_device()))
 with torch.no_grad():
     for n, p in model.named_parameters():
         if p.ndim >= 2: p.normal_(0, 0.1)
@@ -31,9 +36,9 @@ if rank == 1:                              # perturb: broadcast from rank 0 must
     with torch.no_grad(): model.classifiers.action.bias.add_(1.0)
 opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-4, arena=model.arena)
 op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
-tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=world > 1, bucket_bytes=64 << 10)
+tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=world > 1, bucket_bytes=64 << 10, reduce_mode=os.environ.get('AVT_TEST_REDUCE_MODE', 'all_reduce'))
 g = torch.Generator().manual_seed(9)
-B = 4
+B = int(os.environ.get('AVT_TEST_CLIPS', 4))
 video = torch.rand((B, 4, 3, 1, 32, 32), generator=g) * 2 - 1
 target = torch.randint(0, 17, (B,), generator=g); sub = torch.randint(-1, 17, (B, 4, 1), generator=g)
 sl = slice(rank * B // world, (rank + 1) * B // world)
@@ -48,15 +53,18 @@ torch.cuda.synchronize()
 if rank == 0:
     torch.save({k: v.cpu() for k, v in model.state_dict().items()}, sys.argv[2])
 if world > 1:
+    assert tr.reducer is not None and tr.reducer.launched >= 1
+    if backend == 'nccl':                  # the ranks RCCL connected, counted on the devices
+        one = torch.ones(1, device='cuda'); dist.all_reduce(one); assert int(one.item()) == world
     dist.barrier(); dist.destroy_process_group()
 print('OK', rank)
 '''
 
 
-def _run(world, out, tmp_path, port):
+def _run(world, out, tmp_path, port, **extra_env):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
     procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(out)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(world)]
     for p in procs:
@@ -75,6 +83,48 @@ def test_two_rank_training_matches_single_process(tmp_path):
         e = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-12))
         worst = max(worst, e)
         assert e < 2e-2, (k, e)          # bf16 activations; batch split changes rounding, not the maths
+
+
+def _devices():
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.parametrize('mode', ['all_reduce', 'rs_ag'])
+@pytest.mark.parametrize('ranks', ['2', 'all'])
+def test_rccl_training_on_one_device_per_rank_matches_single_process(tmp_path, mode, ranks):
+    """The replacement of the reference's DistributedDataParallel wrap (func/train.py:771-778, common/utils.py:145-148) over RCCL proper:
+    one process per GPU, backend 'nccl', 2 ranks and as many ranks as the node has devices, both exchange forms -- three training steps on a
+    split batch must give the parameters of a single-process run on the whole batch (same limits as the gloo test).  Skipped on a one-GPU
+    box (the driver's 1-GPU tier); turns into RCCL parity evidence by itself on any node with two or more devices."""
+    n = _devices()
+    if n < 2:
+        pytest.skip(f'RCCL needs one device per rank: {n} device(s) here')
+    world = 2 if ranks == '2' else n
+    if ranks == 'all' and n == 2:
+        pytest.skip('covered by the 2-rank case')
+    clips = str(2 * world)
+    _run(1, tmp_path / 'single.pt', tmp_path, 29571, AVT_TEST_CLIPS=clips)
+    _run(world, tmp_path / 'rccl.pt', tmp_path, 29572 + (mode == 'rs_ag'), AVT_TEST_BACKEND='nccl', AVT_TEST_REDUCE_MODE=mode, AVT_TEST_CLIPS=clips)
+    a, b = torch.load(tmp_path / 'single.pt'), torch.load(tmp_path / 'rccl.pt')
+    for k in a:
+        e = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-12))
+        assert e < 2e-2, (k, e, world, mode)
+
+
+def test_bench_multi_gpu_line_over_rccl():
+    """`python bench.py --gpus N` over RCCL on every device of the node (N >= 2): one JSON line, n_gpus = N, RCCL saw N ranks on N distinct
+    devices, per-rank rates and the exchange accounting present.  Skipped on a one-GPU box."""
+    import json
+    n = _devices()
+    if n < 2:
+        pytest.skip(f'needs two or more devices: {n} here')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--batch', '8', '--steps', '3', '--warmup', '2',
+                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=1800)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == n and d['comm']['rccl_ranks_seen'] == n and d['comm']['backend'] == 'nccl'
+    assert len(set(d['comm']['devices'])) == n and len(d['per_rank_clips_per_s']) == n and d['value'] > 0
+    assert all(c['buckets_per_step'] >= 1 for c in d['comm']['per_rank'])
 
 
 NCCL_WORKER = r'''
@@ -150,6 +200,7 @@ def test_bench_two_ranks_end_to_end_over_gloo():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'dp2' and len(d['per_rank_clips_per_s']) == 2
     assert d['value'] > 0 and 'cpu_baseline' not in d
+    assert d['comm']['rccl_ranks_seen'] == 2 and d['comm']['backend'] == 'gloo' and len(d['comm']['devices']) == 2
     assert len(d['comm']['per_rank']) == 2 and all(c['buckets_per_step'] >= 1 and 'comm_exposed_ms' in c for c in d['comm']['per_rank'])
     assert d['host']['abi_calls_per_step'] > 100 and d['roofline']['executed_frac'] < d['roofline']['frac']
     # round 4: the line says what the collectives cost the GEMMs (same step with the exchange paused) and which RCCL knobs were in effect

@@ -292,6 +292,45 @@ def test_persistent_gemm_bit_equal_to_one_tile_per_workgroup(ops, M):
         ops.gemm(a, rnd((776, K), 0.05, 46), M, 776, K, tile=809)        # N % 256 != 0: not covered, and 809 does not fall back
 
 
+CU_MASK_WORKER = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from avt_amd import ops
+def rnd(shape, scale, seed, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(shape, generator=g) * 2 - 1) * scale).to(dtype).cuda()
+M, K = 137900, 768
+a = rnd((M, K), 0.5, 41)
+for N, kw in [(768, dict(bias=rnd((768,), 1.0, 43, torch.float32))),
+              (1024, dict(bias=rnd((1024,), 1.0, 43, torch.float32), act=ops.ACT_GELU_ERF)),
+              (768, dict(bias=rnd((768,), 1.0, 43, torch.float32), res=rnd((M, 768), 1.0, 44)))]:
+    b = rnd((N, K), 0.05, 42)
+    ref = ops.gemm(a, b, M, N, K, tile=808, **kw)
+    for rep in range(3):
+        out = torch.full((M + 256, N), 7.0, device='cuda', dtype=torch.bfloat16)
+        ops.gemm(a, b, M, N, K, out=out[:M], tile=809, **kw)
+        assert torch.equal(out[:M].view(torch.int16), ref.view(torch.int16)), ('persistent GEMM differs under the CU mask', N, rep)
+        assert float(out[M:].float().min()) == 7.0 and float(out[M:].float().max()) == 7.0
+torch.cuda.synchronize()
+print('CU_MASK_OK', torch.cuda.get_device_properties(0).multi_processor_count)
+"""
+
+
+@pytest.mark.parametrize('mask', ['0:0-31', '0:0-7', '0:0-3', '0:0', '0:0-200'])
+def test_persistent_gemm_complete_under_a_cu_mask(mask):
+    """Round-4 advisor finding: the persistent GEMM split its tile walk into eight ranges by XCC_ID and a workgroup never left its own
+    range, so an XCD without a resident workgroup (CU-masked process or stream, partitioned device) left whole ranges of C unwritten.
+    Workgroups now go on with the other ranges; here the process runs under HSA_CU_MASK settings that leave between one and 201 CUs
+    (masks that small cannot populate all eight XCDs) and every output must still equal the one-tile-per-workgroup kernel's, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_CU_MASK=mask)
+    r = subprocess.run([sys.executable, '-c', CU_MASK_WORKER, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'CU_MASK_OK' in r.stdout, (mask, r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_column_sum_reductions_are_bit_reproducible(ops):
     """Every many-workgroups -> one fp32 vector reduction (GEMM colsum at each tile shape incl. ragged edges, LayerNorm backward,
     ViT attention dbias, colsum, patch-embed reduce) gives the same BITS on repeated calls with the partials workspace, and agrees
