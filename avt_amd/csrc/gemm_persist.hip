@@ -79,6 +79,17 @@ __device__ __forceinline__ int pk_draw_sync(int* ctr) {
   return r;
 }
 
+// A buffer descriptor whose words the compiler can PROVE wave-uniform (cdna_hip_programming.md T20): the tile origin is uniform in fact, but it
+// is derived from values the register allocator keeps in vector registers across the K loop, and a descriptor in vector registers makes hipcc wrap
+// EVERY buffer operation that uses it in a waterfall loop (4 v_readfirstlane, 2 compares, s_and_saveexec, the operation, a branch: the 16 / 32
+// stores of a tile's epilogue ran serialised like that through round 4).  Passing the base and the size through readfirstlane once per tile
+// puts the descriptor into scalar registers.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pk_uniform_rsrc(const void* base, uint32_t nrec) {
+  const uint64_t a = (uint64_t)base;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(nrec), 0x00020000);
+}
+
 // 16-byte row-strip stores of a wave tile (lane = row rl = lane / 8 of an 8-row group, columns (lane & 7) * 8 ..): the per-lane part of the
 // address is one register for the whole tile, the row group a scalar added per store (no 64-bit multiply-add, whose don't-care high half
 // the register allocator once paired with a register still waiting for memory: an s_waitcnt vmcnt(0) after every store)
@@ -90,7 +101,7 @@ struct PkStore {
   __device__ __forceinline__ void init(bf16_t* origin, int ld, int lane, int rows) {
     ld2 = (uint32_t)ld * 2u;
     const uint32_t nrec = (uint32_t)(rows < 0 ? 0 : (rows > 128 ? 128 : rows)) * ld2;
-    r = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, nrec, 0x00020000);
+    r = pk_uniform_rsrc(origin, nrec);
     voff = (uint32_t)(lane >> 3) * ld2 + (uint32_t)(lane & 7) * 16u;
   }
   __device__ __forceinline__ void st(int row8, u32x4_t v) const {      // row8 = first row of the 8-row group (wave-uniform)
@@ -113,6 +124,10 @@ __device__ __forceinline__ void pk_store_block(const char* patch_c, const char* 
   }
 }
 
+// (Round 5, measured and removed: stores straight from the accumulator layout -- one v_permlane32_swap per register pairs the half-waves' column
+// groups into 16-byte pieces, cdna_hip_programming.md T21, no LDS patch -- write 32 bytes per row and instruction instead of the row strips'
+// 128-byte lines: qkv forward 1579 -> 1927 us, fc1 forward with GELU + GELU' 2782 -> 4994 us, proj forward 595 -> 656 us, the step 909 -> 835
+// clips/s (profiles/r05b_epilogue_stores.txt).  Full-line stores are worth their LDS round trip.)
 // EPK 0: C = bf16(acc + bias)
 __device__ __forceinline__ void pk_epi_plain(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, const float* bias_l,
                                              int lane, int row0, int col0, int mrem) {
