@@ -18,8 +18,12 @@
 #ifndef AVT_ATTN_LD_AUX
 #define AVT_ATTN_LD_AUX 0
 #endif
-// ... and so do the 8-byte output stores (nt there: forward 727 -> 945 us, backward 2276 -> 2576 us).
+// ... and so do the output stores (nt on the 8-byte stores of round 4: forward 727 -> 945 us, backward 2276 -> 2576 us).
+// Round 5: the outputs leave in 16-byte pieces (AVT_ATTN_WIDE_ST, see the forward kernel's last lines); 0 = the 8-byte stores, for A/B.
 #define AVT_ATTN_STG(p, v) (*(p) = (v))
+#ifndef AVT_ATTN_WIDE_ST
+#define AVT_ATTN_WIDE_ST 1
+#endif
 #include "../../include/avt_hip.h"
 
 namespace {
@@ -30,6 +34,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+
+
 
 // row-major [R][64] bf16 tile, 128-B rows, 16-B chunk c of row r stored at c ^ swz8(r).  Two access patterns read these tiles:
 //   * ds_read_b128 row fragments (16 rows x one chunk): conflict-free when the 8 row pairs of a 16-row group get 8 different
@@ -227,7 +233,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
     // previous item (nothing at the first item)
     // (ALL_LIVE: every wave's strip has at least one row inside the sequence, so every guarded load / store is issued; else
     // a wave may have skipped them and the count would be wrong -> wait for everything)
-    if (ALL_LIVE) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (wide stores: 2 + 3)
+    if (ALL_LIVE) { if (AVT_ATTN_WIDE_ST) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                          // also: everyone is done with the other buffer (item n-1)
     bf16x8_t bq[2];
     bq[0] = nq[0]; bq[1] = nq[1];
@@ -306,16 +314,41 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
       for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16(vf[t & 1][dt], pb[t], o[dt]);
     }
     const int q = q0 + (lane & 15);
+    const float inv = 1.0f / sum;
+#if AVT_ATTN_WIDE_ST
+    {
+      // 16-byte stores: v_permlane16_swap exchanges the odd 16-lane rows of block dt with the even rows of block dt + 1, after which lane (i, g)
+      // holds 8 consecutive columns of block dt + (g & 1): 64 contiguous bytes per output row and instruction instead of 32 (round 5: backward
+      // 2142 -> 1983 us, forward 785 -> 775 us per launch at 2560 frames) ...
+      u32x4_t st2[2];
+#pragma unroll
+      for (int dp = 0; dp < 4; dp += 2) {
+        u32x2_t a, b;
+        a[0] = pack2bf(o[dp][0] * inv, o[dp][1] * inv); a[1] = pack2bf(o[dp][2] * inv, o[dp][3] * inv);
+        b[0] = pack2bf(o[dp + 1][0] * inv, o[dp + 1][1] * inv); b[1] = pack2bf(o[dp + 1][2] * inv, o[dp + 1][3] * inv);
+        const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+        st2[dp >> 1] = (u32x4_t){r0[0], r1[0], r0[1], r1[1]};
+      }
+      // (whole 128-byte rows per instruction -- a further DPP row_ror:8 exchange between the two pieces -- measured no better: backward
+      // 1996 -> 1965 us but three spilled registers, forward 790 -> 795 us, the step 910.9 vs 910.6 clips/s; profiles/r05d_attention_stores.txt)
+      if (q < S) {
+        bf16_t* orow = out + ((size_t)frame * S + q) * D + head * HD + (g >> 1) * 8;
+        *(u32x4_t*)(orow + (g & 1) * 16) = st2[0];
+        *(u32x4_t*)(orow + (2 + (g & 1)) * 16) = st2[1];
+      }
+    }
+#else
     if (q < S) {
-      const float inv = 1.0f / sum;
       bf16_t* orow = out + ((size_t)frame * S + q) * D + head * HD;
-  #pragma unroll
+#pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         u32x2_t w; w[0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv); w[1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
         AVT_ATTN_STG((u32x2_t*)(orow + dt * 16 + 4 * g), w);
       }
-      if (g == 0) lse[((size_t)frame * H + head) * S + q] = mx * scale + __logf(sum);
     }
+#endif
+    if (q < S && g == 0) lse[((size_t)frame * H + head) * S + q] = mx * scale + __logf(sum);
   }
 }
 
@@ -728,7 +761,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 
     // own strips have landed once everything but the youngest 8 vector-memory operations (the previous item's dK / dV stores) is done;
     // older than the strips are the prefetched Q / dO rows of this item and the dQ stores of the previous one
-    if (ALL_LIVE) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (wide stores: 4)
+    if (ALL_LIVE) { if (AVT_ATTN_WIDE_ST) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bf16x8_t bk[2], bv[2];
     bk[0] = nk[0]; bk[1] = nk[1]; bv[0] = nv[0]; bv[1] = nv[1];
     {
@@ -858,6 +893,16 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
             int lane_d = lane;                       // (opaque: the store addresses are recomputed here instead of being kept -- spilled -- across the item)
             asm volatile("" : "+v"(lane_d));
             const int q = qt * 16 + (lane_d & 15);
+#if AVT_ATTN_WIDE_ST
+            {
+              u32x2_t a, b;
+              a[0] = pack2bf(acc[0][0], acc[0][1]); a[1] = pack2bf(acc[0][2], acc[0][3]);
+              b[0] = pack2bf(acc[1][0], acc[1][1]); b[1] = pack2bf(acc[1][2], acc[1][3]);
+              const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false), r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+              const int gd = lane_d >> 4;
+              if (q < S) *(u32x4_t*)(dbase + (size_t)q * ld + (2 * half + (gd & 1)) * 16 + (gd >> 1) * 8) = (u32x4_t){r0[0], r1[0], r0[1], r1[1]};
+            }
+#else
             if (q < S) {
 #pragma unroll
               for (int j = 0; j < 2; ++j) {
@@ -865,6 +910,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
                 AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)q * ld + (2 * half + j) * 16 + 4 * (lane_d >> 4)), w);
               }
             }
+#endif
             if (dbias) {
               // q part of the qkv-bias gradient: sums over the tile's 16 queries = the 16 lanes of a DPP row (rows past the sequence are
               // exactly zero).  The accumulators come straight out of the matrix pipe into hand-written DPP adds: the wait states are
@@ -890,6 +936,29 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 
     // next item's strips: requested after the register-hungry loop, hidden behind the stores and the item's first barrier
     fetch_strips(nitem);                        // unconditional (re-fetches this item at the end): keeps the counted wait above exact
+#if AVT_ATTN_WIDE_ST
+    // 16-byte stores (see the forward kernel): lane (i, g) ends up with 8 consecutive columns of block dp + (g & 1); one tensor after the other
+    // (eight registers of packed output at a time: the kernel sits at its 128-register limit)
+    static_for<0, 2>([&](auto w_) __attribute__((always_inline)) {
+      constexpr int which = decltype(w_)::value;                 // 0 = dK -> columns [D, 2D), 1 = dV -> [2D, 3D)
+      const f32x4_t (&acc4)[4] = which ? adv : adk;
+      u32x4_t sp[2];
+#pragma unroll
+      for (int dp = 0; dp < 4; dp += 2) {
+        u32x2_t a, b;
+        a[0] = pack2bf(acc4[dp][0], acc4[dp][1]); a[1] = pack2bf(acc4[dp][2], acc4[dp][3]);
+        b[0] = pack2bf(acc4[dp + 1][0], acc4[dp + 1][1]); b[1] = pack2bf(acc4[dp + 1][2], acc4[dp + 1][3]);
+        const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false), r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+        sp[dp >> 1] = (u32x4_t){r0[0], r1[0], r0[1], r1[1]};
+      }
+      bf16_t* tb = dbase + (which + 1) * D;
+      if (key < S) {
+        bf16_t* rp = tb + (size_t)key * ld + (g >> 1) * 8;
+        *(u32x4_t*)(rp + (g & 1) * 16) = sp[0];
+        *(u32x4_t*)(rp + (2 + (g & 1)) * 16) = sp[1];
+      }
+    });
+#else
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       if (key < S) {
@@ -899,6 +968,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
         AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g), x);
       }
     }
+#endif
   }
   if (dbias) {
     __syncthreads();
