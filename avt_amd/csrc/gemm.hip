@@ -894,6 +894,13 @@ __global__ __launch_bounds__(256, 2) void gemm_4w_kernel(GemmParams p) {
 // (profiles/r03_issue_rules.txt), no second wave is needed to keep the pipe fed as long as the K loop holds no vector-ALU work:
 // fragment addresses and DMA offsets are per-lane constants, the K advance lives in the scalar buffer descriptor.
 // Ring: 5 stages of [32 k][256 + 256] bf16 = 160 KB (the whole LDS; this epilogue needs none), 4 stages in flight.
+// cache policy of the two operand streams (aux of buffer_load ... lds: 0 = default, 2 = nt, 16 = sc1); A/B switches, see profiles/r05e_w4_cache_policy.txt
+#ifndef AVT_W4_LDA_AUX
+#define AVT_W4_LDA_AUX 0
+#endif
+#ifndef AVT_W4_LDB_AUX
+#define AVT_W4_LDB_AUX 0
+#endif
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   static_assert(EPI == 2, "4-wave weight-gradient kernel: split-K slab epilogue only");
@@ -956,8 +963,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   };
   auto dma = [&](int q, int slot) __attribute__((always_inline)) {    // q = 0..3: A, 4..7: B, of the stage next_stage() prepared
     char* d = dst + slot * STAGE;
-    if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_t, AVT_LDS_PTR(d + q * 8 * ROWB), 16, voffA[q], 0, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_t, AVT_LDS_PTR(d + OP_T + (q - 4) * 8 * ROWB), 16, voffB[q - 4], 0, 0, 0);
+    if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_t, AVT_LDS_PTR(d + q * 8 * ROWB), 16, voffA[q], 0, 0, AVT_W4_LDA_AUX);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_t, AVT_LDS_PTR(d + OP_T + (q - 4) * 8 * ROWB), 16, voffB[q - 4], 0, 0, AVT_W4_LDB_AUX);
   };
   // transposing fragment reads (frag_kstrided<256>): lane (g = l >> 4, i = l & 15) reads k rows ks*16 + (g>>1)*8 + (i>>2) + 4h
   // (h = 0, 1), columns tile*32 + (g&1)*16 + (i&3)*4 .. +3; the 16-B chunk index is swizzled with (row & 3) << 2 = (i>>2) << 2,

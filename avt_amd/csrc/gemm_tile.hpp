@@ -768,6 +768,15 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
   }
 }
 
+// split-K slab stores (written once, read once by splitk_reduce_kernel): 0 = plain, 1 = nontemporal
+#ifndef AVT_SLAB_NT
+#define AVT_SLAB_NT 0
+#endif
+#if AVT_SLAB_NT
+#define AVT_SLAB_ST(ptr, val) __builtin_nontemporal_store((val), (f32x4_t*)(ptr))
+#else
+#define AVT_SLAB_ST(ptr, val) (*(f32x4_t*)(ptr) = (val))
+#endif
 template <int TM, int TN, int WM, int WN, int EPI, int PR = 0, bool TAB = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[TM][TN], char* lds, int wave, int lane,
                                               int row0, int col0, const char* tab = nullptr) {
@@ -785,7 +794,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *(f32x4_t*)(dst + ((i * TN + j) * 4 + q) * 256) = (f32x4_t){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          AVT_SLAB_ST(dst + ((i * TN + j) * 4 + q) * 256, ((f32x4_t){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]}));
     return;
   } else if (EPI == 1) {
     // weight-gradient epilogue: fp32 accumulate into C (atomics; C is pre-zeroed or holds the running sum)
