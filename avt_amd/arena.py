@@ -60,6 +60,9 @@ class ParamArena:
         self._version = None
         self._transposed = {}            # name -> bf16 (in, out) copy of a Linear weight's shadow (see transposed_of)
         self._transpose_jobs = None      # device job table of refresh_transposed
+        self._folded = {}                # weight name -> FoldedLinear (LayerNorm folded into the Linear behind it, see folded_of)
+        self._fold_jobs = None           # device job table of the G -> G^T transposes
+        self._fold_scratch = {}          # (N, K) -> zeroed fp32 scratch of the raw weight gradient; N -> zeroed bias-gradient scratch
         self.refresh_shadow(force=True)
 
     # ---- views -------------------------------------------------------------------------------------------------
@@ -128,11 +131,43 @@ class ParamArena:
 
     def refresh_transposed(self):
         """All registered W^T copies in one launch (a device table of (source, destination) records, rebuilt when a matrix is added)."""
-        if not self._transposed:
+        if self._transposed:
+            if self._transpose_jobs is None:
+                self._transpose_jobs = ops.transpose_jobs([(self.shadow_of(n), t) for n, t in self._transposed.items()])
+            ops.transpose_batch(self._transpose_jobs)
+        self.refresh_folded()
+
+    # ---- LayerNorm folded into the Linear behind it (csrc/lnfold.hip) ------------------------------------------------------
+    def folded_of(self, wname, gname, bname, biasname):
+        """The folded form of LayerNorm(gamma, beta) -> Linear(W, bias): G = gamma o W and G^T (bf16), c = G 1, b' = bias + W beta, re-formed
+        from the fp32 masters whenever the shadow is refreshed (every optimizer step), plus the scratch its backward accumulates into."""
+        f = self._folded.get(wname)
+        if f is None:
+            f = FoldedLinear(self, wname, gname, bname, biasname)
+            self._folded[wname] = f
+            self._fold_jobs = None
+            f.refresh()
+            ops.transpose_into(f.G, f.Gt)
+        return f
+
+    def fold(self, weight, gamma, beta, bias):
+        return self.folded_of(self.name_of[id(weight)], self.name_of[id(gamma)], self.name_of[id(beta)], self.name_of[id(bias)])
+
+    def refresh_folded(self):
+        if not self._folded:
             return
-        if self._transpose_jobs is None:
-            self._transpose_jobs = ops.transpose_jobs([(self.shadow_of(n), t) for n, t in self._transposed.items()])
-        ops.transpose_batch(self._transpose_jobs)
+        for f in self._folded.values():
+            f.refresh()
+        if self._fold_jobs is None:
+            self._fold_jobs = ops.transpose_jobs([(f.G, f.Gt) for f in self._folded.values()])
+        ops.transpose_batch(self._fold_jobs)
+
+    def master_of(self, name):
+        o, shp = self.offsets[name], self.shapes[name]
+        k = 1
+        for s_ in shp:
+            k *= s_
+        return self.master[o:o + k].view(shp)
 
     def grads_attached(self):
         """True when every parameter still has a ``.grad`` (a torch optimizer's ``zero_grad(set_to_none=True)`` drops the
@@ -176,6 +211,43 @@ class ParamArena:
 
     def sh_t(self, param):
         return self.transposed_of(self.name_of[id(param)])
+
+
+class FoldedLinear:
+    """LayerNorm(gamma, beta) followed by Linear(W, bias), folded: see csrc/lnfold.hip and include/avt_hip.h (avt_gemm_ln_bf16)."""
+    def __init__(self, arena, wname, gname, bname, biasname):
+        self.arena, self.wname, self.gname, self.bname, self.biasname = arena, wname, gname, bname, biasname
+        N, K = arena.shapes[wname]
+        dev = arena.device
+        self.N, self.K = N, K
+        self.G = torch.empty((N, K), device=dev, dtype=torch.bfloat16)
+        self.Gt = torch.empty((K, N), device=dev, dtype=torch.bfloat16)
+        self.c = torch.empty(N, device=dev, dtype=torch.float32)
+        self.b2 = torch.empty(N, device=dev, dtype=torch.float32)
+        sc = arena._fold_scratch
+        if (N, K) not in sc:
+            sc[(N, K)] = torch.zeros((N, K), device=dev, dtype=torch.float32)
+        if N not in sc:
+            sc[N] = torch.zeros(N, device=dev, dtype=torch.float32)
+        self.T, self.dbt = sc[(N, K)], sc[N]            # shared by every folded layer of this shape: used and re-zeroed one layer at a time
+
+    def masters(self):
+        a = self.arena
+        return a.master_of(self.wname), a.master_of(self.gname), a.master_of(self.bname), a.master_of(self.biasname)
+
+    def grads(self):
+        a = self.arena
+        return a.grad_of(self.wname), a.grad_of(self.gname), a.grad_of(self.bname), a.grad_of(self.biasname)
+
+    def refresh(self):
+        W, g, b, bias = self.masters()
+        ops.ln_fold_weights(W, g, b, bias, self.G, self.c, self.b2)
+
+    def backward_weights(self):
+        """T (= dY'^T x, accumulated by the caller) and dbt (= colsum(dY)) -> dW, dgamma, dbeta, dbias of the arena's gradient buffer."""
+        W, g, b, _ = self.masters()
+        dW, dg, db, dbias = self.grads()
+        ops.ln_fold_wgrad(self.T, W, g, b, self.dbt, dW, dg, db, dbias)
 
 
 def get_arena(module: torch.nn.Module, padded_numel_fn=None) -> ParamArena:

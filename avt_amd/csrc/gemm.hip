@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   asm volatile("s_barrier" ::: "memory");   // every wave is done reading the ring before the epilogue reuses it
   if (AVT_DBG(p)) t_loop = __builtin_readcyclecounter();
 
-  gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
+  gemm_epilogue<TM, TN, WM, WN, EPI, 0, false, A_KMAJOR && B_KMAJOR>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
 #ifdef AVT_LAB
   if (p.dbg && tid == 0) {
     const long long t_math = __builtin_readcyclecounter();
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
 #ifdef AVT_LAB
   if (p.dbg) t8_loop = __builtin_readcyclecounter();
 #endif
-  gemm_epilogue<TM, TN, WM, WN, EPI, 0, GTAB>(p, acc, lds, wave, lane_e, m0_e, n0_e, smem8);
+  gemm_epilogue<TM, TN, WM, WN, EPI, 0, GTAB, A_KMAJOR && B_KMAJOR>(p, acc, lds, wave, lane_e, m0_e, n0_e, smem8);
 #ifdef AVT_LAB
   if (p.dbg && (tid == 0 || tid == 256)) {            // first wave of each group: start, end of K loop, arithmetic done, stores drained, placement
     const long long t_math = __builtin_readcyclecounter();
@@ -1118,7 +1118,8 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
                      const float* bias, int act, const void* aux, int ldaux,
                      void* C2, int ldc2, const void* res, int ldres, int res_period,
                      float drop_p, uint64_t drop_seed, float* colsum,
-                     int out_mode, int splitk, int tile, void* ws, size_t ws_bytes, float* part, size_t part_bytes, void* stream) {
+                     int out_mode, int splitk, int tile, void* ws, size_t ws_bytes, float* part, size_t part_bytes, void* stream,
+                     const float* ln_stat = nullptr, const float* ln_c = nullptr, float* stat_part = nullptr) {
   AVT_CHECK(A && B && C, "avt_gemm_bf16: null operand");
   AVT_CHECK(M > 0 && N > 0 && K > 0, "avt_gemm_bf16: bad dims M=%d N=%d K=%d", M, N, K);
   AVT_CHECK(aligned16(A) && aligned16(B) && aligned16(C), "avt_gemm_bf16: operands must be 16-byte aligned");
@@ -1135,6 +1136,17 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldc2 = ldc2; p.ldres = ldres; p.ldaux = ldaux;
   p.res_period = res_period; p.act = act; p.out_f32 = (out_mode == 1);
   p.drop_thresh = drop_threshold(drop_p); p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed;
+  p.ln_stat = ln_stat; p.ln_c = ln_c; p.stat_part = stat_part;
+  if (ln_stat || ln_c || stat_part) {
+    // LayerNorm folded into the GEMMs around it (avt_gemm_ln_bf16): activation epilogue of k-major operands only
+    AVT_CHECK(out_mode <= 1 && a_kmajor && b_kmajor, "avt_gemm_ln_bf16: the LayerNorm-fold modes need out_mode 0 | 1 and both operands k-major");
+    AVT_CHECK(!ln_c || ln_stat, "avt_gemm_ln_bf16: ln_c needs ln_stat");
+    AVT_CHECK(!ln_c || ((act == 0 || act == 1) && !res && !colsum && !stat_part && drop_p == 0.f), "avt_gemm_ln_bf16: the fold (ln_c) goes with a bias | erf-GELU epilogue only");
+    AVT_CHECK(ln_c || !ln_stat || (act == 3 && !stat_part), "avt_gemm_ln_bf16: ln_stat without ln_c scales the rows of a saved-derivative epilogue (act 3)");
+    AVT_CHECK(!stat_part || (act == 0 && !colsum && !C2 && drop_p == 0.f && out_mode == 0 && N % 32 == 0 && ldc % 8 == 0 && (!res || ldres % 8 == 0)),
+              "avt_gemm_ln_bf16: row statistics (stat_part) go with a bf16 bias (+ residual) epilogue, N %% 32 == 0 and 16-byte row strides");
+    AVT_CHECK((!ln_stat || (((uintptr_t)ln_stat) & 7) == 0) && (!ln_c || aligned16(ln_c)) && (!stat_part || aligned16(stat_part)), "avt_gemm_ln_bf16: misaligned statistics");
+  }
 #ifdef AVT_LAB
   { static const char* e2 = getenv("AVT_GEMM_STAGGER"); p.stagger = e2 ? atoi(e2) : 0; }
   { static const char* e = getenv("AVT_GEMM_DBG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
@@ -1233,6 +1245,18 @@ extern "C" int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B
   AVT_CHECK(out_mode != 3, "avt_gemm_bf16: out_mode must be 0 (bf16), 1 (fp32) or 2 (fp32 atomic accumulate)");
   return gemm_impl(A, a_kmajor, lda, B, b_kmajor, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, C2, ldc2, res, ldres, res_period,
                    drop_p, drop_seed, colsum, out_mode, splitk, tile, nullptr, 0, part, part_bytes, stream);
+}
+
+extern "C" int avt_gemm_ln_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,
+                                void* C, int ldc, int M, int N, int K,
+                                const float* bias, int act, const void* aux, int ldaux,
+                                void* C2, int ldc2, const void* res, int ldres, int res_period,
+                                float drop_p, uint64_t drop_seed, float* colsum,
+                                int out_mode, int splitk, int tile, float* part, size_t part_bytes,
+                                const float* ln_stat, const float* ln_c, float* stat_part, void* stream) {
+  AVT_CHECK(out_mode != 3, "avt_gemm_ln_bf16: out_mode must be 0 (bf16) or 1 (fp32)");
+  return gemm_impl(A, a_kmajor, lda, B, b_kmajor, ldb, C, ldc, M, N, K, bias, act, aux, ldaux, C2, ldc2, res, ldres, res_period,
+                   drop_p, drop_seed, colsum, out_mode, splitk, tile, nullptr, 0, part, part_bytes, stream, ln_stat, ln_c, stat_part);
 }
 
 extern "C" int avt_gemm_accum_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,

@@ -129,21 +129,32 @@ __device__ __forceinline__ void pk_store_block(const char* patch_c, const char* 
 // 128-byte lines: qkv forward 1579 -> 1927 us, fc1 forward with GELU + GELU' 2782 -> 4994 us, proj forward 595 -> 656 us, the step 909 -> 835
 // clips/s (profiles/r05b_epilogue_stores.txt).  Full-line stores are worth their LDS round trip.)
 // EPK 0: C = bf16(acc + bias)
+// FOLD (EPK 5): the LayerNorm fold -- v = rstd[m] * acc + (bias[n] + (-mean[m] rstd[m]) * c[n]); `rst[i]` = the lane's row statistics of block i,
+// `bias_l + 64` = the c strip
+template <bool FOLD>
 __device__ __forceinline__ void pk_epi_plain(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, const float* bias_l,
-                                             int lane, int row0, int col0, int mrem) {
+                                             int lane, int row0, int col0, int mrem, const f32x2_t (&rst)[4]) {
   const int ml = lane & 31, h = lane >> 5;
   PkStore sc;
   sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc, lane, mrem);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    const f32x2_t rr = (f32x2_t){rst[i][0], rst[i][0]}, tt = (f32x2_t){rst[i][1], rst[i][1]};
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int nl = j * 32 + 8 * q + 4 * h;
         const f32x4_t b = *(const f32x4_t*)(bias_l + nl);
-        const f32x2_t v0 = (f32x2_t){acc[i][j][4 * q], acc[i][j][4 * q + 1]} + (f32x2_t){b[0], b[1]};
-        const f32x2_t v1 = (f32x2_t){acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} + (f32x2_t){b[2], b[3]};
+        f32x2_t v0, v1;
+        if (FOLD) {
+          const f32x4_t c = *(const f32x4_t*)(bias_l + 64 + nl);
+          v0 = (f32x2_t){acc[i][j][4 * q], acc[i][j][4 * q + 1]} * rr + ((f32x2_t){c[0], c[1]} * tt + (f32x2_t){b[0], b[1]});
+          v1 = (f32x2_t){acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} * rr + ((f32x2_t){c[2], c[3]} * tt + (f32x2_t){b[2], b[3]});
+        } else {
+          v0 = (f32x2_t){acc[i][j][4 * q], acc[i][j][4 * q + 1]} + (f32x2_t){b[0], b[1]};
+          v1 = (f32x2_t){acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} + (f32x2_t){b[2], b[3]};
+        }
         *(u32x2_t*)(patch + patch_wr(ml, h, j, q)) = (u32x2_t){pack2bf(v0[0], v0[1]), pack2bf(v1[0], v1[1])};
       }
     pk_store_block<false>(patch, patch, lane, i * 32, sc, sc);
@@ -151,8 +162,8 @@ __device__ __forceinline__ void pk_epi_plain(const GemmParams& p, const f32x16_t
 }
 
 // exact values for the elements of a block that lie above the table (|x| >= 2^8, inf, NaN): WHICH = 0 writes GELU, 1 writes GELU'
-template <int WHICH>
-__device__ __forceinline__ void pk_gelu_fix(const f32x16_t* blk, const float* bias_l, char* patch, int ml, int h) {
+template <int WHICH, bool FOLD>
+__device__ __forceinline__ void pk_gelu_fix(const f32x16_t* blk, const float* bias_l, char* patch, int ml, int h, f32x2_t rs) {
 #pragma unroll 1
   for (int j = 0; j < 2; ++j)
 #pragma unroll 1
@@ -160,7 +171,8 @@ __device__ __forceinline__ void pk_gelu_fix(const f32x16_t* blk, const float* bi
       const int nl = j * 32 + 8 * q + 4 * h;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float x = bf2f(f2bf(blk[j][4 * q + e] + bias_l[nl + e]));       // the bf16-rounded pre-activation, as in the look-up
+        const float pre = FOLD ? fmaf(blk[j][4 * q + e], rs[0], fmaf(bias_l[64 + nl + e], rs[1], bias_l[nl + e])) : blk[j][4 * q + e] + bias_l[nl + e];
+        const float x = bf2f(f2bf(pre));                                        // the bf16-rounded pre-activation, as in the look-up
         if (!(fabsf(x) < GELU_TAB_TOP)) {
           bf16_t hb, db; gelu_big(x, hb, db);
           *(bf16_t*)(patch + patch_wr(ml, h, j, q) + e * 2) = WHICH ? db : hb;
@@ -170,8 +182,10 @@ __device__ __forceinline__ void pk_gelu_fix(const f32x16_t* blk, const float* bi
 }
 // EPK 1: C = GELU(acc + bias), C2 = GELU'(acc + bias), both by the LDS table (see gemm_tile.hpp: epi_fast_block, TAB)
 // (one patch, used twice: GELU rows out, then GELU' rows out)
+template <bool FOLD>
 __device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const EpiBlk<2> blk_, char* patch, const float* bias_l,
-                                                  int lane, int i32, const PkStore& sc, const PkStore& sd, const char* tab) {
+                                                  int lane, int i32, const PkStore& sc, const PkStore& sd, const char* tab, f32x2_t rs) {
+  const f32x2_t rr = (f32x2_t){rs[0], rs[0]}, tt = (f32x2_t){rs[1], rs[1]};
   const f32x16_t* blk = blk_.t;
   const int ml = lane & 31, h = lane >> 5;
   u16x2_t mx = {0, 0};
@@ -183,8 +197,15 @@ __device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const Epi
     for (int q = 0; q < 4; ++q) {
       const int nl = j * 32 + 8 * q + 4 * h;
       const f32x4_t b = *(const f32x4_t*)(bias_l + nl);
-      const f32x2_t v0 = (f32x2_t){blk[j][4 * q], blk[j][4 * q + 1]} + (f32x2_t){b[0], b[1]};
-      const f32x2_t v1 = (f32x2_t){blk[j][4 * q + 2], blk[j][4 * q + 3]} + (f32x2_t){b[2], b[3]};
+      f32x2_t v0, v1;
+      if (FOLD) {
+        const f32x4_t c = *(const f32x4_t*)(bias_l + 64 + nl);
+        v0 = (f32x2_t){blk[j][4 * q], blk[j][4 * q + 1]} * rr + ((f32x2_t){c[0], c[1]} * tt + (f32x2_t){b[0], b[1]});
+        v1 = (f32x2_t){blk[j][4 * q + 2], blk[j][4 * q + 3]} * rr + ((f32x2_t){c[2], c[3]} * tt + (f32x2_t){b[2], b[3]});
+      } else {
+        v0 = (f32x2_t){blk[j][4 * q], blk[j][4 * q + 1]} + (f32x2_t){b[0], b[1]};
+        v1 = (f32x2_t){blk[j][4 * q + 2], blk[j][4 * q + 3]} + (f32x2_t){b[2], b[3]};
+      }
       off[2 * q] = gelu_tab_offsets(pack2bf(v0[0], v0[1]), mx);
       off[2 * q + 1] = gelu_tab_offsets(pack2bf(v1[0], v1[1]), mx);
     }
@@ -203,19 +224,20 @@ __device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const Epi
   }
   constexpr unsigned short HI = ((GELU_TAB_ELO + GELU_TAB_NEXP) << 7) - 1;
   const bool big = __any((mx[0] > HI) | (mx[1] > HI));          // some value of this block lies above the table: patch those elements
-  if (__builtin_expect(big, 0)) pk_gelu_fix<0>(blk, bias_l, patch, ml, h);
+  if (__builtin_expect(big, 0)) pk_gelu_fix<0, FOLD>(blk, bias_l, patch, ml, h, rs);
   pk_store_block<false>(patch, patch, lane, i32, sc, sc);
   if (p.C2) {                                                    // the same patch again for the derivative (the LDS pipe runs a wave's operations in order)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) *(u32x2_t*)(patch + patch_wr(ml, h, j, q)) = dd[j][q];
-    if (__builtin_expect(big, 0)) pk_gelu_fix<1>(blk, bias_l, patch, ml, h);
+    if (__builtin_expect(big, 0)) pk_gelu_fix<1, FOLD>(blk, bias_l, patch, ml, h, rs);
     pk_store_block<false>(patch, patch, lane, i32, sd, sd);
   }
 }
+template <bool FOLD>
 __device__ __forceinline__ void pk_epi_gelu(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, const float* bias_l,
-                                            int lane, int row0, int col0, const char* tab, int mrem) {
+                                            int lane, int row0, int col0, const char* tab, int mrem, const f32x2_t (&rst)[4]) {
   PkStore sc, sd;
   sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc, lane, mrem);
   sd.init(p.C2 ? p.C2 + (size_t)row0 * p.ldc2 + col0 : (bf16_t*)p.C, p.ldc2, lane, mrem);
@@ -223,7 +245,7 @@ __device__ __forceinline__ void pk_epi_gelu(const GemmParams& p, const f32x16_t 
   for (int i = 0; i < 4; ++i) {          // (unrolled: a single copy of the block's code would need the block moved into place -- 32 more registers)
     EpiBlk<2> b;
     b.t[0] = acc[i][0]; b.t[1] = acc[i][1];
-    pk_epi_gelu_block(p, b, patch, bias_l, lane, i * 32, sc, sd, tab);
+    pk_epi_gelu_block<FOLD>(p, b, patch, bias_l, lane, i * 32, sc, sd, tab, rst[i]);
   }
 }
 
@@ -247,16 +269,33 @@ struct PkOperand {
 };
 
 // EPK 2: C = bf16(acc + bias + res);  EPK 3: C = bf16((acc + 0) * aux), column sums of the rounded outputs.
+// EPK 4 = EPK 2 + the rows' partial (sum, sum of squares) per 32-column slot -> stat_part (the next LayerNorm's statistics, from the fp32 values
+//         before their bf16 rounding): one more 16-byte store per block and wave -- through a descriptor that ends behind the strip's last row,
+//         no predicate, so every wave issues the same number of operations (the counted waits).
+// EPK 7 = EPK 3 with the output rows multiplied by rstd[m] (dY' = rstd o dY of the folded LayerNorm backward) and the column sums weighted by
+//         1 / rstd[m], i.e. taken over the UNscaled values: ln_stat[m] = {rstd, 1 / rstd}.
 // Block 0's operand is already on its way into `buf0` (requested during the last K iteration); blocks 1 and 3 use `buf1`.
 template <int EPK>
 __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, char* buf0, char* buf1,
                                           const PkOperand& op, float bias_v, int lane, int row0, int col0, int* tkt, int mrem) {
+  constexpr bool RES = (EPK == 2 || EPK == 4), STATS = (EPK == 4), SCALE = (EPK == 7);
+  constexpr int NST = STATS ? 5 : 4;       // stores per block
   int tk = 0x7fffffff;
   const int ml = lane & 31, h = lane >> 5;
   const int rl = lane >> 3, pc = lane & 7;
+  // (scale: the lane's row statistics of the four blocks, requested BEFORE DMA(1): older than everything the counted waits below count)
+  f32x2_t rst[SCALE ? 4 : 1];
+  if constexpr (SCALE) {
+    // (unconditional loads of a clamped row: a branch around them would make the compiler wait for them on the spot)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mrow = row0 + i * 32 + ml;
+      rst[i] = *(const f32x2_t*)(p.ln_stat + 2 * (size_t)(mrow < p.M ? mrow : p.M - 1));
+    }
+  }
   op.dma_block(buf1, lane, row0, col0, 1, mrem);
   f32x4_t bb[2][4];
-  if (EPK == 2) {          // the bias strip goes through the (still unused) patch once: lane l holds bias[col0 + l]
+  if (RES) {          // the bias strip goes through the (still unused) patch once: lane l holds bias[col0 + l]
     ((float*)patch)[lane] = bias_v;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -270,20 +309,33 @@ __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&
   }
   PkStore sc;
   sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc, lane, mrem);
+  // row statistics: the wave's two 32-column slots are slot pair col0 / 64 of [N / 64][M][2 slots][2] fp32 -- 16 bytes per row, one store per
+  // block; descriptor over this strip's rows
+  __amdgpu_buffer_rsrc_t rstat = sc.r;
+  if constexpr (STATS) {
+    const uint32_t nrec = (uint32_t)(mrem < 0 ? 0 : (mrem > 128 ? 128 : mrem)) * 16u;
+    rstat = pk_uniform_rsrc(p.stat_part + ((size_t)(col0 >> 6) * (size_t)p.M + (size_t)row0) * 4, nrec);
+  }
   float cs[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) cs[k] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    // VMEM operations younger than DMA(i): i = 0: DMA(1);  1: stores(0), DMA(2);  2: stores(0) [DMA(2) is DMA(i)], ... -- as in epi_fast_ext:
-    // i = 0: 4;  i = 1: 8;  i = 2: 12;  i = 3: 8 (one store per row strip)
-    // The wave that draws a ticket does so right after the wait of block 0 (one more operation younger than DMA(1): its wait of block 1
-    // allows 9; the ticket has two blocks' time to return before the wait of block 2 needs it retired)
+    // VMEM operations younger than DMA(i) (NST stores per block; as in epi_fast_ext):
+    //   i = 0: DMA(1) = 4;  i = 1: [ticket], DMA(2), stores(0) = 4 + NST (+ 1);  i = 2: stores(0), DMA(3), stores(1) = 4 + 2 NST;  i = 3: stores(1), stores(2) = 2 NST
+    // The wave that draws a ticket does so right after the wait of block 0 (the ticket has two blocks' time to return before the wait of
+    // block 2 needs it retired)
     switch (i) {
-      case 0: wait_vmcnt<4>(); tk = pk_ticket(tkt, lane); break;
-      case 1: if (tkt) wait_vmcnt<9>(); else wait_vmcnt<8>(); break;
-      case 2: wait_vmcnt<12>(); break;
-      default: wait_vmcnt<8>(); break;
+      case 0:
+        wait_vmcnt<4>();
+        // (the statistics are older than DMA(1): they are here.  Consumed "by" this empty statement, before the ticket's branch hides the count of
+        // younger operations from the compiler -- it would wait for ALL outstanding operations at their first real use otherwise)
+        if constexpr (SCALE) asm volatile("" : "+v"(rst[0]), "+v"(rst[SCALE ? 1 : 0]), "+v"(rst[SCALE ? 2 : 0]), "+v"(rst[SCALE ? 3 : 0]));
+        tk = pk_ticket(tkt, lane);
+        break;
+      case 1: if (tkt) wait_vmcnt<4 + NST + 1>(); else wait_vmcnt<4 + NST>(); break;
+      case 2: wait_vmcnt<4 + 2 * NST>(); break;
+      default: wait_vmcnt<2 * NST>(); break;
     }
     const char* buf = (i & 1) ? buf1 : buf0;
     u32x2_t opv[2][4];
@@ -296,29 +348,42 @@ __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer's previous contents are in registers
       op.dma_block((i & 1) ? buf1 : buf0, lane, row0, col0, i + 2, mrem);
     }
+    const f32x2_t rr = SCALE ? (f32x2_t){rst[SCALE ? i : 0][0], rst[SCALE ? i : 0][0]} : (f32x2_t){1.f, 1.f};
+    u32x4_t stw = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
+      f32x2_t s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x2_t v0 = (f32x2_t){acc[i][j][4 * q], acc[i][j][4 * q + 1]} + (f32x2_t){bb[j][q][0], bb[j][q][1]};
         f32x2_t v1 = (f32x2_t){acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} + (f32x2_t){bb[j][q][2], bb[j][q][3]};
         const f32x2_t o0 = (f32x2_t){bflo(opv[j][q][0]), bfhi(opv[j][q][0])}, o1 = (f32x2_t){bflo(opv[j][q][1]), bfhi(opv[j][q][1])};
-        if (EPK == 3) { v0 *= o0; v1 *= o1; } else { v0 += o0; v1 += o1; }
+        if (!RES) { v0 *= o0; v1 *= o1; if (SCALE) { v0 *= rr; v1 *= rr; } } else { v0 += o0; v1 += o1; }
+        if (STATS) { s1 += v0; s1 += v1; s2 += v0 * v0; s2 += v1 * v1; }
         *(u32x2_t*)(patch + patch_wr(ml, h, j, q)) = (u32x2_t){pack2bf(v0[0], v0[1]), pack2bf(v1[0], v1[1])};
       }
+      if constexpr (STATS) {
+        // the two half-waves hold the two halves of the slot's columns of one row; both store the (same) total
+        float a1 = s1[0] + s1[1], a2 = s2[0] + s2[1];
+        a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+        stw[2 * j] = __builtin_bit_cast(uint32_t, a1); stw[2 * j + 1] = __builtin_bit_cast(uint32_t, a2);
+      }
+    }
+    if constexpr (STATS) __builtin_amdgcn_raw_buffer_store_b128(stw, rstat, (uint32_t)(i * 32 + ml) * 16u, 0, 0);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + rl;
       const u32x2_t lo = *(const u32x2_t*)(patch + patch_rd(row, pc, 0)), hi = *(const u32x2_t*)(patch + patch_rd(row, pc, 1));
       sc.st(i * 32 + it * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
-      if (EPK == 3 && p.colsum) {                            // (a row past M adds nothing: selected, not branched around)
-        const float live = (i * 32 + row < mrem) ? 1.f : 0.f;
+      if (!RES && p.colsum) {                                // (a row past M adds nothing: selected, not branched around)
+        float live = (i * 32 + row < mrem) ? 1.f : 0.f;
+        if (SCALE) live *= __shfl(rst[SCALE ? i : 0][1], row, 64);      // 1 / rstd of the strip's row (held by lane `row` in the accumulator layout)
         cs[0] += live * bflo(lo[0]); cs[1] += live * bfhi(lo[0]); cs[2] += live * bflo(lo[1]); cs[3] += live * bfhi(lo[1]);
         cs[4] += live * bflo(hi[0]); cs[5] += live * bfhi(hi[0]); cs[6] += live * bflo(hi[1]); cs[7] += live * bfhi(hi[1]);
       }
     }
   }
-  if (EPK == 3 && p.colsum) {
+  if (!RES && p.colsum) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
 #pragma unroll
@@ -343,11 +408,13 @@ struct PkWalk { uint32_t mg_tn, mg_per, mg_w, mg_wl, per, nfull, wl; };
 __device__ __forceinline__ uint32_t pk_div(uint32_t n, uint32_t d, uint32_t mg) { return d == 1 ? n : __umulhi(n, mg); }
 
 // EPK: 0 = bias | 1 = bias, GELU (+ GELU') by table | 2 = bias, + residual | 3 = * saved derivative (+ column sums)
+//      4 = 2 + row statistics out | 5 = 0 with the LayerNorm fold | 6 = 1 with the LayerNorm fold | 7 = 3 with the rows scaled by rstd (see pk_epi_ext, pk_epi_plain)
 template <int EPK>
 __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_arg, int* __restrict__ sched) {
   constexpr int BK = 64, HALF = PK_HALF;
-  constexpr int TABB = (EPK == 1) ? GELU_TAB_BYTES : 0;
-  constexpr bool HAS_OP = (EPK == 2 || EPK == 3);
+  constexpr bool GELU = (EPK == 1 || EPK == 6), FOLD = (EPK == 5 || EPK == 6), AUX = (EPK == 3 || EPK == 7);
+  constexpr int TABB = GELU ? GELU_TAB_BYTES : 0;
+  constexpr bool HAS_OP = (EPK == 2 || EPK == 3 || EPK == 4 || EPK == 7);
   constexpr bool FULLPF = !HAS_OP && PK_FULLPF;
   extern __shared__ __attribute__((aligned(16))) char smem8[];
   char* const lds = smem8 + TABB;                       // the ring: 8 half-tile slots (kind x K-tile parity), as in gemm_8p_kernel
@@ -356,7 +423,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wn = wave & 3;
-  if constexpr (EPK == 1) {       // the table: once per workgroup
+  if constexpr (GELU) {       // the table: once per workgroup
     __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)g_gelu_tab, 0, GELU_TAB_BYTES, 0x00020000);
 #pragma unroll
     for (int i = 0; i < GELU_TAB_BYTES / (8 * 1024); ++i)
@@ -365,7 +432,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
   }
   // the wave's epilogue space: 8 KB in a parity-1 slot (two waves per slot), and its share of the space behind the ring
   char* const P1 = FULLPF ? lds + (wave < 4 ? 5 : 7) * HALF + (wave & 3) * 4096 : lds + (2 * wn + 1) * HALF + grp * 8192;
-  char* const P2 = ext + wave * (EPK == 1 ? 1024 : 4096);
+  char* const P2 = ext + wave * (GELU ? 1024 : 4096);
 
   const int ntile = p.tiles_m * p.tiles_n;
   const int nk = p.K / BK;                               // even, >= 4 (host-checked)
@@ -491,7 +558,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
 
   const bool two_outputs = p.C2 != nullptr;
   PkOperand op;
-  if (HAS_OP) op.init(EPK == 3 ? p.aux : p.res, EPK == 3 ? p.ldaux : p.ldres);
+  if (HAS_OP) op.init(AUX ? p.aux : p.res, AUX ? p.ldaux : p.ldres);
 
 #define P8_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define P8_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -544,7 +611,8 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
     if (grp == 1) P8_BARRIER();
     f32x16_t acc[4][2];                                     // (first written by the zero-operand MFMAs of iteration 0)
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float bias_v = 0.f;
+    float bias_v = 0.f, c_v = 0.f;
+    f32x2_t rst[4] = {};
     const int m0_e = cur.tm0 + grp * 128, n0_e = cur.tn0 + wn * 64;
     const int mrem = p.M - m0_e;                           // valid rows of this wave's strip (>= 128 everywhere but in the last row tile)
     read_b(fb0, 0, 0);
@@ -578,7 +646,18 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
         has_next = tkn != 0x7fffffff;
         if (has_next) nxt = tile_at(tkn);
       }
-      if (last && (EPK == 0 || EPK == 1 || EPK == 2) && p.bias) bias_v = p.bias[n0_e + pk_lane_id()];   // used two phases later at the earliest
+      if (last && !AUX && p.bias) bias_v = p.bias[n0_e + pk_lane_id()];   // used two phases later at the earliest
+      if constexpr (FOLD) {
+        if (last) {                                         // the c strip and the lane's row statistics of the four blocks: requested here, ahead of the next
+          const int le = pk_lane_id();                      // tile's operand stages, so that waiting for them in the epilogue does not wait for those
+          c_v = p.ln_c[n0_e + le];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {                     // (a clamped row instead of a branch: rows past M are never stored)
+            const int mrow = m0_e + i * 32 + (le & 31);
+            rst[i] = *(const f32x2_t*)(p.ln_stat + 2 * (size_t)(mrow < p.M ? mrow : p.M - 1));
+          }
+        }
+      }
       read_a(fa, 0, 1); P8_PIN(); stage_b(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb0n, 0, 0); P8_BARRIER();
       read_b(fb1, 1, 1); P8_PIN(); stage_a(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
@@ -615,14 +694,19 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
 #endif
       const int lane_e = pk_lane_id();
       int* const tkt = (wave == 0 && has_next && vic < 8) ? sched + ((xcc + (uint32_t)vic) & 7u) * 32 : nullptr;   // wave 0 draws the ticket for the tile after next
-      if constexpr (EPK == 0) {
+      // (fold: the strip and the statistics are consumed "by" this empty statement, next to the bias, while the compiler still knows how many
+      // younger operations are in flight: at their first real use, behind the ticket's branch, it would wait for ALL of them)
+      if constexpr (FOLD) asm volatile("" : "+v"(c_v), "+v"(rst[0]), "+v"(rst[1]), "+v"(rst[2]), "+v"(rst[3]), "+v"(bias_v));
+      if constexpr (EPK == 0 || EPK == 5) {
         tk = pk_ticket(tkt, lane_e);
         ((float*)P2)[lane_e] = bias_v;
-        pk_epi_plain(pe, acc, P1, (const float*)P2, lane_e, m0_e, n0_e, mrem);
-      } else if constexpr (EPK == 1) {
+        if (FOLD) ((float*)P2)[64 + lane_e] = c_v;
+        pk_epi_plain<FOLD>(pe, acc, P1, (const float*)P2, lane_e, m0_e, n0_e, mrem, rst);
+      } else if constexpr (GELU) {
         tk = pk_ticket(tkt, lane_e);
         ((float*)P2)[lane_e] = bias_v;
-        pk_epi_gelu(pe, acc, P1, (const float*)P2, lane_e, m0_e, n0_e, smem8, mrem);
+        if (FOLD) ((float*)P2)[64 + lane_e] = c_v;
+        pk_epi_gelu<FOLD>(pe, acc, P1, (const float*)P2, lane_e, m0_e, n0_e, smem8, mrem, rst);
       } else {
         tk = pk_epi_ext<EPK>(pe, acc, P1, P2, P1 + 4096, op, bias_v, lane_e, m0_e, n0_e, tkt, mrem);
       }
@@ -630,7 +714,8 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
 #ifdef AVT_LAB
     if (p.dbg) ts_epi = __builtin_readcyclecounter();
 #endif
-    if (EPK == 1 && two_outputs) wait_vmcnt<32>();    // (GELU + GELU': 32 stores per wave and tile)
+    if (GELU && two_outputs) wait_vmcnt<32>();        // (GELU + GELU': 32 stores per wave and tile)
+    else if (EPK == 4) wait_vmcnt<20>();                   // (16 output stores + 4 of the row statistics)
     else wait_vmcnt<16>();                                 // everything older than the tile's last 16 stores: the next tile's K tile 0, the ticket
     asm volatile("" :: "v"(tk));                           // (every wave "uses" the ticket here: the compiler's own bookkeeping of the atomic ends at this
                                                            //  point on every path, not only inside wave 0's branch below)
@@ -711,7 +796,7 @@ int* sched_block(hipStream_t s) {
 
 template <int EPK>
 int launch_8pp(const GemmParams& p, int grid, hipStream_t s) {
-  constexpr int smem = 8 * PK_HALF + (EPK == 1 ? GELU_TAB_BYTES + 8192 : 32768);
+  constexpr int smem = 8 * PK_HALF + ((EPK == 1 || EPK == 6) ? GELU_TAB_BYTES + 8192 : 32768);
   static_assert(smem <= 160 * 1024, "persistent 8-phase kernel: LDS");
   static bool attr_set = false;
   if (!attr_set) {
@@ -751,6 +836,21 @@ int avt_gemm_persist(GemmParams& p, int kinds, bool force, hipStream_t s) {
   if (ntile < 512 || ntile >= 65536) return 0;              // fewer than two tiles per CU: nothing to overlap; (the walk's reciprocals: n, d < 2^16)
   if ((uint64_t)p.a_bytes + 256ull * p.lda * 2 >= (1ull << 32) || (uint64_t)p.b_bytes + 256ull * p.ldb * 2 >= (1ull << 32)) return 0;
   const int grid = 256;                                     // one workgroup per CU (a multiple of the 8 XCDs)
+  const bool fold = p.ln_c != nullptr, scale = !fold && p.ln_stat != nullptr, stats = p.stat_part != nullptr;
+  if (fold) {                                                // LayerNorm fold: bias | GELU epilogues only
+    if (scale || stats || p.res || p.colsum) return 0;
+    if ((kinds & 1) && p.act == 0 && !p.C2) return launch_8pp<5>(p, grid, s);
+    if ((kinds & 2) && p.act == 1) return launch_8pp<6>(p, grid, s);
+    return 0;
+  }
+  if (scale) {                                               // rows scaled by rstd: saved-derivative epilogue only
+    if ((kinds & 8) && !stats && p.act == 3 && p.aux && !p.res && !p.bias && !p.C2) return launch_8pp<7>(p, grid, s);
+    return 0;
+  }
+  if (stats) {                                               // row statistics out: bias + residual epilogue only
+    if ((kinds & 4) && p.act == 0 && p.res && !p.colsum && !p.C2 && p.N % 64 == 0) return launch_8pp<4>(p, grid, s);
+    return 0;
+  }
   if ((kinds & 1) && p.act == 0 && !p.res && !p.colsum && !p.C2) return launch_8pp<0>(p, grid, s);
   if ((kinds & 2) && p.act == 1 && !p.res && !p.colsum) return launch_8pp<1>(p, grid, s);
   if ((kinds & 4) && p.act == 0 && p.res && !p.colsum && !p.C2) return launch_8pp<2>(p, grid, s);

@@ -27,6 +27,13 @@ struct GemmParams {
   int stagger;                   // lab only: cycles over which the first wave of workgroups spreads its start (0 = off)
 #endif
   int wide_ok;                   // all epilogue leading dims are multiples of 8 -> 16-byte accesses allowed
+  // LayerNorm folded into the GEMMs around it (avt_gemm_ln_bf16, include/avt_hip.h):
+  //   ln_c != NULL ("fold"): A holds the UN-normalised rows x, B = gamma o W, and v = rstd[m] * acc + (bias[n] - mean[m] * rstd[m] * ln_c[n]) with
+  //                          ln_stat[m] = {rstd, -mean * rstd} -- the LayerNorm of the rows without a normalised copy of them;
+  //   ln_c == NULL, ln_stat != NULL ("scale", act 3 only): the output rows are multiplied by ln_stat[m][0] (= rstd) on their way out and the column
+  //                          sums are taken over the UNscaled values (weights ln_stat[m][1] = 1 / rstd): dY' = rstd o dY for the folded backward;
+  //   stat_part != NULL: per-row partial (sum, sum of squares) of the output over each 32-column slot, [ceil(N / 64)][M][2 slots][2] fp32 -- the next LayerNorm's statistics.
+  const float* ln_stat; const float* ln_c; float* stat_part;
 #ifdef AVT_LAB
   long long* dbg;                // lab only: per-block phase timestamps (s_memtime)
 #endif
@@ -349,8 +356,15 @@ __device__ __forceinline__ void epi_cols(EpiLane& e, const GemmParams& p, const 
                                          const EpiStrip& aux_s, const EpiStrip& res_s) {
   const int nn = e.n + co;
   float v[W];
+  f32x2_t rs = {1.f, 0.f};
+  if (p.ln_stat) rs = *(const f32x2_t*)(p.ln_stat + 2 * (size_t)m);
+  if (p.ln_c) {                           // LayerNorm fold: rstd * acc + (bias - mean * rstd * c)
 #pragma unroll
-  for (int k = 0; k < W; ++k) v[k] = src[co + k] + e.bias8[co + k];
+    for (int k = 0; k < W; ++k) v[k] = fmaf(src[co + k], rs[0], fmaf(rs[1], p.ln_c[nn + k], e.bias8[co + k]));
+  } else {
+#pragma unroll
+    for (int k = 0; k < W; ++k) v[k] = src[co + k] + e.bias8[co + k];
+  }
   auto store_bf = [&](bf16_t* ptr, const float* x) {
     if (W == 8) {
       u32x4_t o; o[0] = pack2bf(x[0], x[1]); o[1] = pack2bf(x[2], x[3]); o[2] = pack2bf(x[4], x[5]); o[3] = pack2bf(x[6], x[7]);
@@ -386,6 +400,10 @@ __device__ __forceinline__ void epi_cols(EpiLane& e, const GemmParams& p, const 
   if (p.colsum) {
 #pragma unroll
     for (int k = 0; k < W; ++k) e.csum[co + k] += v[k];
+  }
+  if (p.ln_stat && !p.ln_c) {             // scale mode: the rows leave multiplied by rstd (the column sums above are over the unscaled values)
+#pragma unroll
+    for (int k = 0; k < W; ++k) v[k] *= rs[0];
   }
   if (p.out_f32) {
     float* crow = (float*)p.C + (size_t)m * p.ldc + nn;
@@ -632,8 +650,10 @@ __device__ __forceinline__ void epi_fast(const GemmParams& p, const f32x16_t (&a
 // chunk pc ^ ((r >> 1) & (LPR-1)) of row r, which makes the 8-byte reads of the accumulator layout (32 lanes = 32 rows, same
 // column) at most 2-way bank conflicted.  Column sums (bias gradients) are taken over the bf16-rounded outputs on their way
 // out (row-strip layout: 8 running sums per lane, folded across the lanes that share columns once per tile).
-template <int TM, int TN, int WN, int ACT>
+// LNM (LayerNorm-fold mode, compile time: the 8-phase kernels sit at their register limit): 0 none | 1 fold (ACT 0 | 1) | 2 scale (ACT 3) | 3 row statistics out (ACT 0)
+template <int TM, int TN, int WN, int ACT, int LNM = 0>
 __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t (&acc)[TM][TN], char* wave_lds, int lane, int row0, int col0) {
+  static_assert(LNM == 0 || (LNM == 1 && (ACT == 0 || ACT == 1)) || (LNM == 2 && ACT == 3) || (LNM == 3 && ACT == 0), "epi_fast_ext: LayerNorm-fold mode");
   constexpr int LDB = WN * 2 + 8;
   constexpr int LPR = WN / 8, RPI = 64 / LPR, IT = 32 / RPI;
   constexpr int OPB = 32 * WN * 2;
@@ -641,9 +661,27 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
   char* patch_c = wave_lds + WN * 4;
   char* patch_d = patch_c + 32 * LDB;
   char* opbuf = patch_d + 32 * LDB;
-  for (int c_ = lane; c_ < WN; c_ += 64) bias_l[c_] = (p.bias && col0 + c_ < p.N) ? p.bias[col0 + c_] : 0.f;
+  constexpr bool fold = LNM == 1;                              // LayerNorm fold (host-checked: no second operand then, so its buffer holds the c strip)
+  constexpr bool scale = LNM == 2;                             // rows leave multiplied by rstd, column sums over the unscaled values
+  constexpr bool stats = LNM == 3;
+  float* c_l = (float*)opbuf;
+  for (int c_ = lane; c_ < WN; c_ += 64) {
+    bias_l[c_] = (p.bias && col0 + c_ < p.N) ? p.bias[col0 + c_] : 0.f;
+    if (fold) c_l[c_] = (col0 + c_ < p.N) ? p.ln_c[col0 + c_] : 0.f;
+  }
   const int ml = lane & 31, h = lane >> 5;
   const int rl = lane / LPR, pc = lane % LPR, cl = pc * 8;
+  // the lane's row statistics for its row of every 32-row block (accumulator layout: lane = row); requested before the second operand's DMA so
+  // that the counted waits below (operations YOUNGER than DMA(i)) stay as they are
+  f32x2_t rst[(fold || scale) ? TM : 1];
+  if constexpr (fold || scale) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      rst[i] = (f32x2_t){1.f, 0.f};
+      const int m = row0 + i * 32 + ml;
+      if (m < p.M) rst[i] = *(const f32x2_t*)(p.ln_stat + 2 * (size_t)m);
+    }
+  }
   const bf16_t* prim_ptr = (ACT == 3) ? p.aux : p.res;
   const int prim_ld = (ACT == 3) ? p.ldaux : p.ldres;
   const int prim_period = (ACT == 3) ? 0 : p.res_period;
@@ -671,11 +709,13 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
 #pragma unroll (ACT == 0 || ACT == 3 ? 4 : 1)
   for (int i = 0; i < TM; ++i) {
     EpiBlk<TN> b;
+    f32x2_t rs = {1.f, 0.f};
+    constexpr bool RS = fold || scale;
     switch (i) {
-      case 0: b = epi_take<TM, TN, 0>(acc); break;
-      case 1: b = epi_take<TM, TN, 1>(acc); break;
-      case 2: b = epi_take<TM, TN, 2>(acc); break;
-      default: b = epi_take<TM, TN, 3>(acc); break;
+      case 0: b = epi_take<TM, TN, 0>(acc); if (RS) rs = rst[0]; break;
+      case 1: b = epi_take<TM, TN, 1>(acc); if (RS) rs = rst[RS && TM > 1 ? 1 : 0]; break;
+      case 2: b = epi_take<TM, TN, 2>(acc); if (RS) rs = rst[RS && TM > 2 ? 2 : 0]; break;
+      default: b = epi_take<TM, TN, 3>(acc); if (RS) rs = rst[RS && TM > 3 ? 3 : 0]; break;
     }
     if (has_prim) {          // see the general path for the counts
       switch (i) {
@@ -698,16 +738,25 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer's previous contents are in registers
       dma_block(i + 2);
     }
+    const f32x2_t rr = (f32x2_t){rs[0], rs[0]}, tt = (f32x2_t){rs[1], rs[1]};
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+      f32x2_t s1 = {0.f, 0.f}, s2 = {0.f, 0.f};               // the row's partial (sum, sum of squares) over this 32-column slot (stat_part)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int nl = j * 32 + 8 * q + 4 * h;
         const f32x4_t bb = *(const f32x4_t*)(bias_l + nl);
-        f32x2_t v0 = (f32x2_t){b.t[j][4 * q], b.t[j][4 * q + 1]} + (f32x2_t){bb[0], bb[1]};
-        f32x2_t v1 = (f32x2_t){b.t[j][4 * q + 2], b.t[j][4 * q + 3]} + (f32x2_t){bb[2], bb[3]};
+        f32x2_t v0, v1;
+        if (fold) {
+          const f32x4_t cc = *(const f32x4_t*)(c_l + nl);
+          v0 = (f32x2_t){b.t[j][4 * q], b.t[j][4 * q + 1]} * rr + ((f32x2_t){cc[0], cc[1]} * tt + (f32x2_t){bb[0], bb[1]});
+          v1 = (f32x2_t){b.t[j][4 * q + 2], b.t[j][4 * q + 3]} * rr + ((f32x2_t){cc[2], cc[3]} * tt + (f32x2_t){bb[2], bb[3]});
+        } else {
+          v0 = (f32x2_t){b.t[j][4 * q], b.t[j][4 * q + 1]} + (f32x2_t){bb[0], bb[1]};
+          v1 = (f32x2_t){b.t[j][4 * q + 2], b.t[j][4 * q + 3]} + (f32x2_t){bb[2], bb[3]};
+        }
         const f32x2_t o0 = (f32x2_t){bflo(opv[j][q][0]), bfhi(opv[j][q][0])}, o1 = (f32x2_t){bflo(opv[j][q][1]), bfhi(opv[j][q][1])};
-        if (ACT == 3) { v0 *= o0; v1 *= o1; }
+        if (ACT == 3) { v0 *= o0; v1 *= o1; if (scale) { v0 *= rr; v1 *= rr; } }
         if (ACT == 1 || ACT == 2) {
           f32x2_t d0, d1;
           if (ACT == 1) gelu_tab_both4(v0, v1, d0, d1);
@@ -729,8 +778,17 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
           v1[1] = drop_keep(p.drop_seed, idx + 3, p.drop_thresh) ? v1[1] * p.drop_scale : 0.f;
         }
         if (ACT != 3 && has_prim) { v0 += o0; v1 += o1; }
+        if (stats) { s1 += v0; s1 += v1; s2 += v0 * v0; s2 += v1 * v1; }
         *(u32x2_t*)(patch_c + ml * LDB + nl * 2) = (u32x2_t){pack2bf(v0[0], v0[1]), pack2bf(v1[0], v1[1])};
       }
+      if (stats) {
+        // the two half-waves hold the two halves of the slot's columns of the same row
+        float a1 = s1[0] + s1[1], a2 = s2[0] + s2[1];
+        a1 += __shfl_xor(a1, 32, 64); a2 += __shfl_xor(a2, 32, 64);
+        if (h == 0 && m < p.M && col0 + j * 32 < p.N)
+          *(f32x2_t*)(p.stat_part + ((size_t)((col0 + j * 32) >> 6) * (size_t)p.M + (size_t)m) * 4 + (((col0 + j * 32) >> 5) & 1) * 2) = (f32x2_t){a1, a2};
+      }
+    }
     const int n = col0 + cl;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -738,13 +796,15 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
       const char* src = patch_c + row * LDB + cl * 2;
       u32x2_t lo = *(const u32x2_t*)src, hi = *(const u32x2_t*)(src + 8);
       u32x2_t lo2 = lo, hi2 = hi;
-      if (p.C2) { const char* s2 = patch_d + row * LDB + cl * 2; lo2 = *(const u32x2_t*)s2; hi2 = *(const u32x2_t*)(s2 + 8); }
+      if (p.C2) { const char* s2_ = patch_d + row * LDB + cl * 2; lo2 = *(const u32x2_t*)s2_; hi2 = *(const u32x2_t*)(s2_ + 8); }
+      float w = 1.f;
+      if (scale) w = __shfl(rs[1], row, 64);                  // 1 / rstd of the strip's row: the column sums are over the unscaled values
       if (mm < p.M && n < p.N) {
         sc.st(i * 32 + row, cl, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
         if (p.C2) sd.st(i * 32 + row, cl, (u32x4_t){lo2[0], lo2[1], hi2[0], hi2[1]});
         if (p.colsum) {
-          cs[0] += bflo(lo[0]); cs[1] += bfhi(lo[0]); cs[2] += bflo(lo[1]); cs[3] += bfhi(lo[1]);
-          cs[4] += bflo(hi[0]); cs[5] += bfhi(hi[0]); cs[6] += bflo(hi[1]); cs[7] += bfhi(hi[1]);
+          cs[0] += w * bflo(lo[0]); cs[1] += w * bfhi(lo[0]); cs[2] += w * bflo(lo[1]); cs[3] += w * bfhi(lo[1]);
+          cs[4] += w * bflo(hi[0]); cs[5] += w * bfhi(hi[0]); cs[6] += w * bflo(hi[1]); cs[7] += w * bfhi(hi[1]);
         }
       }
     }
@@ -777,7 +837,8 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
 #else
 #define AVT_SLAB_ST(ptr, val) (*(f32x4_t*)(ptr) = (val))
 #endif
-template <int TM, int TN, int WM, int WN, int EPI, int PR = 0, bool TAB = false>
+// LN: compile the LayerNorm-fold variants of the epilogue (only the kernels with both operands k-major are ever asked for them)
+template <int TM, int TN, int WM, int WN, int EPI, int PR = 0, bool TAB = false, bool LN = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[TM][TN], char* lds, int wave, int lane,
                                               int row0, int col0, const char* tab = nullptr) {
   // row0/col0: global coordinates of this wave's tile origin
@@ -818,17 +879,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     char* wave_lds = lds + wave * epi_wave_lds<WN>();
     const bool fast_ok = !p.out_f32 && p.wide_ok && (p.N % 8 == 0) && !(p.act == 3 && p.res);
     if (fast_ok) {
-      const bool extra = p.res || p.act == 3 || p.colsum || p.drop_thresh;
+      const bool extra = p.res || p.act == 3 || p.colsum || p.drop_thresh || p.ln_stat || p.stat_part;
       if (!extra) {
         if (p.act == 0) epi_fast<TM, TN, WN, 0>(p, acc, wave_lds, lane, row0, col0);
         else if (p.act == 1) epi_fast<TM, TN, WN, 1, TAB>(p, acc, wave_lds, lane, row0, col0, tab);
         else epi_fast<TM, TN, WN, 2>(p, acc, wave_lds, lane, row0, col0);
-      } else {
-        if (p.act == 3) epi_fast_ext<TM, TN, WN, 3>(p, acc, wave_lds, lane, row0, col0);
-        else if (p.act == 0) epi_fast_ext<TM, TN, WN, 0>(p, acc, wave_lds, lane, row0, col0);
-        else if (p.act == 1) epi_fast_ext<TM, TN, WN, 1>(p, acc, wave_lds, lane, row0, col0);
-        else epi_fast_ext<TM, TN, WN, 2>(p, acc, wave_lds, lane, row0, col0);
-      }
+      } else if (p.act == 3) {
+        if (LN && p.ln_stat) epi_fast_ext<TM, TN, WN, 3, LN ? 2 : 0>(p, acc, wave_lds, lane, row0, col0);
+        else epi_fast_ext<TM, TN, WN, 3>(p, acc, wave_lds, lane, row0, col0);
+      } else if (p.act == 0) {
+        if (LN && p.ln_c) epi_fast_ext<TM, TN, WN, 0, LN ? 1 : 0>(p, acc, wave_lds, lane, row0, col0);
+        else if (LN && p.stat_part) epi_fast_ext<TM, TN, WN, 0, LN ? 3 : 0>(p, acc, wave_lds, lane, row0, col0);
+        else epi_fast_ext<TM, TN, WN, 0>(p, acc, wave_lds, lane, row0, col0);
+      } else if (p.act == 1) {
+        if (LN && p.ln_c) epi_fast_ext<TM, TN, WN, 1, LN ? 1 : 0>(p, acc, wave_lds, lane, row0, col0);
+        else epi_fast_ext<TM, TN, WN, 1>(p, acc, wave_lds, lane, row0, col0);
+      } else epi_fast_ext<TM, TN, WN, 2>(p, acc, wave_lds, lane, row0, col0);
       return;
     }
     // general path, per 32-row block i: wait for the second operand of block i (LDS-DMA issued two blocks earlier: global ->

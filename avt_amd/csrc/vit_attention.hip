@@ -684,11 +684,14 @@ __device__ __forceinline__ void dma_rows8(__amdgpu_buffer_rsrc_t rsrc, int ld, i
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(rm + j * 1024), 16, off, 0, 0, AVT_ATTN_LD_AUX);
 }
 
-template <int NKT, bool ALL_LIVE>
+template <int NKT, bool ALL_LIVE, bool SCALED>
 __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                  bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
-                                                                 float* __restrict__ part, int S, int H, int items, float scale) {
+                                                                 float* __restrict__ part, int S, int H, int items, float scale,
+                                                                 const float* __restrict__ row_scale) {
+  // row_scale != NULL (avt_vit_attn_bwd_scaled): row r of dqkv leaves multiplied by row_scale[2 r] -- the rstd of the LayerNorm folded into the qkv
+  // projection (dY' = rstd o dY, include/avt_hip.h); the bias column sums stay those of the unscaled gradient
   constexpr int NP = (NKT + 1) / 2;          // 32-query chunks = key / query tile pairs
   constexpr int KP = NP * 32;                // rows of every LDS tile (zero padded)
   constexpr int RM = KP * 128;               // bytes of a row-major [KP][64] bf16 tile
@@ -704,6 +707,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
   float* bias_s = dq_s + KP;                 // [H][3*64] column sums of dq | dk | dv, kept for the whole kernel
   float* stq_s = bias_s + H * 192;           // [NKT][64] this item's dq sums per query tile
   float* stv_s = stq_s + NKT * 64;           // [NP][64]  this item's dO sums per query pair (= the dv sums: every row of P sums to one)
+  float* rs_s = stv_s + NP * 64;             // [KP] row_scale of this item's rows (read by the dQ products: query rows)
   int prev_head = -1;
   const int D = H * HD, ld = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = 64 * NKT;
@@ -728,7 +732,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 
   // own strips of the NEXT item (B-operand layout, straight from global): K, V of this wave's keys; dO, O of the same rows as queries
   bf16x8_t nk[2], nv[2], ndo[2], no[2];
-  float nlq = 0.f;
+  float nlq = 0.f, nrs = 1.f;
   auto fetch_strips = [&](int it) __attribute__((always_inline)) {
     const int fr = it / H, hd = it % H;
     const size_t r0 = (size_t)fr * S;
@@ -740,6 +744,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     load_strip(out + r0 * D + hd * HD, D, S, k0, lane_f, no);
     const int key_f = k0 + (lane_f & 15);
     nlq = (key_f < S) ? lse[((size_t)fr * H + hd) * S + key_f] * LOG2E : 0.f;
+    if (SCALED) nrs = (key_f < S) ? row_scale[2 * (r0 + key_f)] : 0.f;
   };
   int item = blockIdx.x;
   if (item < items) {
@@ -775,7 +780,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       dsum = gsum(dsum) * scale;
       int lane_s = lane;                        // (opaque: these LDS addresses are used once per item)
       asm volatile("" : "+v"(lane_s));
-      if (lane_s < 16) { dq_s[k0 + lane_s] = dsum; lse_s[k0 + lane_s] = nlq; }         // k0 + 15 < NKT * 16 <= KP; rows past the sequence: 0 / 0
+      if (lane_s < 16) { dq_s[k0 + lane_s] = dsum; lse_s[k0 + lane_s] = nlq; if (SCALED) rs_s[k0 + lane_s] = nrs; }         // k0 + 15 < NKT * 16 <= KP; rows past the sequence: 0 / 0
       if (NKT * 16 < KP && wv == 0 && lane_s < KP - NKT * 16) { dq_s[NKT * 16 + lane_s] = 0.f; lse_s[NKT * 16 + lane_s] = 0.f; }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // barrier S: scalars visible; every wave is done with the previous item
@@ -896,8 +901,13 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #if AVT_ATTN_WIDE_ST
             {
               u32x2_t a, b;
-              a[0] = pack2bf(acc[0][0], acc[0][1]); a[1] = pack2bf(acc[0][2], acc[0][3]);
-              b[0] = pack2bf(acc[1][0], acc[1][1]); b[1] = pack2bf(acc[1][2], acc[1][3]);
+              float rq = 1.f;
+              if (SCALED) {       // the query rows' scale, read here and now (inline assembly: hoisted above the products by the compiler it cost 13 spilled registers)
+                const uint32_t ra_ = lds_addr32((const char*)rs_s) + (uint32_t)((qt * 16 + (lane_d & 15)) * 4);
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(rq) : "v"(ra_) : "memory");
+              }
+              a[0] = pack2bf(acc[0][0] * rq, acc[0][1] * rq); a[1] = pack2bf(acc[0][2] * rq, acc[0][3] * rq);
+              b[0] = pack2bf(acc[1][0] * rq, acc[1][1] * rq); b[1] = pack2bf(acc[1][2] * rq, acc[1][3] * rq);
               const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false), r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
               const int gd = lane_d >> 4;
               if (q < S) *(u32x4_t*)(dbase + (size_t)q * ld + (2 * half + (gd & 1)) * 16 + (gd >> 1) * 8) = (u32x4_t){r0[0], r1[0], r0[1], r1[1]};
@@ -906,7 +916,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
             if (q < S) {
 #pragma unroll
               for (int j = 0; j < 2; ++j) {
-                u32x2_t w; w[0] = pack2bf(acc[j][0], acc[j][1]); w[1] = pack2bf(acc[j][2], acc[j][3]);
+                const float rq = SCALED ? rs_s[qt * 16 + (lane_d & 15)] : 1.f;
+                u32x2_t w; w[0] = pack2bf(acc[j][0] * rq, acc[j][1] * rq); w[1] = pack2bf(acc[j][2] * rq, acc[j][3] * rq);
                 AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)q * ld + (2 * half + j) * 16 + 4 * (lane_d >> 4)), w);
               }
             }
@@ -934,6 +945,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       }
     });
 
+    // (scaled: this item's scale of the wave's own key rows, back from LDS -- kept in a register across the item it cost 14 spilled registers)
+    float crs = 1.f;
+    if (SCALED) crs = rs_s[key];
     // next item's strips: requested after the register-hungry loop, hidden behind the stores and the item's first barrier
     fetch_strips(nitem);                        // unconditional (re-fetches this item at the end): keeps the counted wait above exact
 #if AVT_ATTN_WIDE_ST
@@ -946,8 +960,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #pragma unroll
       for (int dp = 0; dp < 4; dp += 2) {
         u32x2_t a, b;
-        a[0] = pack2bf(acc4[dp][0], acc4[dp][1]); a[1] = pack2bf(acc4[dp][2], acc4[dp][3]);
-        b[0] = pack2bf(acc4[dp + 1][0], acc4[dp + 1][1]); b[1] = pack2bf(acc4[dp + 1][2], acc4[dp + 1][3]);
+        a[0] = pack2bf(acc4[dp][0] * crs, acc4[dp][1] * crs); a[1] = pack2bf(acc4[dp][2] * crs, acc4[dp][3] * crs);
+        b[0] = pack2bf(acc4[dp + 1][0] * crs, acc4[dp + 1][1] * crs); b[1] = pack2bf(acc4[dp + 1][2] * crs, acc4[dp + 1][3] * crs);
         const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false), r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
         sp[dp >> 1] = (u32x4_t){r0[0], r1[0], r0[1], r1[1]};
       }
@@ -962,9 +976,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       if (key < S) {
-        u32x2_t w; w[0] = pack2bf(adk[dt][0], adk[dt][1]); w[1] = pack2bf(adk[dt][2], adk[dt][3]);
+        u32x2_t w; w[0] = pack2bf(adk[dt][0] * crs, adk[dt][1] * crs); w[1] = pack2bf(adk[dt][2] * crs, adk[dt][3] * crs);
         AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + D + dt * 16 + 4 * g), w);
-        u32x2_t x; x[0] = pack2bf(adv[dt][0], adv[dt][1]); x[1] = pack2bf(adv[dt][2], adv[dt][3]);
+        u32x2_t x; x[0] = pack2bf(adv[dt][0] * crs, adv[dt][1] * crs); x[1] = pack2bf(adv[dt][2] * crs, adv[dt][3] * crs);
         AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g), x);
       }
     }
@@ -1001,7 +1015,7 @@ int pick_nkt(int S) { int n = (S + 15) / 16; if (n <= 1) return 1; if (n <= 2) r
 template <int NKT> size_t fwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128; }     // K, V x 2 buffers
 template <int NKT> size_t bwd_smem(int H) { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128 + (size_t)(2 * NP * 32 + H * 192 + NKT * 192) * 4; }
 
-template <int NKT> size_t bwd1_smem(int H) { constexpr int NP = (NKT + 1) / 2, KP = NP * 32; return (size_t)3 * KP * 128 + (size_t)2 * KP * 72 + (size_t)(2 * KP + H * 192 + NKT * 64 + NP * 64) * 4; }
+template <int NKT> size_t bwd1_smem(int H) { constexpr int NP = (NKT + 1) / 2, KP = NP * 32; return (size_t)3 * KP * 128 + (size_t)2 * KP * 72 + (size_t)(3 * KP + H * 192 + NKT * 64 + NP * 64) * 4; }
 
 template <int NKT>
 int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, int H, float scale, hipStream_t s) {
@@ -1019,14 +1033,16 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, in
 }
 template <int NKT>
 int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, float* dbias,
-               float* part, size_t part_bytes, int frames, int S, int H, float scale, hipStream_t s) {
+               float* part, size_t part_bytes, int frames, int S, int H, float scale, hipStream_t s, const float* row_scale = nullptr) {
 #ifndef AVT_ATTN_BWD_TWO_PHASE
   {
     // single-pass kernel (default since round 4); the two-phase kernel stays selectable for A/B (-DAVT_ATTN_BWD_TWO_PHASE)
     const size_t sm1 = bwd1_smem<NKT>(H);
     if (sm1 > 160 * 1024) { avt_set_error("avt_vit_attn_bwd: H = %d needs more LDS than a CU has", H); return -1; }
-    (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
-    (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
+    (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
+    (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
+    (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
+    (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
     const bool live = S > (NKT - 1) * 16;
     const int items1 = frames * H;
     const int pc = (int)((160 * 1024) / sm1) < 1 ? 1 : (int)((160 * 1024) / sm1);
@@ -1034,12 +1050,15 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
     if (grid1 > items1) grid1 = items1;
     if (!dbias) part = nullptr;
     if (part && part_bytes < (size_t)grid1 * 3 * H * HD * 4) { avt_set_error("avt_vit_attn_bwd: partials workspace too small"); return -1; }
-    if (live) hipLaunchKernelGGL((vit_attn_bwd1_kernel<NKT, true>), dim3(grid1), dim3(64 * NKT), sm1, s, qkv, out, dout, lse, dqkv, dbias, part, S, H, items1, scale);
-    else hipLaunchKernelGGL((vit_attn_bwd1_kernel<NKT, false>), dim3(grid1), dim3(64 * NKT), sm1, s, qkv, out, dout, lse, dqkv, dbias, part, S, H, items1, scale);
+#define AVT_BWD1(LIVE, SC) hipLaunchKernelGGL((vit_attn_bwd1_kernel<NKT, LIVE, SC>), dim3(grid1), dim3(64 * NKT), sm1, s, qkv, out, dout, lse, dqkv, dbias, part, S, H, items1, scale, row_scale)
+    if (row_scale) { if (live) AVT_BWD1(true, true); else AVT_BWD1(false, true); }
+    else { if (live) AVT_BWD1(true, false); else AVT_BWD1(false, false); }
+#undef AVT_BWD1
     if (part) { float* outs[1] = {dbias}; return avt_reduce_partials(part, grid1, 3L * H * HD, outs, 1, s); }
     return 0;
   }
 #endif
+  if (row_scale) { avt_set_error("avt_vit_attn_bwd_scaled: the two-phase kernel has no row scaling"); return -1; }
   size_t sm = bwd_smem<NKT>(H);
   if (sm > 160 * 1024) { avt_set_error("avt_vit_attn_bwd: H = %d needs more LDS than a CU has", H); return -1; }
   (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
@@ -1088,8 +1107,8 @@ extern "C" size_t avt_vit_attn_bwd_workspace_bytes(int frames, int S, int H) {
   (void)frames; (void)S;
   return (size_t)2048 * 3 * (size_t)H * HD * 4;                   // at most 256 x 8 persistent workgroups
 }
-extern "C" int avt_vit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
-                                int frames, int S, int H, int head_dim, float scale, float* part, size_t part_bytes, void* stream) {
+static int vit_attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
+                             int frames, int S, int H, int head_dim, float scale, float* part, size_t part_bytes, const float* row_scale, void* stream) {
   AVT_CHECK(qkv && out && dout && lse && dqkv, "avt_vit_attn_bwd: null argument");
   AVT_CHECK(head_dim == 64, "avt_vit_attn_bwd: head_dim must be 64 (got %d)", head_dim);
   AVT_CHECK(S >= 1 && S <= 208, "avt_vit_attn_bwd: S must be in [1, 208] (got %d)", S);
@@ -1098,13 +1117,24 @@ extern "C" int avt_vit_attn_bwd(const void* qkv, const void* out, const void* do
   const bf16_t* q = (const bf16_t*)qkv; const bf16_t* o = (const bf16_t*)out; const bf16_t* d = (const bf16_t*)dout; bf16_t* dq = (bf16_t*)dqkv;
   int rc = 0;
   switch (pick_nkt(S)) {
-    case 1: rc = launch_bwd<1>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s); break;
-    case 2: rc = launch_bwd<2>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s); break;
-    case 4: rc = launch_bwd<4>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s); break;
-    case 8: rc = launch_bwd<8>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s); break;
-    default: rc = launch_bwd<13>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s); break;
+    case 1: rc = launch_bwd<1>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s, row_scale); break;
+    case 2: rc = launch_bwd<2>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s, row_scale); break;
+    case 4: rc = launch_bwd<4>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s, row_scale); break;
+    case 8: rc = launch_bwd<8>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s, row_scale); break;
+    default: rc = launch_bwd<13>(q, o, d, lse, dq, dbias, part, part_bytes, frames, S, H, scale, s, row_scale); break;
   }
   if (rc) return rc;
   AVT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int avt_vit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
+                                int frames, int S, int H, int head_dim, float scale, float* part, size_t part_bytes, void* stream) {
+  return vit_attn_bwd_impl(qkv, out, dout, lse, dqkv, dbias, frames, S, H, head_dim, scale, part, part_bytes, nullptr, stream);
+}
+extern "C" int avt_vit_attn_bwd_scaled(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
+                                       int frames, int S, int H, int head_dim, float scale, float* part, size_t part_bytes,
+                                       const float* row_stat, void* stream) {
+  AVT_CHECK(row_stat && (((uintptr_t)row_stat) & 7) == 0, "avt_vit_attn_bwd_scaled: row_stat must be an 8-byte aligned [frames * S][2] fp32 array");
+  return vit_attn_bwd_impl(qkv, out, dout, lse, dqkv, dbias, frames, S, H, head_dim, scale, part, part_bytes, row_stat, stream);
 }

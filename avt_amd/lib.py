@@ -9,7 +9,7 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AVT_HIP_LIB') or os.path.join(_HERE, 'libavt_hip.so')      # AVT_HIP_LIB: A/B a differently built library (lab use)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _P, _I, _F, _L, _U64, _SZ = c_void_p, c_int, c_float, c_long, c_uint64, ctypes.c_size_t
 
@@ -19,6 +19,13 @@ SIGNATURES = {
     'avt_gemm_bf16': [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _U64, _P,
                       _I, _I, _I, _P, _SZ, _P],
     'avt_gemm_accum_bf16': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, ctypes.c_size_t, _P],
+    'avt_gemm_ln_bf16': [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _U64, _P,
+                         _I, _I, _I, _P, _SZ, _P, _P, _P, _P],
+    'avt_ln_stats_finalize': [_P, _I, _I, _I, _F, _P, _P, _P],
+    'avt_ln_fold_weights': [_P, _I, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P],
+    'avt_layernorm_bwd_folded': [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P, _SZ, _P],
+    'avt_ln_fold_wgrad': [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P, _SZ, _P],
+    'avt_vit_attn_bwd_scaled': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _SZ, _P, _P],
     'avt_layernorm_fwd': [_P, _I, _P, _P, _P, _I, _P, _P, _I, _I, _F, _P],
     'avt_layernorm_bwd': [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _SZ, _P],
     'avt_vit_attn_fwd': [_P, _P, _P, _I, _I, _I, _I, _F, _P],
@@ -64,6 +71,8 @@ SIZE_QUERIES = {
     'avt_gemm_accum_workspace_bytes': [_I, _I, _I],
     'avt_gemm_colsum_workspace_bytes': [_I, _I, _I],
     'avt_layernorm_bwd_workspace_bytes': [_I, _I],
+    'avt_layernorm_bwd_folded_workspace_bytes': [_I, _I],
+    'avt_ln_fold_wgrad_workspace_bytes': [_I, _I],
     'avt_vit_attn_bwd_workspace_bytes': [_I, _I, _I],
     'avt_patch_embed_bwd_reduce_workspace_bytes': [_I, _I, _I],
     'avt_colsum_workspace_bytes': [_I, _I],

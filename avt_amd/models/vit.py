@@ -59,6 +59,11 @@ class HipViT(nn.Module):
     # tokens and everything else on the CLS rows only (10/12 of one block's GEMM work and its attention disappear; results
     # are identical).  False = the generic all-token path for every block (kept for the parity tests).
     cls_only_last_block = True
+    # LayerNorm folded into the GEMMs around it (round 5; csrc/lnfold.hip, include/avt_hip.h "LayerNorm folded into the GEMMs"): norm1 -> qkv and
+    # norm2 -> fc1 of every all-token block read the residual stream itself; the rows' statistics come out of the epilogue of the GEMM that wrote
+    # the stream.  No normalised copy is written or kept: one read + one write of [tokens, D] per LayerNorm less (ln_fwd2_kernel: 6.3 ms of a
+    # 256-clip step).  False = a LayerNorm kernel in front of every projection (kept for the parity tests; the CLS-only last block always does that).
+    fold_layernorm = True
 
     def __init__(self, embed_dim=768, depth=12, num_heads=12, img_size=224):
         super().__init__()
@@ -93,12 +98,30 @@ def _vit_forward(m: HipViT, arena, frames, keep):
     N = frames.size(0)
     M = N * S
     sh = arena.sh
+    full_blocks = m.blocks[:-1] if m.cls_only_last_block else m.blocks
+    fold = bool(m.fold_layernorm) and len(full_blocks) > 0 and D % 32 == 0 and D <= 2048
     patches = ops.im2col_patch16(frames)
     R = ops.posres_prep(m.pos_embed, m.cls_token, m.patch_embed.proj.bias, S, D)
-    x = ops.gemm(patches, sh(m.patch_embed.proj.weight).view(D, 768), M, D, 768, res=R, res_period=S)
-    saved = {'patches': patches if keep else None, 'blocks': [], 'cls_last': bool(m.cls_only_last_block)}
-    full_blocks = m.blocks[:-1] if m.cls_only_last_block else m.blocks
-    for blk in full_blocks:
+    part = ops.ln_stat_part(M, D, frames.device) if fold else None          # the next LayerNorm's statistics, emitted by the GEMM that writes its input
+    x = ops.gemm(patches, sh(m.patch_embed.proj.weight).view(D, 768), M, D, 768, res=R, res_period=S, stat_part=part)
+    saved = {'patches': patches if keep else None, 'blocks': [], 'cls_last': bool(m.cls_only_last_block), 'fold': fold}
+    for bi, blk in enumerate(full_blocks):
+        if fold:
+            f1 = arena.fold(blk.attn.qkv.weight, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.bias)
+            f2 = arena.fold(blk.mlp.fc1.weight, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.bias)
+            sf1, sb1 = ops.ln_stats_finalize(part, D, m.EPS, want_bwd=keep)
+            qkv = ops.linear_fwd(x, f1.G, bias=f1.b2, ln_stat=sf1, ln_c=f1.c)
+            att, lse = ops.vit_attn_fwd(qkv, N, S, H)
+            x1 = ops.linear_fwd(att, sh(blk.attn.proj.weight), bias=blk.attn.proj.bias, res=x, stat_part=part)
+            sf2, sb2 = ops.ln_stats_finalize(part, D, m.EPS, want_bwd=keep)
+            pre = torch.empty((M, 4 * D), device=x.device, dtype=torch.bfloat16) if keep else None
+            act = ops.linear_fwd(x1, f2.G, bias=f2.b2, act=ops.ACT_GELU_ERF, c2=pre, ln_stat=sf2, ln_c=f2.c)
+            more = bi + 1 < len(full_blocks)                                  # another folded block follows: it needs the statistics of x2
+            x2 = ops.linear_fwd(act, sh(blk.mlp.fc2.weight), bias=blk.mlp.fc2.bias, res=x1, stat_part=part if more else None)
+            if keep:
+                saved['blocks'].append((x, sf1, sb1, qkv, att, lse, x1, sf2, sb2, pre, act))
+            x = x2
+            continue
         ln1, mean1, rstd1 = ops.layernorm_fwd(x, blk.norm1.weight, blk.norm1.bias, m.EPS)
         qkv = ops.linear_fwd(ln1, sh(blk.attn.qkv.weight), bias=blk.attn.qkv.bias)
         att, lse = ops.vit_attn_fwd(qkv, N, S, H)
@@ -110,6 +133,7 @@ def _vit_forward(m: HipViT, arena, frames, keep):
         if keep:
             saved['blocks'].append((x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act))
         x = x2
+    del part
     if m.cls_only_last_block:
         x, last = _last_block_forward(m, arena, m.blocks[-1], x, N, keep)          # x: [N, D], the CLS rows only
         if keep:
@@ -201,6 +225,36 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
             hook(m.norm.weight, m.norm.bias)
     for i in range(first_full, -1, -1):
         blk = m.blocks[i]
+        prev_bias = gr(m.blocks[i - 1].mlp.fc2.bias) if i > 0 else None
+        if saved['fold']:
+            # LayerNorm folded into qkv / fc1 (csrc/lnfold.hip): the gradients of their outputs travel multiplied by the rows' rstd (dY'), the raw
+            # weight gradients dY'^T x are centred, scaled by gamma and split into dW / dgamma / dbeta / dbias by FoldedLinear.backward_weights
+            (x, sf1, sb1, qkv, att, lse, x1, sf2, sb2, pre, act) = saved['blocks'][i]
+            saved['blocks'][i] = None
+            f1 = arena.fold(blk.attn.qkv.weight, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.bias)
+            f2 = arena.fold(blk.mlp.fc1.weight, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.bias)
+            ops.linear_wgrad(dx, act, gr(blk.mlp.fc2.weight))
+            dh = ops.linear_fwd(dx, sh_t(blk.mlp.fc2.weight), act=ops.ACT_MUL_AUX, aux=pre, colsum=f2.dbt, ln_stat=sb2)     # = rstd2 o dh; dbt = colsum(dh)
+            del act, pre
+            ops.linear_wgrad(dh, x1, f2.T)
+            f2.backward_weights()
+            dln2 = ops.linear_fwd(dh, f2.Gt)
+            del dh
+            dx1 = ops.layernorm_bwd_folded(dln2, x1, sf2, dres=dx, colsum=gr(blk.attn.proj.bias))
+            del dln2, x1, dx
+            ops.linear_wgrad(dx1, att, gr(blk.attn.proj.weight))
+            datt = ops.linear_fwd(dx1, sh_t(blk.attn.proj.weight))
+            dqkv = ops.vit_attn_bwd(qkv, att, datt, lse, N, S, H, dbias=f1.dbt, row_stat=sb1)                          # = rstd1 o dqkv
+            del datt, att, qkv
+            ops.linear_wgrad(dqkv, x, f1.T)
+            f1.backward_weights()
+            dln1 = ops.linear_fwd(dqkv, f1.Gt)
+            del dqkv
+            dx = ops.layernorm_bwd_folded(dln1, x, sf1, dres=dx1, colsum=prev_bias)
+            del dln1, dx1, x
+            if hook:
+                hook(blk.norm1.weight, blk.mlp.fc2.bias)
+            continue
         (x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act) = saved['blocks'][i]
         saved['blocks'][i] = None
         # x2 = act @ W2^T + b2 + x1          (db2 was accumulated by the producer of dx)
@@ -221,7 +275,6 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
         ops.linear_wgrad(dqkv, ln1, gr(blk.attn.qkv.weight))
         dln1 = ops.linear_fwd(dqkv, sh_t(blk.attn.qkv.weight))
         del dqkv, ln1
-        prev_bias = gr(m.blocks[i - 1].mlp.fc2.bias) if i > 0 else None
         dx = ops.layernorm_bwd(dln1, x, mean1, rstd1, blk.norm1.weight, gr(blk.norm1.weight), gr(blk.norm1.bias),
                                dres=dx1, colsum=prev_bias)
         del dln1, dx1, x

@@ -120,8 +120,11 @@ def _ld(t):
 
 
 def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_BF16, bias=None, act=ACT_NONE,
-         aux=None, c2=None, res=None, res_period=0, drop_p=0.0, seed=0, colsum=None, splitk=0, tile=0):
-    """C[M,N] = epilogue(sum_k opA[m,k] opB[n,k]); see avt_gemm_bf16 in include/avt_hip.h."""
+         aux=None, c2=None, res=None, res_period=0, drop_p=0.0, seed=0, colsum=None, splitk=0, tile=0,
+         ln_stat=None, ln_c=None, stat_part=None):
+    """C[M,N] = epilogue(sum_k opA[m,k] opB[n,k]); see avt_gemm_bf16 in include/avt_hip.h.
+    ln_stat / ln_c / stat_part: the LayerNorm-fold modes of avt_gemm_ln_bf16 (fold: ln_stat [M,2] + ln_c [N]; scale: ln_stat alone with
+    act=ACT_MUL_AUX; stat_part [N/32, M, 2]: row statistics of the output)."""
     _chk(A, BF16, 'A'); _chk(B, BF16, 'B')
     if tile == 0 and FORCE_TILE:
         tile = FORCE_TILE
@@ -133,15 +136,25 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     part, part_bytes = _partials(A.device, 'avt_gemm_colsum_workspace_bytes', M, N, tile) if colsum is not None else (None, 0)
-    _lib.call('avt_gemm_bf16', _p(A), int(a_kmajor), _ld(A), _p(B), int(b_kmajor), _ld(B), _p(out), _ld(out), M, N, K,
-              _p(bias), act, _p(aux), _ld(aux) if aux is not None else 0, _p(c2), _ld(c2) if c2 is not None else 0,
-              _p(res), _ld(res) if res is not None else 0, res_period, float(drop_p), int(seed), _p(colsum),
-              out_mode, splitk, tile, part, part_bytes, _stream())
+    args = (_p(A), int(a_kmajor), _ld(A), _p(B), int(b_kmajor), _ld(B), _p(out), _ld(out), M, N, K,
+            _p(bias), act, _p(aux), _ld(aux) if aux is not None else 0, _p(c2), _ld(c2) if c2 is not None else 0,
+            _p(res), _ld(res) if res is not None else 0, res_period, float(drop_p), int(seed), _p(colsum),
+            out_mode, splitk, tile, part, part_bytes)
+    ln = ln_stat is not None or ln_c is not None or stat_part is not None
+    if ln:
+        for t_, nm in ((ln_stat, 'ln_stat'), (ln_c, 'ln_c'), (stat_part, 'stat_part')):
+            if t_ is not None:
+                _chk(t_, torch.float32, nm)
+        _lib.call('avt_gemm_ln_bf16', *args, _p(ln_stat), _p(ln_c), _p(stat_part), _stream())
+    else:
+        _lib.call('avt_gemm_bf16', *args, _stream())
     if trace is not None:
         ev1.record()
         # (the epilogues the persistent kernel covers: bias | erf-GELU (+ derivative) | bias + residual | saved derivative (+ column sums))
         ep_ok = persist_epilogue_kind(out_mode, act, bias is not None, res is not None, aux is not None, c2 is not None, colsum is not None,
                                       drop_p, res_period)
+        if ep_ok is not None and ln:          # the LayerNorm-fold variants of the persistent kernel: 4 = 2 + statistics, 5 / 6 = 0 / 1 folded, 7 = 3 scaled
+            ep_ok = {0: 5, 1: 6}.get(ep_ok) if ln_c is not None else ({3: 7}.get(ep_ok) if ln_stat is not None else ({2: 4}.get(ep_ok) if N % 64 == 0 else None))
         trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, ep_ok), 2.0 * M * N * K, ev0, ev1, (M, N, K)))
     return out
 
@@ -248,6 +261,49 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, dres=None, colsum=
     return dx
 
 
+# ---- LayerNorm folded into the GEMMs around it (include/avt_hip.h: avt_gemm_ln_bf16 and friends) ----------------------------------
+def ln_stat_part(M, N, device):
+    """Scratch for the row statistics a GEMM epilogue emits (``gemm(..., stat_part=...)``): [ceil(N / 64), M, 2 slots, 2] fp32."""
+    return torch.empty(((N + 63) // 64, M, 2, 2), device=device, dtype=torch.float32)
+
+
+def ln_stats_finalize(part, D, eps, want_bwd=True):
+    """part [ceil(D / 64), rows, 2, 2] -> (stat_fwd [rows, 2] = {rstd, -mean * rstd}, stat_bwd [rows, 2] = {rstd, 1 / rstd} | None)."""
+    _chk(part, torch.float32, 'part')
+    rows = part.size(1)
+    nslots = (D + 31) // 32
+    sf = torch.empty((rows, 2), device=part.device, dtype=torch.float32)
+    sb = torch.empty((rows, 2), device=part.device, dtype=torch.float32) if want_bwd else None
+    _lib.call('avt_ln_stats_finalize', _p(part), nslots, rows, D, float(eps), _p(sf), _p(sb), _stream())
+    return sf, sb
+
+
+def ln_fold_weights(W, gamma, beta, bias, G, c, b2):
+    """G (bf16 [N, K]) = gamma o W, c [N] = G 1, b2 [N] = bias + W beta from the fp32 master parameters."""
+    _chk(W, torch.float32, 'W'); _chk(G, BF16, 'G')
+    N, K = W.shape
+    _lib.call('avt_ln_fold_weights', _p(W), _ld(W), _p(gamma), _p(beta), _p(bias), _p(G), _ld(G), _p(c), _p(b2), N, K, _stream())
+
+
+def layernorm_bwd_folded(dy, x, stat_fwd, *, dres=None, colsum=None):
+    """dx of a folded LayerNorm: dy = d xhat' (already carrying the rows' rstd), see avt_layernorm_bwd_folded."""
+    _chk(dy, BF16, 'dy'); _chk(x, BF16, 'x'); _chk(stat_fwd, torch.float32, 'stat_fwd')
+    rows, D = x.shape
+    dx = torch.empty((rows, D), device=x.device, dtype=BF16)
+    part, part_bytes = _partials(x.device, 'avt_layernorm_bwd_folded_workspace_bytes', rows, D) if colsum is not None else (None, 0)
+    _lib.call('avt_layernorm_bwd_folded', _p(dy), _ld(dy), _p(x), _ld(x), _p(stat_fwd), _p(dres), _ld(dres) if dres is not None else 0,
+              _p(dx), D, _p(colsum), rows, D, part, part_bytes, _stream())
+    return dx
+
+
+def ln_fold_wgrad(T, W, gamma, beta, dbias_tmp, dW, dgamma, dbeta, dbias):
+    """Weight-side backward of the fold: raw T = dY'^T x (fp32, re-zeroed here) -> dW, dgamma, dbeta, dbias (all accumulate)."""
+    N, K = W.shape
+    part, part_bytes = _partials(W.device, 'avt_ln_fold_wgrad_workspace_bytes', N, K)
+    _lib.call('avt_ln_fold_wgrad', _p(T), _ld(T), _p(W), _ld(W), _p(gamma), _p(beta), _p(dbias_tmp), _p(dW), _ld(dW), _p(dgamma), _p(dbeta),
+              _p(dbias), N, K, part, part_bytes, _stream())
+
+
 # ---- attention cores ---------------------------------------------------------------------------------------------------
 def vit_attn_fwd(qkv, frames, S, H):
     _chk(qkv, BF16, 'qkv')
@@ -258,11 +314,17 @@ def vit_attn_fwd(qkv, frames, S, H):
     return out, lse
 
 
-def vit_attn_bwd(qkv, out, dout, lse, frames, S, H, dbias=None):
+def vit_attn_bwd(qkv, out, dout, lse, frames, S, H, dbias=None, row_stat=None):
+    """row_stat [frames * S, 2] (= stat_bwd of the LayerNorm folded into the qkv projection): the rows of dqkv leave multiplied by row_stat[:, 0]."""
     dqkv = torch.empty_like(qkv)
     part, part_bytes = _partials(qkv.device, 'avt_vit_attn_bwd_workspace_bytes', frames, S, H) if dbias is not None else (None, 0)
-    _lib.call('avt_vit_attn_bwd', _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(dbias), frames, S, H, 64, 0.125,
-              part, part_bytes, _stream())
+    if row_stat is not None:
+        _chk(row_stat, torch.float32, 'row_stat')
+        _lib.call('avt_vit_attn_bwd_scaled', _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(dbias), frames, S, H, 64, 0.125,
+                  part, part_bytes, _p(row_stat), _stream())
+    else:
+        _lib.call('avt_vit_attn_bwd', _p(qkv), _p(out), _p(dout), _p(lse), _p(dqkv), _p(dbias), frames, S, H, 64, 0.125,
+                  part, part_bytes, _stream())
     return dqkv
 
 

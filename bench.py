@@ -88,6 +88,9 @@ def build(args, device, world):
                future_predictor=fp, classifier=Cfg(_target_='torch.nn.Linear', bias=True), same_temp_agg_dim=False,
                project_dim_for_nce=None, dropout=0.2, use_cls_mappings=False, classifier_on_past=True,
                add_regression_head=False, bn=Cfg(eps=0.001, mom=0.1))
+    if os.environ.get('AVT_FOLD_LN') is not None:          # lab A/B: the LayerNorm kernels in front of qkv / fc1 instead of the fold
+        from avt_amd.models.vit import HipViT
+        HipViT.fold_layernorm = os.environ['AVT_FOLD_LN'] != '0'
     torch.manual_seed(42)
     model = BaseModel(mcfg, {'action': NUM_CLASSES}, {}).to(device)
     with torch.no_grad():                       # ViT weights: N(0, 0.02) stand-in for the (absent) pretrained checkpoint

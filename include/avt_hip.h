@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 5
+#define AVT_ABI_VERSION 6
 
 const char* avt_last_error(void);
 int avt_abi_version(void);
@@ -97,6 +97,42 @@ int avt_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const fl
                       float* partials, size_t partials_bytes, void* stream);
 size_t avt_layernorm_bwd_workspace_bytes(int rows, int D);
 
+/* ---- LayerNorm folded into the GEMMs around it (round 5) ----------------------------------------------------------------
+ * [timm] Block.forward: x + attn(norm1(x)), x + mlp(norm2(x)) (models/video_classification.py:224).  The normalised copy of the
+ * residual stream is never written (one read + one write of [tokens, D] per LayerNorm saved):
+ *   forward   LN(x) W^T + b = rstd o (x G^T) - (rstd o mean) c^T + b'   with  G = gamma o W (bf16),  c = G 1,  b' = b + W beta
+ *   backward  dY' = rstd o dY;  d xhat' = dY' G;  dx = d xhat' - mean_k(d xhat') - xhat o mean_k(d xhat' o xhat) (+ dres);
+ *             T = dY'^T x;  dG = T - rowmean_k(T);  dW = gamma o dG + db beta^T;  dgamma = colsum(W o dG);  dbeta = W^T db;  db = colsum(dY)
+ * avt_gemm_ln_bf16 = avt_gemm_bf16 (same arguments, same kernels) plus three optional pointers -- both operands k-major, out_mode 0 | 1:
+ *   ln_c != NULL  ("fold"; act 0 | 1, no residual / column sums / dropout): A = the UN-normalised rows, B = G, bias = b', ln_c = c [N],
+ *                 ln_stat [M][2] = {rstd, -mean * rstd}:  v = rstd[m] * acc + (bias[n] - mean[m] rstd[m] c[n]), then the activation as usual;
+ *   ln_c == NULL, ln_stat != NULL ("scale"; act 3 only): ln_stat [M][2] = {rstd, 1 / rstd}: the output rows leave multiplied by rstd[m]
+ *                 (dY' for the folded backward) and `colsum` is taken over the UNscaled values (= db);
+ *   stat_part != NULL (act 0, bf16 output, bias (+ residual) epilogue, N % 32 == 0): [ceil(N / 64)][M][2][2] fp32, the rows' partial (sum, sum of squares)
+ *                 over each 32-column slot of the output (slot s at [s / 2][m][s % 2]) -- the statistics of the NEXT LayerNorm, taken where its input is produced.
+ * avt_ln_stats_finalize: stat_part -> stat_fwd [rows][2] = {rstd, -mean * rstd} and stat_bwd [rows][2] = {rstd, 1 / rstd} (either may be NULL).
+ * avt_ln_fold_weights: G [N][K] (bf16, row stride ldg), c [N], b' [N] from the fp32 master W [N][K], gamma / beta [K], bias [N] (may be NULL).
+ * avt_layernorm_bwd_folded: dx from dy = d xhat' (lddy), x, stat_fwd; dres / colsum as in avt_layernorm_bwd (colsum = column sums of dx).
+ * avt_ln_fold_wgrad: T [N][K] fp32 (the raw gradient accumulated by avt_gemm_accum_bf16 into a ZEROED scratch; re-zeroed here), dbias_tmp [N]
+ *   (this backward's colsum(dY); re-zeroed here) -> dW [N][K] += , dgamma [K] += , dbeta [K] += , dbias [N] += (may be NULL).  K % 4 == 0, K <= 2048. */
+int avt_gemm_ln_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,
+                     void* C, int ldc, int M, int N, int K,
+                     const float* bias, int act, const void* aux, int ldaux,
+                     void* C2, int ldc2, const void* res, int ldres, int res_period,
+                     float drop_p, uint64_t drop_seed, float* colsum,
+                     int out_mode, int splitk, int tile, float* partials, size_t partials_bytes,
+                     const float* ln_stat, const float* ln_c, float* stat_part, void* stream);
+int avt_ln_stats_finalize(const float* stat_part, int nslots, int rows, int D, float eps, float* stat_fwd, float* stat_bwd, void* stream);
+int avt_ln_fold_weights(const float* W, int ldw, const float* gamma, const float* beta, const float* bias, void* G, int ldg,
+                        float* c, float* b2, int N, int K, void* stream);
+int avt_layernorm_bwd_folded(const void* dy, int lddy, const void* x, int ldx, const float* stat_fwd, const void* dres, int lddres,
+                             void* dx, int lddx, float* colsum, int rows, int D, float* partials, size_t partials_bytes, void* stream);
+size_t avt_layernorm_bwd_folded_workspace_bytes(int rows, int D);
+int avt_ln_fold_wgrad(float* T, int ldt, const float* W, int ldw, const float* gamma, const float* beta, float* dbias_tmp,
+                      float* dW, int lddw, float* dgamma, float* dbeta, float* dbias, int N, int K,
+                      float* partials, size_t partials_bytes, void* stream);
+size_t avt_ln_fold_wgrad_workspace_bytes(int N, int K);
+
 /* ---- ViT spatial attention core ----------------------------------------------------------------------------------
  * [timm] Attention.forward: softmax(q k^T * scale) v per (frame, head); qkv [frames*S, 3*H*64] with columns [q|k|v]
  * head-major; out [frames*S, H*64]; lse fp32 [frames, H, S].  S <= 208, head_dim == 64.
@@ -105,6 +141,11 @@ int avt_vit_attn_fwd(const void* qkv, void* out, float* lse, int frames, int S, 
 int avt_vit_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
                      int frames, int S, int H, int head_dim, float scale, float* partials, size_t partials_bytes, void* stream);
 size_t avt_vit_attn_bwd_workspace_bytes(int frames, int S, int H);
+/* avt_vit_attn_bwd with row r of dqkv multiplied by row_stat[2 r] on its way out (row_stat [frames*S][2] = {rstd, 1 / rstd} of the LayerNorm folded
+ * into the qkv projection: dY' = rstd o dY, see "LayerNorm folded into the GEMMs"); dbias stays the column sums of the UNscaled gradient. */
+int avt_vit_attn_bwd_scaled(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias,
+                            int frames, int S, int H, int head_dim, float scale, float* partials, size_t partials_bytes,
+                            const float* row_stat, void* stream);
 
 /* ---- single-query attention ---------------------------------------------------------------------------------------
  * avt_cls_attn_*: the LAST ViT block's attention for the CLS query only.  [timm] VisionTransformer.forward_features returns

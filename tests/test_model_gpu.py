@@ -13,7 +13,7 @@ import os
 import pytest
 import torch
 
-from helpers import LOSS_WTS, build_hip_model, build_oracle_model, hip_step, load_golden, oracle_step, rel
+from helpers import LOSS_WTS, build_hip_model, build_oracle_model, cosine, hip_step, load_golden, oracle_step, rel
 
 pytestmark = pytest.mark.gpu
 TOL_OUT, TOL_GRAD = 3e-2, 5e-2
@@ -560,6 +560,65 @@ def test_g6b_rollout_full_size_head_vs_reference_golden(golden_dir):
 
 
 # ---- round 2: structure checks -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('cls_only', [True, False])
+def test_layernorm_fold_equals_the_layernorm_kernel_path(cls_only):
+    """HipViT.fold_layernorm (round 5: norm1 -> qkv and norm2 -> fc1 folded into the GEMMs, statistics from the producing GEMM's epilogue, scaled
+    gradients, centred weight gradients -- csrc/lnfold.hip) against a LayerNorm kernel in front of every projection: same outputs, losses and
+    EVERY parameter gradient (incl. the folded layers' weights, biases, gamma, beta) within the limits the oracle tests use; gamma / beta away
+    from (1, 0) and rows with a common offset so that every term of the fold is exercised.  Then against the fp32 oracle itself."""
+    from avt_amd.models.vit import HipViT
+    torch.manual_seed(3)
+    vit = (256, 3, 4, 32)
+    orc = build_oracle_model('vit', 256, 64, 2, 4, 17, vit=vit)
+    with torch.no_grad():
+        for n, p in orc.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.08)
+            elif 'norm' in n and n.endswith('weight'):
+                p.uniform_(0.5, 1.5)
+            elif n.endswith('bias'):
+                p.normal_(0, 0.2)
+        orc.backbone.model.pos_embed.add_(0.7)                # a common offset on every token row
+    g = torch.Generator().manual_seed(5)
+    video = torch.rand((3, 4, 3, 1, 32, 32), generator=g) * 2 - 1
+    target = torch.randint(0, 17, (3,), generator=g)
+    sub = torch.randint(-1, 17, (3, 4, 1), generator=g)
+    res = {}
+    old = (HipViT.fold_layernorm, HipViT.cls_only_last_block)
+    try:
+        HipViT.cls_only_last_block = cls_only
+        for fold in (False, True):
+            HipViT.fold_layernorm = fold
+            model = build_hip_model('vit', 256, 64, 2, 4, 17, vit=vit)
+            model.load_state_dict(orc.state_dict())
+            out, losses, _, tot = hip_step(model, video.cuda(), target.cuda(), sub.cuda())
+            res[fold] = ({k: v.detach().float().cpu() for k, v in out.items() if torch.is_tensor(v)}, float(tot),
+                         {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()})
+    finally:
+        HipViT.fold_layernorm, HipViT.cls_only_last_block = old
+    (o0, t0, g0), (o1, t1, g1) = res[False], res[True]
+    for k in o0:
+        assert rel(o1[k], o0[k]) < 3e-2, k
+    assert abs(t1 - t0) / abs(t0) < 3e-2
+    worst = 0.0
+    for n in g0:
+        if float(g0[n].abs().max()) == 0.0:
+            assert float(g1[n].abs().max()) == 0.0, n
+            continue
+        e = float((g1[n] - g0[n]).abs().max() / g0[n].abs().max())
+        worst = max(worst, e)
+        assert e < 4e-2 and cosine(g1[n], g0[n]) > 0.999, (n, e, cosine(g1[n], g0[n]))
+    # ... and the folded path against the fp32 oracle
+    o_out, _, _, o_tot = oracle_step(orc, video, target, sub)
+    assert rel(o1['logits/action'], o_out['logits/action']) < 3e-2 and abs(t1 - float(o_tot)) / abs(float(o_tot)) < 3e-2
+    og = {n: p.grad.detach().float().cpu() for n, p in orc.named_parameters() if p.grad is not None}
+    for n, gref in og.items():
+        if float(gref.abs().max()) == 0.0:
+            continue
+        e = float((g1[n] - gref).abs().max() / gref.abs().max())
+        assert e < 5e-2 and cosine(g1[n], gref) > 0.998, (n, e)
+
+
 def test_cls_only_last_block_equals_all_token_path():
     """The last ViT block computed for the CLS rows only gives the same features and gradients as the all-token path."""
     from avt_amd.models.vit import HipViT

@@ -424,6 +424,155 @@ def test_gemm_epilogue_dropout(ops):
     assert torch.equal(m != 0, kept)
 
 
+# ---- LayerNorm folded into the GEMMs around it (round 5: csrc/lnfold.hip, avt_gemm_ln_bf16) ---------------------------------------
+def _ln_stats_torch(x, eps):
+    xf = x.float()
+    mean = xf.mean(1)
+    rstd = (xf.var(1, unbiased=False) + eps).rsqrt()
+    return mean, rstd, torch.stack([rstd, -mean * rstd], 1).contiguous(), torch.stack([rstd, 1.0 / rstd], 1).contiguous()
+
+
+@pytest.mark.parametrize('M,tiles', [(140 * 1024 + 77, (0, 808, 809)), (197 * 6, (0, 128, 64, 808))])
+def test_layernorm_fold_forward_gemm_equals_layernorm_then_linear(ops, M, tiles):
+    """y = rstd o (x G^T) - (rstd o mean) c^T + b' against LayerNorm -> Linear (-> erf GELU) evaluated in fp32 on the same bf16 rows, for the
+    persistent kernel (EPK 5 / 6), the one-tile-per-workgroup kernel and the small tiles; rows with a large common offset (the fold's cancellation);
+    the persistent and the one-tile kernels agree bit for bit; nothing is written past row M."""
+    K, N, eps = 768, 1024, 1e-6
+    x = (rnd((M, K), 1.5, 60).float() + rnd((M, 1), 3.0, 61).float()).to(torch.bfloat16)          # per-row offsets up to +-9 on values of +-4
+    W = rnd((N, K), 0.03, 62, torch.float32)
+    gamma, beta = torch.rand(K, device='cuda') + 0.5, rnd((K,), 0.3, 63, torch.float32)
+    bias = rnd((N,), 0.5, 64, torch.float32)
+    G = torch.empty((N, K), device='cuda', dtype=torch.bfloat16)
+    c, b2 = torch.empty(N, device='cuda'), torch.empty(N, device='cuda')
+    ops.ln_fold_weights(W, gamma, beta, bias, G, c, b2)
+    assert torch.equal(G, (W * gamma).to(torch.bfloat16)) and relerr(c, G.float().sum(1)) < 1e-6 and relerr(b2, bias + W @ beta) < 1e-5
+    mean, rstd, sf, _ = _ln_stats_torch(x, eps)
+    ln = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, eps)
+    pre = (ln @ W.t() + bias).requires_grad_(True)
+    post = torch.nn.functional.gelu(pre)
+    post.sum().backward()
+    outs = {}
+    for tile in tiles:
+        full = torch.full((M + 256, N), 7.0, device='cuda', dtype=torch.bfloat16)
+        ops.gemm(x, G, M, N, K, bias=b2, ln_stat=sf, ln_c=c, out=full[:M], tile=tile)
+        assert relerr(full[:M], pre.detach()) < 1.5e-2, tile
+        assert float(full[M:].float().min()) == 7.0 and float(full[M:].float().max()) == 7.0, tile
+        full2 = torch.full((M + 256, N), 7.0, device='cuda', dtype=torch.bfloat16)
+        c2 = torch.full((M + 256, N), 7.0, device='cuda', dtype=torch.bfloat16)
+        ops.gemm(x, G, M, N, K, bias=b2, ln_stat=sf, ln_c=c, act=ops.ACT_GELU_ERF, c2=c2[:M], out=full2[:M], tile=tile)
+        assert relerr(full2[:M], post.detach()) < 1.5e-2 and relerr(c2[:M], pre.grad) < 1.5e-2, tile
+        assert float(full2[M:].float().min()) == 7.0 and float(c2[M:].float().max()) == 7.0, tile
+        outs[tile] = (full[:M].clone(), full2[:M].clone(), c2[:M].clone())
+    if 808 in outs and 809 in outs:
+        for a_, b_ in zip(outs[808], outs[809]):
+            assert torch.equal(a_.view(torch.int16), b_.view(torch.int16))
+        for a_, b_ in zip(outs[0], outs[809]):
+            assert torch.equal(a_.view(torch.int16), b_.view(torch.int16))
+    f32 = ops.gemm(x, G, M, N, K, bias=b2, ln_stat=sf, ln_c=c, out_mode=ops.OUT_F32, tile=tiles[-1] if tiles[-1] != 809 else 808)          # the general (fp32 output) path
+    assert relerr(f32, pre.detach()) < 1e-2
+
+
+@pytest.mark.parametrize('M,tiles', [(140 * 1024 + 77, (0, 808, 809)), (197 * 6, (0, 128, 64, 808))])
+def test_layernorm_statistics_from_the_producing_gemm(ops, M, tiles):
+    """A bias + residual GEMM with stat_part emits the rows' partial sums over 32-column slots; avt_ln_stats_finalize turns them into the
+    statistics of the rows it wrote (checked against torch on the bf16 output; the sums are taken before the bf16 rounding) -- also with the
+    row-periodic residual of the patch embedding -- and the output itself is unchanged, bit for bit."""
+    K, N, eps = 256, 768, 1e-6
+    a, b = rnd((M, K), 0.5, 65), rnd((N, K), 0.1, 66)
+    bias = rnd((N,), 1.0, 67, torch.float32)
+    res = (rnd((M, N), 1.0, 68).float() + rnd((M, 1), 2.0, 69).float()).to(torch.bfloat16)
+    for tile in tiles:
+        plain = ops.gemm(a, b, M, N, K, bias=bias, res=res, tile=tile)
+        part = ops.ln_stat_part(M, N, a.device)
+        part.fill_(float('nan'))
+        out = ops.gemm(a, b, M, N, K, bias=bias, res=res, stat_part=part, tile=tile)
+        assert torch.equal(out.view(torch.int16), plain.view(torch.int16)), tile
+        sf, sb = ops.ln_stats_finalize(part, N, eps)
+        mean, rstd, sf_ref, sb_ref = _ln_stats_torch(out, eps)
+        assert relerr(sf[:, 0], rstd) < 2e-3 and float((sf[:, 1] + mean * rstd).abs().max()) < 3e-3, tile
+        assert relerr(sb[:, 1], 1.0 / rstd) < 2e-3 and torch.equal(sb[:, 0], sf[:, 0]), tile
+    period = 197
+    resp = rnd((period, N), 1.0, 70)
+    part = ops.ln_stat_part(M, N, a.device)
+    out = ops.gemm(a, b, M, N, K, res=resp, res_period=period, stat_part=part)
+    sf, _ = ops.ln_stats_finalize(part, N, eps, want_bwd=False)
+    mean, rstd, _, _ = _ln_stats_torch(out, eps)
+    assert relerr(sf[:, 0], rstd) < 2e-3 and float((sf[:, 1] + mean * rstd).abs().max()) < 3e-3
+
+
+@pytest.mark.parametrize('M,tiles', [(140 * 1024 + 77, (0, 808, 809)), (197 * 6, (0, 128, 64, 808))])
+def test_scaled_saved_derivative_epilogue(ops, M, tiles):
+    """The backward half of the fold: (acc * aux) leaves multiplied by the rows' rstd, the column sums are those of the UNscaled product."""
+    K, N = 768, 1024
+    a, b = rnd((M, K), 0.5, 71), rnd((N, K), 0.05, 72)
+    aux = rnd((M, N), 1.0, 73)
+    rstd = torch.rand(M, device='cuda', generator=torch.Generator(device='cuda').manual_seed(83)) * 3 + 0.2
+    sb = torch.stack([rstd, 1.0 / rstd], 1).contiguous()
+    un = (a.float() @ b.float().t()) * aux.float()
+    got = {}
+    for tile in tiles:
+        cs = torch.zeros(N, device='cuda')
+        out = ops.gemm(a, b, M, N, K, act=ops.ACT_MUL_AUX, aux=aux, colsum=cs, ln_stat=sb, tile=tile)
+        assert relerr(out, un * rstd[:, None]) < 1e-2, tile
+        assert relerr(cs, un.double().sum(0).float()) < 5e-3, tile          # (sums of the bf16-rounded outputs, as in the unscaled epilogue)
+        got[tile] = (out, cs)
+    if 808 in got and 809 in got:
+        assert torch.equal(got[808][0].view(torch.int16), got[809][0].view(torch.int16)) and torch.equal(got[0][0].view(torch.int16), got[809][0].view(torch.int16))
+
+
+@pytest.mark.parametrize('rows,D', [(197 * 4, 768), (333, 1024), (70, 256), (90, 128), (50, 320)])
+def test_layernorm_fold_backward_kernels(ops, rows, D):
+    """avt_layernorm_bwd_folded and avt_ln_fold_wgrad against autograd through LayerNorm -> Linear in fp64: with dY' = rstd o dY,
+    d xhat' = dY' G and T = dY'^T x the two kernels give dx (+ dres, column sums), dW, dgamma, dbeta, dbias."""
+    N, eps = 512, 1e-6
+    x = (rnd((rows, D), 1.5, 74).float() + rnd((rows, 1), 2.0, 75).float()).to(torch.bfloat16)
+    W = rnd((N, D), 0.05, 76, torch.float32)
+    gamma, beta, bias = torch.rand(D, device='cuda') + 0.5, rnd((D,), 0.3, 77, torch.float32), rnd((N,), 0.3, 78, torch.float32)
+    dY = rnd((rows, N), 1.0, 79)
+    dres = rnd((rows, D), 1.0, 80)
+    xd, Wd, gd, bd, biasd = (t.double().requires_grad_(True) for t in (x, W, gamma, beta, bias))
+    y = torch.nn.functional.linear(torch.nn.functional.layer_norm(xd, (D,), gd, bd, eps), Wd, biasd)
+    y.backward(dY.double())
+    mean, rstd, sf, sb = _ln_stats_torch(x, eps)
+    dYp = (dY.float() * rstd[:, None]).to(torch.bfloat16)                       # what the scaling epilogues hand on
+    G = (W * gamma).to(torch.bfloat16)
+    dxh = (dYp.float() @ G.float()).to(torch.bfloat16)
+    cs = torch.zeros(D, device='cuda')
+    dx = ops.layernorm_bwd_folded(dxh, x, sf, dres=dres, colsum=cs)
+    assert relerr(dx, xd.grad.float() + dres.float()) < 2e-2
+    assert relerr(cs, dx.float().sum(0)) < 1e-3
+    T = (dYp.float().t() @ x.float()).contiguous()
+    dbt = dY.float().sum(0).contiguous()
+    dW, dg, db, dbias = (torch.full_like(t, 0.25) for t in (W, gamma, beta, bias))
+    ops.ln_fold_wgrad(T, W, gamma, beta, dbt, dW, dg, db, dbias)
+    assert float(T.abs().max()) == 0.0 and float(dbt.abs().max()) == 0.0          # scratch handed back zeroed
+    assert relerr(dW - 0.25, Wd.grad.float()) < 1e-2 and relerr(dg - 0.25, gd.grad.float()) < 1e-2
+    assert relerr(db - 0.25, bd.grad.float()) < 1e-2 and relerr(dbias - 0.25, biasd.grad.float()) < 1e-2
+    # bit-reproducible (fixed-order partials)
+    T2 = (dYp.float().t() @ x.float()).contiguous(); dbt2 = dY.float().sum(0).contiguous()
+    dW2, dg2, db2, dbias2 = (torch.full_like(t, 0.25) for t in (W, gamma, beta, bias))
+    ops.ln_fold_wgrad(T2, W, gamma, beta, dbt2, dW2, dg2, db2, dbias2)
+    assert torch.equal(dW, dW2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize('frames,S,H', [(3, 197, 12), (2, 50, 3), (2, 100, 2)])
+def test_vit_attention_backward_scaled_rows(ops, frames, S, H):
+    """avt_vit_attn_bwd_scaled: dqkv rows multiplied by row_stat[:, 0]; the bias gradient stays that of the unscaled dqkv."""
+    D = H * 64
+    qkv = rnd((frames * S, 3 * D), 0.7, 81)
+    out, lse = ops.vit_attn_fwd(qkv, frames, S, H)
+    dout = rnd((frames * S, D), 1.0, 82)
+    db0, db1 = torch.zeros(3 * D, device='cuda'), torch.zeros(3 * D, device='cuda')
+    d0 = ops.vit_attn_bwd(qkv, out, dout, lse, frames, S, H, dbias=db0)
+    rstd = torch.rand(frames * S, device='cuda') * 3 + 0.2
+    sb = torch.stack([rstd, 1.0 / rstd], 1).contiguous()
+    d1 = ops.vit_attn_bwd(qkv, out, dout, lse, frames, S, H, dbias=db1, row_stat=sb)
+    assert torch.equal(db0, db1)
+    # the product is rounded once from fp32 in the scaled kernel, d0 is already rounded: one bf16 ulp of slack on top of the scale
+    ref = d0.float() * rstd[:, None]
+    assert float(((d1.float() - ref).abs() / (ref.abs() + 1e-3)).max()) < 1.2e-2
+
+
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('rows,D,eps', [(197 * 4, 768, 1e-6), (160, 2048, 1e-5), (33, 64, 1e-6), (100, 1024, 1e-6)])
 def test_layernorm(ops, rows, D, eps):
