@@ -60,12 +60,13 @@ def flops_skipped_per_clip(D, T, S=197):
 def algorithmic_bytes_per_step(D, L, T, B, Dh=2048, Lh=6, S=197):
     """HBM bytes per step per GPU of the implemented dataflow if every tensor crossed HBM exactly as often as the kernel
     sequence consumes / produces it (DESIGN.md section 4 lists the per-kernel terms).  Unit u = one [tokens, D] bf16 tensor.
-    A full ViT block moves 30 u forward (LN1 2, qkv 4, attention 4, proj 3, LN2 2, fc1 9, fc2 6) and 52 u backward (fc2
-    w/dgrad 14, fc1 w/dgrad 10, LN2 4, proj w/dgrad 4, attention 8, qkv w/dgrad 8, LN1 4); the CLS-only last block 20 u;
+    A full ViT block moves 26 u forward (qkv 4, attention 4, proj 3, fc1 9, fc2 6 -- since round 5 the two LayerNorms are folded into qkv /
+    fc1 and write nothing: 30 u before) and 52 u backward (fc2 w/dgrad 14, fc1 w/dgrad 10, LN2 4, proj w/dgrad 4, attention 8, qkv w/dgrad 8,
+    LN1 4); the CLS-only last block 20 u;
     patch embedding: fp32 frames once + 6 u; parameters: 38 B each (bf16 shadow read by forward and dgrad, fp32 gradient
     read-modify-write, 26 B in the fused SGD); the temporal head's activations with u_h = [B*T, Dh] bf16."""
     u = B * T * S * D * 2
-    vit = ((L - 1) * 82 + 20 + 6) * u + B * T * 3 * 224 * 224 * 4
+    vit = ((L - 1) * 78 + 20 + 6) * u + B * T * 3 * 224 * 224 * 4
     n_vit = 768 * D + D + S * D + D + L * (12 * D * D + 13 * D) + 2 * D
     n_head = 2 * D * Dh + 1024 * Dh + Lh * (12 * Dh * Dh + 13 * Dh) + 2 * Dh
     n_cls = (D + 1) * NUM_CLASSES
