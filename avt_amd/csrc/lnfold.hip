@@ -159,6 +159,9 @@ __global__ __launch_bounds__(256) void ln_bwd_folded_kernel(const bf16_t* __rest
   }
 }
 
+// (Round 5, measured and removed: two rows per wave for D = 768, as ln_fwd2_kernel does -- 148 registers, three waves per SIMD: 569 us against this
+// kernel's 558 us at 504320 x 768 (5.45 vs 5.55 TB/s), the step 951 vs 953 clips/s; profiles/r05h_ln_bwd_and_attention_scaling.txt.)
+
 // ---- weight-side backward of the fold.  T [N][K] fp32 = dY'^T x (accumulated by avt_gemm_accum_bf16 into a zeroed scratch), dbt [N] = this
 // backward's colsum(dY) (unscaled).  Per row n: dG = T[n,:] - mean_k(T[n,:]);  dW[n,:] += gamma o dG + dbt[n] beta;  dbias[n] += dbt[n];
 // per column: dgamma[k] += sum_n W[n,k] dG[n,k], dbeta[k] += sum_n W[n,k] dbt[n] (per-workgroup partial vectors, merged in fixed order).
