@@ -47,8 +47,13 @@ constexpr int PK_HALF = 128 * 64 * 2;                      // one half-tile slot
 // Longer reductions stay with gemm_8p_kernel unless the caller forces tile 809: what the persistent form removes is per-TILE time (fill,
 // store drain, workgroup turn-over: 12-20 % of a K = 768 tile, 2-4 % of a K = 3072 tile), and the step runs at the board's power limit --
 // at K >= 2304 the busier matrix pipe costs as much clock as the removed idle time is worth (measured, 256 clips, same box:
-// 907.4 clips/s without, 920.1 with every shape persistent, 924.1 with K <= 1024 only; profiles/r04_persistent_gemm.txt)
-constexpr int PK_KMAX = 1024;
+// 907.4 clips/s without, 920.1 with every shape persistent, 924.1 with K <= 1024 only; profiles/r04_persistent_gemm.txt).
+// Round 5, after the epilogue stores lost their waterfall loops: every shape persistent 963.5 / 962.5 against 960.2 / 958.6 clips/s with K <= 1024 only
+// (same box, profiles/r05j_persistent_all_k.txt): the limit now covers every reduction of ViT-B / ViT-L (K <= 4096).
+#ifndef AVT_PK_KMAX
+#define AVT_PK_KMAX 4096
+#endif
+constexpr int PK_KMAX = AVT_PK_KMAX;
 
 // swizzled wave-private patch [32 rows][128 B]: the 8-byte position q8 (0..15) of row r lives at position q8 ^ (r & 15).
 // Writes (accumulator layout: lane = row, 8 B per (j, q)): the 32 lanes of a half-wave hit 16 positions x 2 rows each = every

@@ -21,7 +21,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-PERSIST_KMAX = 1024      # mirrors PK_KMAX in csrc/gemm_persist.hip
+PERSIST_KMAX = 4096      # mirrors PK_KMAX in csrc/gemm_persist.hip
 
 
 # Every kernel-template prefix the router below can return for an output tile of 128 rows or more: what bench.py's GEMM-family /

@@ -407,7 +407,9 @@ def main(argv=None):
     if world == 1 and not args.no_also and (args.model, args.frames) == ('vit_base_patch16_224', 10):
         also = []
         for label, kw in (('config 4: ViT-B/16 + AVT-h, T = 15', dict(frames=15, batch=max(1, args.batch // 2))),
-                          ('config 5: ViT-L/16 + AVT-h, T = 10', dict(model='vit_large_patch16_224', batch=max(1, args.batch * 3 // 8)))):
+                          ('config 5: ViT-L/16 + AVT-h, T = 10', dict(model='vit_large_patch16_224', batch=max(1, args.batch * 3 // 8))),
+                          # SURVEY 8d's batch list for config 2 ends at 64 clips per GPU (the reference's own runs use 3): the same model at a quarter of the headline's clips
+                          ('config 2 at a quarter of the clips: ViT-B/16 + AVT-h, T = 10', dict(batch=max(1, args.batch // 4)))):
             a2 = argparse.Namespace(**{**vars(args), **kw})
             try:
                 m2 = measure(a2, 5, 2)

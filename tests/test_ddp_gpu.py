@@ -222,7 +222,7 @@ def test_bench_single_gpu_line_carries_configs_4_and_5():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 1 and d['config']['clips_per_gpu'] == 8 and d['value'] > 0
     also = d['also']
-    assert [a['frames'] for a in also] == [15, 10] and [a['model'] for a in also] == ['vit_base_patch16_224', 'vit_large_patch16_224']
-    assert [a['clips_per_gpu'] for a in also] == [4, 3] and all(a['value'] > 0 and 0 < a['executed_frac'] < a['frac'] for a in also)
+    assert [a['frames'] for a in also] == [15, 10, 10] and [a['model'] for a in also] == ['vit_base_patch16_224', 'vit_large_patch16_224', 'vit_base_patch16_224']
+    assert [a['clips_per_gpu'] for a in also] == [4, 3, 2] and all(a['value'] > 0 and 0 < a['executed_frac'] < a['frac'] for a in also)
     w = d['roofline']['worst_large_gemm_row']
     assert w['tflops'] > 0 and len(w['MNK']) == 3 and w['share_of_step_time'] >= 0.02

@@ -373,13 +373,14 @@ def test_gpu_clip_transform_draws_follow_the_reference_rules():
 
 def test_gemm_variant_names_mirror_the_library_routing():
     """ops.gemm_variant names the kernel a GEMM lands on (the bench's per-kernel rows): the persistent 8-phase kernel for the big k-major
-    contractions with K <= 1024 and a covered epilogue (csrc/gemm_persist.hip: avt_gemm_persist), gemm_8p_kernel for longer reductions,
+    contractions with K <= 4096 and a covered epilogue (csrc/gemm_persist.hip: avt_gemm_persist), gemm_8p_kernel for longer reductions,
     uncovered epilogues and other layouts."""
     from avt_amd import ops
     M = 2560 * 197
     assert ops.gemm_variant(M, 2304, 768, True, True, ops.OUT_BF16, 0, True) == 'gemm_8pp_kernel'            # qkv forward
     assert ops.gemm_variant(M, 3072, 768, True, True, ops.OUT_BF16, 0, True) == 'gemm_8pp_kernel'            # fc1 forward / fc2 data gradient
-    assert ops.gemm_variant(M, 768, 3072, True, True, ops.OUT_BF16, 0, True).startswith('gemm_8p_kernel')    # K > 1024
+    assert ops.gemm_variant(M, 768, 3072, True, True, ops.OUT_BF16, 0, True) == 'gemm_8pp_kernel'            # fc2 forward (round 5: every K <= 4096)
+    assert ops.gemm_variant(M, 768, 8192, True, True, ops.OUT_BF16, 0, True).startswith('gemm_8p_kernel')    # K > 4096
     assert ops.gemm_variant(M, 768, 768, True, True, ops.OUT_BF16, 0, False).startswith('gemm_8p_kernel')    # epilogue not covered
     assert ops.gemm_variant(M, 768, 768, True, False, ops.OUT_BF16, 0, True).startswith('gemm_8p_kernel')    # B not k-major
     assert ops.gemm_variant(M, 776, 768, True, True, ops.OUT_BF16, 0, True).startswith('gemm_8p_kernel')     # N % 256 != 0

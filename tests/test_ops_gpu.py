@@ -248,7 +248,7 @@ def test_big_tile_gemm_and_attention_bit_reproducible(ops):
 
 @pytest.mark.parametrize('M', [140 * 1024, 137900])          # 560 full row tiles; 538.67 (a partial last row tile, rows past M must stay untouched)
 def test_persistent_gemm_bit_equal_to_one_tile_per_workgroup(ops, M):
-    """gemm_persist.hip (tile 809; the automatic choice for K <= 1024) against gemm_8p_kernel (tile 808) on the four epilogues it covers:
+    """gemm_persist.hip (tile 809; the automatic choice for K <= 4096) against gemm_8p_kernel (tile 808) on the four epilogues it covers:
     same bits in every output (incl. the GELU' second output and the column sums), nothing written past row M, and a repeated call
     gives the same bits (its tile tickets are drawn dynamically: the order of tiles differs from call to call)."""
     K = 768
