@@ -894,6 +894,16 @@ __global__ __launch_bounds__(256, 2) void gemm_4w_kernel(GemmParams p) {
 // (profiles/r03_issue_rules.txt), no second wave is needed to keep the pipe fed as long as the K loop holds no vector-ALU work:
 // fragment addresses and DMA offsets are per-lane constants, the K advance lives in the scalar buffer descriptor.
 // Ring: 5 stages of [32 k][256 + 256] bf16 = 160 KB (the whole LDS; this epilogue needs none), 4 stages in flight.
+// fragment F of a k-step (0: A0, 1..4: B0..B3, 5..7: A1..A3): its per-lane LDS address and its place in the register arrays, selected at
+// compile time (the macro form with ?: indexed the arrays out of bounds in its dead branches: 700 -Warray-bounds warnings per build)
+template <int F>
+__device__ __forceinline__ uint32_t w4_frag_addr(const uint32_t (&a)[4], const uint32_t (&b)[4]) {
+  if constexpr (F == 0) return a[0]; else if constexpr (F <= 4) return b[F - 1]; else return a[F - 4];
+}
+template <int F>
+__device__ __forceinline__ void w4_frag_put(bf16x8_t (&af)[4], bf16x8_t (&bf)[4], bf16x8_t v) {
+  if constexpr (F == 0) af[0] = v; else if constexpr (F <= 4) bf[F - 1] = v; else af[F - 4] = v;
+}
 // cache policy of the two operand streams (aux of buffer_load ... lds: 0 = default, 2 = nt, 16 = sc1); A/B switches, see profiles/r05e_w4_cache_policy.txt
 #ifndef AVT_W4_LDA_AUX
 #define AVT_W4_LDA_AUX 0
@@ -1004,10 +1014,9 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
 #define W4_RDF(NB, SLOT, KS, F)                                                                                       \
   do {                                                                                                                \
     constexpr int imm_ = ((SLOT) & 1) * STAGE + (KS) * 16 * ROWB;                                                     \
-    const uint32_t a_ = ((F) == 0) ? adA[(SLOT) >> 1][0] : ((F) <= 4 ? adB[(SLOT) >> 1][(F) - 1] : adA[(SLOT) >> 1][(F) - 4]);  \
+    const uint32_t a_ = w4_frag_addr<(F)>(adA[(SLOT) >> 1], adB[(SLOT) >> 1]);                                        \
     const u32x2_t lo_ = ds_read_tr_na<imm_>(a_), hi_ = ds_read_tr_na<imm_ + 4 * ROWB>(a_);   /* inline asm: no compiler-placed vmcnt(0) */ \
-    const bf16x8_t v_ = tr_join(lo_, hi_);                                                                            \
-    if ((F) == 0) af[NB][0] = v_; else if ((F) <= 4) bfr[NB][(F) - 1] = v_; else af[NB][(F) - 4] = v_;                \
+    w4_frag_put<(F)>(af[NB], bfr[NB], tr_join(lo_, hi_));                                                             \
   } while (0)
   // 16 MFMAs of buffer CB; between them the 8 fragments of (SLOT, KS) into buffer NB and the DMA instructions Q0..Q0+3 of stage ST
 #define W4_STEP(CB, NB, SLOT, KS, Q0, ST, READ)                                                                       \

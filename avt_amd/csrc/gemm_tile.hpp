@@ -706,7 +706,8 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
   float cs[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) cs[k] = 0.f;
-#pragma unroll (ACT == 0 || ACT == 3 ? 4 : 1)
+  constexpr int UNR = (ACT == 0 || ACT == 3) ? 4 : 1;
+#pragma unroll UNR
   for (int i = 0; i < TM; ++i) {
     EpiBlk<TN> b;
     f32x2_t rs = {1.f, 0.f};

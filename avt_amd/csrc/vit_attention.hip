@@ -717,9 +717,12 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
   if (dbias) for (int i = tid; i < H * 192; i += nthr) bias_s[i] = 0.f;
   // key rows past the last wave's strip exist in the dS buffers (the dQ products walk whole 32-key pairs) but are never written: zero
   // them once -- they meet all-zero K rows, and 0 x (whatever bits the LDS held) must not be a NaN
-  for (int i = tid; i < 2 * (KP - NKT * 16) * (DSP / 4); i += nthr) {
-    const int b = i / ((KP - NKT * 16) * (DSP / 4)), r = i % ((KP - NKT * 16) * (DSP / 4));
-    ((uint32_t*)(dSb + b * DSB + NKT * 16 * DSP))[r] = 0u;
+  constexpr int PADW = (KP - NKT * 16) * (DSP / 4);          // 32-bit words of padding rows per buffer (none when the strips fill the pairs)
+  if constexpr (PADW > 0) {
+    for (int i = tid; i < 2 * PADW; i += nthr) {
+      const int b = i / PADW, r = i % PADW;
+      ((uint32_t*)(dSb + b * DSB + NKT * 16 * DSP))[r] = 0u;
+    }
   }
 
   uint32_t tr0[4], trK[4];                   // per-lane addresses of the transposing reads: Q / dO tiles, K tile
