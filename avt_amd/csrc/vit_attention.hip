@@ -24,6 +24,9 @@
 #ifndef AVT_ATTN_WIDE_ST
 #define AVT_ATTN_WIDE_ST 1
 #endif
+#ifndef AVT_ATTN_ROWS_EARLY
+#define AVT_ATTN_ROWS_EARLY 0      // 1: measured 20-25 spilled registers (the requests at the top of the last chunk)
+#endif
 #include "../../include/avt_hip.h"
 
 namespace {
@@ -199,6 +202,39 @@ __device__ __forceinline__ void lsum16x4(f32x4_t& v) {
   v = (f32x4_t){a, b, c, d};
 }
 
+// A wave's own strips of the NEXT item are requested by hand-written loads: the compiler does not track them, so no s_waitcnt of its own appears
+// between the requests and the counted wait at the top of the next item.  With compiler-tracked loads (until late round 5) hipcc put
+//   * backward: `s_waitcnt vmcnt(0)` right behind the lse load -- its `* log2(e)` was the first use of a loaded value -- so every wave sat out the full
+//     memory latency in the tail of every item, before its dK / dV stores (tools/lab/attn_timeline.py: 9-13 k of an item's 44 k cycles); with the
+//     multiplication moved away the wait reappeared in front of the first use at the loop top, now also covering the four stores just issued;
+//   * forward: `s_waitcnt vmcnt(0)` on the loop's back edge (the Q strip is copied there), i.e. behind the output stores of every item, and one more in
+//     front of the barrier (__syncthreads() = release fence).
+// Rows past the sequence get an out-of-range offset and arrive as zeros (STRIP_OOB: beyond num_records, and + 64 of the instruction offset
+// does not wrap around 32 bits as it would with the 0xFFFFFFF0 of the LDS-DMA requests).
+constexpr uint32_t STRIP_OOB = 0x80000000u;
+__device__ __forceinline__ u32x4_t raw_rsrc(const void* p) {
+  const uint64_t a = (uint64_t)p;
+  u32x4_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+  r[2] = 0x7FFFFFF0u; r[3] = 0x00020000u;
+  return r;
+}
+template <int IMM>
+__device__ __forceinline__ bf16x8_t strip_ld_na(u32x4_t rsrc, uint32_t voff, uint32_t soff) {
+  bf16x8_t v;
+  // s_nop 4: the hazard recogniser does not look into inline assembly, and a scalar operand may have just been written by a vector instruction
+  // (v_readlane of a spilled SGPR, v_readfirstlane): 5 wait states before a memory instruction reads it.  Measured the hard way: without them the
+  // V strip's scalar offset was occasionally stale and test_big_tile_gemm_and_attention_bit_reproducible failed.
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff), "n"(IMM));
+  return v;
+}
+__device__ __forceinline__ float dword_ld_na(const float* base, uint32_t voff) {
+  float v;
+  asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(base));
+  return v;
+}
+
 // Forward: persistent workgroups walking over (frame, head) items with the K / V tiles double-buffered in LDS: the tiles of
 // item n+1 are requested (LDS-DMA) when item n starts computing, and this wave's Q strip of item n+1 right after, so the
 // only exposed global latency is the very first item's.
@@ -214,14 +250,24 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const int q0 = wave * 16, g = lane >> 4;
   int item = blockIdx.x;
-  bf16x8_t nq[2];
+  // ONE register set for the Q strip: the next item's strip is requested into it as soon as this item's score products have read it, and nothing but
+  // the counted wait at the loop top touches it in between (a second set would be copied into the first by the compiler -- in front of the wait)
+  bf16x8_t bq[2];
+  auto fetch_q = [&](const bf16_t* hb) __attribute__((always_inline)) {      // this wave's Q strip (B-operand layout) of the head slice at hb
+    int lane_f = lane;                         // (opaque: the per-lane offset is recomputed here, not kept across the item)
+    asm volatile("" : "+v"(lane_f));
+    const int qf = q0 + (lane_f & 15);
+    const uint32_t o = qf < S ? (uint32_t)((qf * ld + (lane_f >> 4) * 8) * 2) : STRIP_OOB;
+    const u32x4_t r = raw_rsrc(hb);
+    bq[0] = strip_ld_na<0>(r, o, 0u); bq[1] = strip_ld_na<64>(r, o, 0u);
+  };
   uint32_t troff[4];
   tr_lane_offsets(lane, troff);
   if (item < items) {
     const bf16_t* base = qkv + (size_t)(item / H) * S * ld + (item % H) * HD;
     stage_head_dma(base + D, ld, S, smem, KP, wv, NKT, lane);
     stage_head_dma(base + 2 * D, ld, S, smem + RM, KP, wv, NKT, lane);
-    load_strip(base, ld, S, q0, lane, nq);
+    fetch_q(base);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   int buf = 0;
@@ -229,23 +275,24 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
     const int frame = item / H, head = item % H;
     const char* Kb = smem + buf * 2 * RM;
     const char* Vb = Kb + RM;
-    // K, V of this item were requested one item ago; younger than them are only the 2 Q-strip loads and the 5 stores of the
+    // K, V of this item were requested one item ago; younger than them are only the 2 Q-strip loads and the 3 (5) stores of the
     // previous item (nothing at the first item)
     // (ALL_LIVE: every wave's strip has at least one row inside the sequence, so every guarded load / store is issued; else
     // a wave may have skipped them and the count would be wrong -> wait for everything)
     // (wide stores: 2 + 3)
-    if (ALL_LIVE) { if (AVT_ATTN_WIDE_ST) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                          // also: everyone is done with the other buffer (item n-1)
-    bf16x8_t bq[2];
-    bq[0] = nq[0]; bq[1] = nq[1];
+    // (late round 5: the Q strip, requested right behind the tiles, is waited for here too -- all but the previous item's 3 / 5 stores -- and the
+    // barrier is a bare s_barrier: __syncthreads() brought a full `s_waitcnt vmcnt(0)` with it, i.e. the completion of those stores)
+#define AVT_Q_LANDED(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bq[0]), "+v"(bq[1]) :: "memory")
+    if (ALL_LIVE) { if (AVT_ATTN_WIDE_ST) AVT_Q_LANDED(3); else AVT_Q_LANDED(5); }
+    else AVT_Q_LANDED(0);
+#undef AVT_Q_LANDED
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // also: everyone is done with the other buffer (item n-1)
+    const int nitem = item + gridDim.x < items ? item + gridDim.x : item;     // the last item re-requests itself (keeps the counts)
+    const bf16_t* nbase = qkv + (size_t)(nitem / H) * S * ld + (nitem % H) * HD;
     {
-      const int nitem = item + gridDim.x < items ? item + gridDim.x : item;     // the last item re-requests itself (keeps the counts)
-      const bf16_t* nbase = qkv + (size_t)(nitem / H) * S * ld + (nitem % H) * HD;
       char* nb = smem + (buf ^ 1) * 2 * RM;
       stage_head_dma(nbase + D, ld, S, nb, KP, wv, NKT, lane);
       stage_head_dma(nbase + 2 * D, ld, S, nb + RM, KP, wv, NKT, lane);
-      load_strip(nbase, ld, S, q0, lane, nq);
     }
     f32x4_t st[2 * NP];
   #pragma unroll
@@ -264,6 +311,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
       }
       st[kt] = a;
     }
+    // (the score products above were the last readers of the Q strip; the 11 wait states between an MFMA's operand read and a memory write
+    // to the same registers are far exceeded by the request's latency)
+    fetch_q(nbase);
     mx = gmax(mx);
     const float sl = scale * LOG2E;
     const float mxs = mx * sl;
@@ -684,6 +734,17 @@ __device__ __forceinline__ void dma_rows8(__amdgpu_buffer_rsrc_t rsrc, int ld, i
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(rm + j * 1024), 16, off, 0, 0, AVT_ATTN_LD_AUX);
 }
 
+#ifdef AVT_LAB
+// lab only (tools/lab/attn_timeline.py): cycle stamps of ONE item per workgroup at the points where the wave's LDS counter is zero anyway
+// (before / after every barrier, after a dQ product), parked in LDS (32 words per wave behind the kernel's own arrays) and written out at the end
+__device__ unsigned long long g_bwd1_stamps = 0;
+#ifndef AVT_BWD1_STAMP_MASK      // which of the 24 stamps are compiled in (each costs registers: all of them at once spill in the item's tail)
+#define AVT_BWD1_STAMP_MASK 0xF0000Fu
+#endif
+#define AVT_BWD1_STAMP(i) do { if ((AVT_BWD1_STAMP_MASK >> (i)) & 1u) if (rec) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ((uint32_t*)(rs_s + KP))[wv * 32 + (i)] = (uint32_t)t_; } } while (0)
+#else
+#define AVT_BWD1_STAMP(i) do { } while (0)
+#endif
 template <int NKT, bool ALL_LIVE, bool SCALED>
 __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -733,28 +794,49 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
   const uint32_t dsrd = lds_addr32(dSb) + (uint32_t)((4 * g + (i16 >> 2)) * DSP + (i16 & 3) * 8);  // this lane's address in a transposing read of the buffer
   const int k0 = wave * 16, key = k0 + i16;  // own key strip; the same rows as a QUERY tile for the per-query scalars
 
-  // own strips of the NEXT item (B-operand layout, straight from global): K, V of this wave's keys; dO, O of the same rows as queries
-  bf16x8_t nk[2], nv[2], ndo[2], no[2];
+  // own strips (B-operand layout, straight from global): K, V of this wave's keys; dO, O of the same rows as queries.  ONE register set each: the next
+  // item's K / V strips are requested into bk / bv as soon as the last chunk's score products have read them, dO / O / the per-row scalars after the
+  // last chunk's barrier; nothing but the counted wait at the loop top touches them in between (a second set would be copied into the first by the
+  // compiler -- possibly in front of the wait)
+  bf16x8_t bk[2], bv[2], ndo[2], no[2];
   float nlq = 0.f, nrs = 1.f;
-  auto fetch_strips = [&](int it) __attribute__((always_inline)) {
+  auto fetch_kv = [&](int it) __attribute__((always_inline)) {
+    const size_t r0 = (size_t)(it / H) * S;
+    int lane_f = lane;                         // (opaque: the strips' per-lane offsets are recomputed here, not kept across the item)
+    asm volatile("" : "+v"(lane_f));
+    const int key_f = k0 + (lane_f & 15);
+    const uint32_t oq = key_f < S ? (uint32_t)((key_f * ld + (lane_f >> 4) * 8) * 2) : STRIP_OOB;      // row of qkv (the k / v parts through the scalar offset)
+    const u32x4_t rq = raw_rsrc(qkv + r0 * ld + (it % H) * HD);
+    const uint32_t sk = (uint32_t)(D * 2), sv = (uint32_t)(D * 4);
+    bk[0] = strip_ld_na<0>(rq, oq, sk);  bk[1] = strip_ld_na<64>(rq, oq, sk);
+    bv[0] = strip_ld_na<0>(rq, oq, sv);  bv[1] = strip_ld_na<64>(rq, oq, sv);
+  };
+  auto fetch_rows = [&](int it) __attribute__((always_inline)) {
     const int fr = it / H, hd = it % H;
     const size_t r0 = (size_t)fr * S;
-    int lane_f = lane;                         // (opaque: the strips' per-lane global offsets are recomputed here, not kept across the item)
+    int lane_f = lane;
     asm volatile("" : "+v"(lane_f));
-    load_strip(qkv + r0 * ld + D + hd * HD, ld, S, k0, lane_f, nk);
-    load_strip(qkv + r0 * ld + 2 * D + hd * HD, ld, S, k0, lane_f, nv);
-    load_strip(dout + r0 * D + hd * HD, D, S, k0, lane_f, ndo);
-    load_strip(out + r0 * D + hd * HD, D, S, k0, lane_f, no);
     const int key_f = k0 + (lane_f & 15);
-    nlq = (key_f < S) ? lse[((size_t)fr * H + hd) * S + key_f] * LOG2E : 0.f;
-    if (SCALED) nrs = (key_f < S) ? row_scale[2 * (r0 + key_f)] : 0.f;
+    const bool in = key_f < S;
+    const uint32_t od = in ? (uint32_t)((key_f * D + (lane_f >> 4) * 8) * 2) : STRIP_OOB;       // row of dout / out
+    const u32x4_t rd = raw_rsrc(dout + r0 * D + hd * HD), ro = raw_rsrc(out + r0 * D + hd * HD);
+    ndo[0] = strip_ld_na<0>(rd, od, 0u); ndo[1] = strip_ld_na<64>(rd, od, 0u);
+    no[0] = strip_ld_na<0>(ro, od, 0u);  no[1] = strip_ld_na<64>(ro, od, 0u);
+    // per-row scalars of rows past the sequence: the last row's (finite; they only ever meet zeros -- D[q] of such a row is 0 through the zero strips)
+    const int kc = in ? key_f : S - 1;
+    nlq = dword_ld_na(lse + ((size_t)fr * H + hd) * S, (uint32_t)(kc * 4));              // raw: `* log2(e)` where it is stored to LDS
+    if (SCALED) nrs = dword_ld_na(row_scale + 2 * r0, (uint32_t)(kc * 8));
   };
+#ifdef AVT_LAB
+  if (lane < 32) ((uint32_t*)(rs_s + KP))[wave * 32 + lane] = 0u;
+#endif
   int item = blockIdx.x;
   if (item < items) {
     const size_t r0 = (size_t)(item / H) * S;
     stage_head_dma(qkv + r0 * ld + (item % H) * HD, ld, S, Qs, KP, wv, NKT, lane);
     stage_head_dma(dout + r0 * D + (item % H) * HD, D, S, dOs, KP, wv, NKT, lane);
-    fetch_strips(item);
+    fetch_kv(item);
+    fetch_rows(item);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   for (; item < items; item += gridDim.x) {
@@ -764,16 +846,19 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     const bool has_next = item + gridDim.x < items;
     const int nitem = has_next ? item + gridDim.x : item;
     const size_t nr0 = (size_t)(nitem / H) * S;
+#ifdef AVT_LAB
+    const bool rec = g_bwd1_stamps != 0 && item == (int)blockIdx.x + 3 * (int)gridDim.x;
+#endif
     __amdgpu_buffer_rsrc_t nrq = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + nr0 * ld + (nitem % H) * HD), 0, 0x7FFFFFF0u, 0x00020000);
     __amdgpu_buffer_rsrc_t nrdo = __builtin_amdgcn_make_buffer_rsrc((void*)(dout + nr0 * D + (nitem % H) * HD), 0, 0x7FFFFFF0u, 0x00020000);
 
     // own strips have landed once everything but the youngest 8 vector-memory operations (the previous item's dK / dV stores) is done;
     // older than the strips are the prefetched Q / dO rows of this item and the dQ stores of the previous one
     // (wide stores: 4)
-    if (ALL_LIVE) { if (AVT_ATTN_WIDE_ST) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bf16x8_t bk[2], bv[2];
-    bk[0] = nk[0]; bk[1] = nk[1]; bv[0] = nv[0]; bv[1] = nv[1];
+#define AVT_STRIPS_LANDED(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(ndo[0]), "+v"(ndo[1]), "+v"(no[0]), "+v"(no[1]), "+v"(nlq), "+v"(nrs) :: "memory")
+    if (ALL_LIVE) { if (AVT_ATTN_WIDE_ST) AVT_STRIPS_LANDED(4); else AVT_STRIPS_LANDED(8); }
+    else AVT_STRIPS_LANDED(0);
+#undef AVT_STRIPS_LANDED
     {
       float dsum = 0.f;
 #pragma unroll
@@ -783,13 +868,20 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       dsum = gsum(dsum) * scale;
       int lane_s = lane;                        // (opaque: these LDS addresses are used once per item)
       asm volatile("" : "+v"(lane_s));
-      if (lane_s < 16) { dq_s[k0 + lane_s] = dsum; lse_s[k0 + lane_s] = nlq; if (SCALED) rs_s[k0 + lane_s] = nrs; }         // k0 + 15 < NKT * 16 <= KP; rows past the sequence: 0 / 0
+      if (lane_s < 16) { dq_s[k0 + lane_s] = dsum; lse_s[k0 + lane_s] = nlq * LOG2E; if (SCALED) rs_s[k0 + lane_s] = nrs; }         // k0 + 15 < NKT * 16 <= KP; rows past the sequence: 0 / 0
       if (NKT * 16 < KP && wv == 0 && lane_s < KP - NKT * 16) { dq_s[NKT * 16 + lane_s] = 0.f; lse_s[NKT * 16 + lane_s] = 0.f; }
     }
+#ifdef AVT_LAB
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    AVT_BWD1_STAMP(0);
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // barrier S: scalars visible; every wave is done with the previous item
+    AVT_BWD1_STAMP(1);
     if (dbias && prev_head >= 0) {            // the previous item's sums, folded in tile order by the column's owner thread
       float* bh = bias_s + prev_head * 192;
-      for (int c = tid; c < 64; c += nthr) {
+      int tid_b = tid;                        // (opaque: the addresses below are formed here, not kept -- spilled -- across the item)
+      asm volatile("" : "+v"(tid_b));
+      for (int c = tid_b; c < 64; c += nthr) {
         float t = bh[c];
 #pragma unroll
         for (int w = 0; w < NKT; ++w) t += stq_s[w * 64 + c];
@@ -809,6 +901,11 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 
     static_for<0, NP>([&](auto c_) __attribute__((always_inline)) {
       constexpr int c = decltype(c_)::value;
+#if AVT_ATTN_ROWS_EARLY
+      // next item's dO / O strips and per-row scalars: requested at the top of the last chunk (one query tile only: the chunk with the fewest live
+      // registers), a whole chunk + the tail ahead of their use.  Unconditional (re-fetches this item at the end): keeps the counted wait at the loop top exact
+      if constexpr (c == NP - 1) fetch_rows(nitem);
+#endif
       // software pipeline: the transposing reads of the dO tile (for dV) are requested first and land under the score / softmax work;
       // those of the Q tile (for dK) are requested before the dV products and land under them
       bf16x8_t tfo[4], tfq[4];
@@ -825,8 +922,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
           s = mfma16(frag_rm(Qs, qt, 1, lane), bk[1], s);
           dp = mfma16(frag_rm(dOs, qt, 0, lane), bv[0], dp);
           dp = mfma16(frag_rm(dOs, qt, 1, lane), bv[1], dp);
-          const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g);      // pre-scaled by log2(e)
-          const f32x4_t d4 = *(const f32x4_t*)(dq_s + qt * 16 + 4 * g);       // pre-scaled by `scale`
+          int g_s = g;                           // (opaque: the scalars' LDS address is formed per chunk, not kept -- spilled -- across the item)
+          asm volatile("" : "+v"(g_s));
+          const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g_s);    // pre-scaled by log2(e)
+          const f32x4_t d4 = *(const f32x4_t*)(dq_s + qt * 16 + 4 * g_s);     // pre-scaled by `scale`
           const f32x2_t s01 = (f32x2_t){s[0], s[1]} * sl - (f32x2_t){l4[0], l4[1]}, s23 = (f32x2_t){s[2], s[3]} * sl - (f32x2_t){l4[2], l4[3]};
           const f32x2_t e01 = (f32x2_t){dp[0], dp[1]} * scale - (f32x2_t){d4[0], d4[1]}, e23 = (f32x2_t){dp[2], dp[3]} * scale - (f32x2_t){d4[2], d4[3]};
           const f32x2_t p01 = (f32x2_t){__builtin_amdgcn_exp2f(s01[0]), __builtin_amdgcn_exp2f(s01[1])};
@@ -836,6 +935,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
           ds2[u] = (f32x4_t){d01[0], d01[1], d23[0], d23[1]};
         }
       }
+      // (the last chunk's score products were the last readers of this item's K / V strips)
+      if constexpr (c == NP - 1) fetch_kv(nitem);
       const bf16x8_t bp = pack_pair(pv2[0], pv2[1]);
       union { bf16x8_t v; uint32_t w[4]; } bd;
       bd.v = pack_pair(ds2[0], ds2[1]);
@@ -867,7 +968,12 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) adk[dt] = mfma16(tfq[dt], bd.v, adk[dt]);
       if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the K tile has landed
+#ifdef AVT_LAB
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      AVT_BWD1_STAMP(2 + 3 * c);
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // barrier c: dS chunk complete; the chunk's Q / dO rows are free
+      AVT_BWD1_STAMP(3 + 3 * c);
       // ---- dQ of the chunk's two query tiles: four (tile, half) products, one wave each ----
       static_for<0, 4>([&](auto hh_) __attribute__((always_inline)) {
         constexpr int h = 4 * c + decltype(hh_)::value;
@@ -939,6 +1045,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
           }
         }
       });
+#ifdef AVT_LAB
+      if (rec) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      AVT_BWD1_STAMP(4 + 3 * c);
+#endif
       // the NEXT item's Q / dO rows of this chunk (4 + 4 LDS-DMA instructions of 8 rows), spread over the waves
       if (has_next) {
         for (int j = wv; j < 8; j += NKT) {
@@ -951,11 +1061,16 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     // (scaled: this item's scale of the wave's own key rows, back from LDS -- kept in a register across the item it cost 14 spilled registers)
     float crs = 1.f;
     if (SCALED) crs = rs_s[key];
-    // next item's strips: requested after the register-hungry loop, hidden behind the stores and the item's first barrier
-    fetch_strips(nitem);                        // unconditional (re-fetches this item at the end): keeps the counted wait above exact
+#if !AVT_ATTN_ROWS_EARLY
+    // next item's dO / O strips and per-row scalars: requested after the register-hungry loop, hidden behind the stores and the item's first barrier
+    fetch_rows(nitem);                          // unconditional (re-fetches this item at the end): keeps the counted wait at the loop top exact
+#endif
 #if AVT_ATTN_WIDE_ST
     // 16-byte stores (see the forward kernel): lane (i, g) ends up with 8 consecutive columns of block dp + (g & 1); one tensor after the other
     // (eight registers of packed output at a time: the kernel sits at its 128-register limit)
+    int lane_t = lane;                          // (opaque: the store addresses are formed here, not kept -- spilled -- across the item)
+    asm volatile("" : "+v"(lane_t));
+    const int key_t = k0 + (lane_t & 15), g_t = lane_t >> 4;
     static_for<0, 2>([&](auto w_) __attribute__((always_inline)) {
       constexpr int which = decltype(w_)::value;                 // 0 = dK -> columns [D, 2D), 1 = dV -> [2D, 3D)
       const f32x4_t (&acc4)[4] = which ? adv : adk;
@@ -969,10 +1084,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
         sp[dp >> 1] = (u32x4_t){r0[0], r1[0], r0[1], r1[1]};
       }
       bf16_t* tb = dbase + (which + 1) * D;
-      if (key < S) {
-        bf16_t* rp = tb + (size_t)key * ld + (g >> 1) * 8;
-        *(u32x4_t*)(rp + (g & 1) * 16) = sp[0];
-        *(u32x4_t*)(rp + (2 + (g & 1)) * 16) = sp[1];
+      if (key_t < S) {
+        bf16_t* rp = tb + (size_t)key_t * ld + (g_t >> 1) * 8;
+        *(u32x4_t*)(rp + (g_t & 1) * 16) = sp[0];
+        *(u32x4_t*)(rp + (2 + (g_t & 1)) * 16) = sp[1];
       }
     });
 #else
@@ -986,7 +1101,17 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       }
     }
 #endif
+#ifdef AVT_LAB
+    if (rec) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    AVT_BWD1_STAMP(3 * NP + 2);
+#endif
   }
+#ifdef AVT_LAB
+  if (g_bwd1_stamps != 0 && lane == 0) {
+    uint32_t* d = (uint32_t*)g_bwd1_stamps + ((size_t)blockIdx.x * 16 + wave) * 32;
+    for (int i = 0; i < 3 * NP + 3; ++i) d[i] = ((uint32_t*)(rs_s + KP))[wave * 32 + i];
+  }
+#endif
   if (dbias) {
     __syncthreads();
     if (prev_head >= 0) {
@@ -1018,7 +1143,12 @@ int pick_nkt(int S) { int n = (S + 15) / 16; if (n <= 1) return 1; if (n <= 2) r
 template <int NKT> size_t fwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128; }     // K, V x 2 buffers
 template <int NKT> size_t bwd_smem(int H) { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128 + (size_t)(2 * NP * 32 + H * 192 + NKT * 192) * 4; }
 
-template <int NKT> size_t bwd1_smem(int H) { constexpr int NP = (NKT + 1) / 2, KP = NP * 32; return (size_t)3 * KP * 128 + (size_t)2 * KP * 72 + (size_t)(3 * KP + H * 192 + NKT * 64 + NP * 64) * 4; }
+#ifdef AVT_LAB
+constexpr size_t BWD1_LAB_SMEM = 16 * 32 * 4;      // the stamps of AVT_BWD1_STAMP
+#else
+constexpr size_t BWD1_LAB_SMEM = 0;
+#endif
+template <int NKT> size_t bwd1_smem(int H) { constexpr int NP = (NKT + 1) / 2, KP = NP * 32; return (size_t)3 * KP * 128 + (size_t)2 * KP * 72 + (size_t)(3 * KP + H * 192 + NKT * 64 + NP * 64) * 4 + BWD1_LAB_SMEM; }
 
 template <int NKT>
 int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, int H, float scale, hipStream_t s) {
@@ -1048,6 +1178,14 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
     (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
     const bool live = S > (NKT - 1) * 16;
     const int items1 = frames * H;
+#ifdef AVT_LAB
+    {
+      const char* e = getenv("AVT_BWD1_STAMPS_PTR");             // read on every launch: the tool sets and clears it
+      unsigned long long v = e ? strtoull(e, nullptr, 0) : 0ull;
+      static unsigned long long last = 0;
+      if (v != last) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bwd1_stamps), &v, sizeof(v)); last = v; }
+    }
+#endif
     const int pc = (int)((160 * 1024) / sm1) < 1 ? 1 : (int)((160 * 1024) / sm1);
     int grid1 = 256 * (pc > 8 ? 8 : pc);
     if (grid1 > items1) grid1 = items1;
