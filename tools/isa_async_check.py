@@ -8,7 +8,8 @@ operations of a wave return in order, so a wait for N outstanding retires all bu
 
 Found with it in round 3: a union of the two 64-bit halves of a fragment through 16-bit element vectors made hipcc "merge" them with one
 `v_bfi_b32 d, 0xffff, s, s` per register BEFORE the wait (32 per K-loop trip of the weight-gradient kernel; a race in a small attention
-instantiation).  tests/test_isa_cpu.py runs it on the built library."""
+instantiation).  Round 5: the same walk for the hand-written global loads of the attention kernels (check_vmem_lines).
+tests/test_isa_cpu.py runs both on the built library."""
 import os, re, subprocess, sys, tempfile
 
 LLVM = '/opt/rocm/lib/llvm/bin'
@@ -58,6 +59,84 @@ def check_lines(lines, name, verbose=False, out=None):
     return per_kernel, n_tr
 
 
+VMEM_KERNELS = re.compile(r'vit_attn_(fwd|bwd1)_kernel')
+
+
+def check_vmem_lines(lines, name, verbose=False, out=None, kernels=VMEM_KERNELS):
+    """The same hazard for the hand-written global loads of the attention kernels (strip_ld_na / dword_ld_na in vit_attention.hip: the next item's
+    strips are requested in one trip of the item loop and retired by a counted `s_waitcnt vmcnt(N)` at the top of the next): no instruction may touch
+    a destination register between the request and the wait that retires it.  Vector-memory operations retire in order, loads and stores alike; the
+    walk is linear and follows every backward `s_branch` once (the item loop's back edge), i.e. it assumes -- as the counted waits do -- that every
+    guarded memory operation on the way is issued.  -> ({kernel: hazardous instructions}, loads with a destination seen)"""
+    per_kernel, n_ld = {}, 0
+    # split into kernels: [(name, [(addr, text)])]
+    funcs, cur = [], None
+    for line in lines:
+        m = re.match(r'^(?:[0-9a-f]+ <)?(_Z\w+)>?:', line)
+        if m:
+            cur = (m.group(1), [])
+            funcs.append(cur)
+            continue
+        if cur is None:
+            continue
+        parts = re.split(r';|//', line)
+        t = parts[0].strip()
+        if not t or t.startswith('.') or t.endswith(':'):
+            continue
+        am = re.match(r'\s*([0-9A-Fa-f]+):', parts[1]) if len(parts) > 1 else None
+        cur[1].append((int(am.group(1), 16) if am else None, t))
+    for kernel, ins in funcs:
+        if not kernels.search(kernel):
+            continue
+        index = {a: i for i, (a, _) in enumerate(ins) if a is not None}
+        pending, followed, i, steps = [], set(), 0, 0
+        while i < len(ins) and steps < 4 * len(ins):
+            steps += 1
+            addr, t = ins[i]
+            op = t.split()[0]
+            args = [a.strip() for a in t[len(op):].split(',')]
+            if op == 's_endpgm':
+                break
+            if op == 's_branch' and addr is not None:
+                off = int(args[0])
+                off = off - 65536 if off >= 32768 else off
+                tgt = addr + 4 + 4 * off
+                if off < 0 and i not in followed and tgt in index:
+                    followed.add(i)
+                    i = index[tgt]
+                    continue
+                if off < 0:
+                    break                      # second time round the loop: everything has been seen
+                i += 1
+                continue
+            if op == 's_waitcnt':
+                m = re.search(r'vmcnt\((\d+)\)', t)
+                if m:
+                    n = int(m.group(1))
+                    pending = pending[len(pending) - n:] if 0 < n < len(pending) else ([] if n == 0 else pending)
+                i += 1
+                continue
+            is_vmem = op.startswith(('buffer_', 'global_', 'scratch_', 'flat_'))
+            is_load = is_vmem and ('_load' in op) and ' lds' not in t and not t.endswith('lds')
+            srcs = args[1:] if is_load else args
+            used = set()
+            for a in srcs:
+                used |= _regs(a.split()[0] if a else '')
+            if not is_vmem:
+                used |= _regs(args[0].split()[0]) if args and args[0] else set()
+            for d, at in pending:
+                if d & used:
+                    per_kernel[kernel] = per_kernel.get(kernel, 0) + 1
+                    if verbose:
+                        print(f'{name}: {kernel}: `{t}` touches v{sorted(d & used)} of the load `{ins[at][1]}` before its wait', file=out or sys.stdout)
+            if is_vmem:
+                dest = _regs(args[0].split()[0]) if is_load else set()
+                n_ld += 1 if dest else 0
+                pending.append((dest, i))
+            i += 1
+    return per_kernel, n_ld
+
+
 def device_disassembly(so_path):
     """The gfx950 code objects of a HIP shared library, disassembled: [(name, [lines])]."""
     res = []
@@ -88,6 +167,17 @@ def check_path(path, verbose=False):
     return total, n_tr
 
 
+def check_path_vmem(path, verbose=False):
+    units = device_disassembly(path) if path.endswith('.so') else [(path, open(path).read().splitlines())]
+    total, n_ld = {}, 0
+    for name, lines in units:
+        pk, n = check_vmem_lines(lines, name, verbose)
+        n_ld += n
+        for k, v in pk.items():
+            total[k] = total.get(k, 0) + v
+    return total, n_ld
+
+
 if __name__ == '__main__':
     verbose = '-v' in sys.argv
     bad = 0
@@ -97,4 +187,9 @@ if __name__ == '__main__':
             print(f'{n:5d}  {k}')
         bad += sum(total.values())
         print(f'{path}: {n_tr} transposing reads scanned, {sum(total.values())} instructions touch an in-flight destination')
+        total, n_ld = check_path_vmem(path, verbose)
+        for k, n in total.items():
+            print(f'{n:5d}  {k}')
+        bad += sum(total.values())
+        print(f'{path}: {n_ld} global loads of the attention kernels followed to their wait, {sum(total.values())} instructions touch an in-flight destination')
     sys.exit(1 if bad else 0)
