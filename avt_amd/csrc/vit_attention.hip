@@ -741,11 +741,16 @@ __device__ unsigned long long g_bwd1_stamps = 0;
 #ifndef AVT_BWD1_STAMP_MASK      // which of the 24 stamps are compiled in (each costs registers: all of them at once spill in the item's tail)
 #define AVT_BWD1_STAMP_MASK 0xF0000Fu
 #endif
-#define AVT_BWD1_STAMP(i) do { if ((AVT_BWD1_STAMP_MASK >> (i)) & 1u) if (rec) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ((uint32_t*)(rs_s + KP))[wv * 32 + (i)] = (uint32_t)t_; } } while (0)
+#define AVT_BWD1_STAMP(i) do { if ((AVT_BWD1_STAMP_MASK >> (i)) & 1u) if (rec) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ((uint32_t*)((char*)(rs_s + KP) + OTB))[wv * 32 + (i)] = (uint32_t)t_; } } while (0)
 #else
 #define AVT_BWD1_STAMP(i) do { } while (0)
 #endif
-template <int NKT, bool ALL_LIVE, bool SCALED>
+// OT ("O tile", late round 5; chosen by the launcher when the LDS has room: H <= 12 at NKT = 13): the head's O rows get a row-major tile of their own
+// (NKT * 16 rows, filled by LDS-DMA chunk by chunk like the Q / dO rows), and D[q] = sum_d dO[q,d] O[q,d] of a wave's strip is formed from the two LDS
+// tiles after the item's first barrier instead of from 16 registers of global strips requested in the previous item's tail: those requests could not be
+// issued early enough (no registers) and their latency sat exposed in front of the first barrier of every item (tools/lab/attn_timeline.py); price: a
+// second barrier (S2) in front of chunk 0.
+template <int NKT, bool ALL_LIVE, bool SCALED, bool OT>
 __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                  const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                  bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
@@ -769,6 +774,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
   float* stq_s = bias_s + H * 192;           // [NKT][64] this item's dq sums per query tile
   float* stv_s = stq_s + NKT * 64;           // [NP][64]  this item's dO sums per query pair (= the dv sums: every row of P sums to one)
   float* rs_s = stv_s + NP * 64;             // [KP] row_scale of this item's rows (read by the dQ products: query rows)
+  char* Os = (char*)(rs_s + KP);             // OT: [NKT * 16][64] O rows, swizzled row-major like the Q / dO tiles
+  constexpr int OTB = OT ? NKT * 16 * 128 : 0;
   int prev_head = -1;
   const int D = H * HD, ld = 3 * D;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = 64 * NKT;
@@ -818,23 +825,26 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     asm volatile("" : "+v"(lane_f));
     const int key_f = k0 + (lane_f & 15);
     const bool in = key_f < S;
-    const uint32_t od = in ? (uint32_t)((key_f * D + (lane_f >> 4) * 8) * 2) : STRIP_OOB;       // row of dout / out
-    const u32x4_t rd = raw_rsrc(dout + r0 * D + hd * HD), ro = raw_rsrc(out + r0 * D + hd * HD);
-    ndo[0] = strip_ld_na<0>(rd, od, 0u); ndo[1] = strip_ld_na<64>(rd, od, 0u);
-    no[0] = strip_ld_na<0>(ro, od, 0u);  no[1] = strip_ld_na<64>(ro, od, 0u);
+    if constexpr (!OT) {
+      const uint32_t od = in ? (uint32_t)((key_f * D + (lane_f >> 4) * 8) * 2) : STRIP_OOB;       // row of dout / out
+      const u32x4_t rd = raw_rsrc(dout + r0 * D + hd * HD), ro = raw_rsrc(out + r0 * D + hd * HD);
+      ndo[0] = strip_ld_na<0>(rd, od, 0u); ndo[1] = strip_ld_na<64>(rd, od, 0u);
+      no[0] = strip_ld_na<0>(ro, od, 0u);  no[1] = strip_ld_na<64>(ro, od, 0u);
+    }
     // per-row scalars of rows past the sequence: the last row's (finite; they only ever meet zeros -- D[q] of such a row is 0 through the zero strips)
     const int kc = in ? key_f : S - 1;
     nlq = dword_ld_na(lse + ((size_t)fr * H + hd) * S, (uint32_t)(kc * 4));              // raw: `* log2(e)` where it is stored to LDS
     if (SCALED) nrs = dword_ld_na(row_scale + 2 * r0, (uint32_t)(kc * 8));
   };
 #ifdef AVT_LAB
-  if (lane < 32) ((uint32_t*)(rs_s + KP))[wave * 32 + lane] = 0u;
+  if (lane < 32) ((uint32_t*)((char*)(rs_s + KP) + OTB))[wave * 32 + lane] = 0u;
 #endif
   int item = blockIdx.x;
   if (item < items) {
     const size_t r0 = (size_t)(item / H) * S;
     stage_head_dma(qkv + r0 * ld + (item % H) * HD, ld, S, Qs, KP, wv, NKT, lane);
     stage_head_dma(dout + r0 * D + (item % H) * HD, D, S, dOs, KP, wv, NKT, lane);
+    if constexpr (OT) stage_head_dma(out + r0 * D + (item % H) * HD, D, S, Os, NKT * 16, wv, NKT, lane);
     fetch_kv(item);
     fetch_rows(item);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -851,32 +861,52 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #endif
     __amdgpu_buffer_rsrc_t nrq = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + nr0 * ld + (nitem % H) * HD), 0, 0x7FFFFFF0u, 0x00020000);
     __amdgpu_buffer_rsrc_t nrdo = __builtin_amdgcn_make_buffer_rsrc((void*)(dout + nr0 * D + (nitem % H) * HD), 0, 0x7FFFFFF0u, 0x00020000);
+    __amdgpu_buffer_rsrc_t nro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + nr0 * D + (nitem % H) * HD), 0, 0x7FFFFFF0u, 0x00020000);      // (OT)
 
     // own strips have landed once everything but the youngest 8 vector-memory operations (the previous item's dK / dV stores) is done;
     // older than the strips are the prefetched Q / dO rows of this item and the dQ stores of the previous one
     // (wide stores: 4)
-#define AVT_STRIPS_LANDED(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(ndo[0]), "+v"(ndo[1]), "+v"(no[0]), "+v"(no[1]), "+v"(nlq), "+v"(nrs) :: "memory")
+#define AVT_STRIPS_LANDED(N) do { if constexpr (OT) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(nlq), "+v"(nrs) :: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(ndo[0]), "+v"(ndo[1]), "+v"(no[0]), "+v"(no[1]), "+v"(nlq), "+v"(nrs) :: "memory"); } while (0)
     if (ALL_LIVE) { if (AVT_ATTN_WIDE_ST) AVT_STRIPS_LANDED(4); else AVT_STRIPS_LANDED(8); }
     else AVT_STRIPS_LANDED(0);
 #undef AVT_STRIPS_LANDED
-    {
-      float dsum = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dsum += (float)ndo[ks][e] * (float)no[ks][e];
+    auto publish_rows = [&](float dsum) __attribute__((always_inline)) {
       dsum = gsum(dsum) * scale;
       int lane_s = lane;                        // (opaque: these LDS addresses are used once per item)
       asm volatile("" : "+v"(lane_s));
       if (lane_s < 16) { dq_s[k0 + lane_s] = dsum; lse_s[k0 + lane_s] = nlq * LOG2E; if (SCALED) rs_s[k0 + lane_s] = nrs; }         // k0 + 15 < NKT * 16 <= KP; rows past the sequence: 0 / 0
       if (NKT * 16 < KP && wv == 0 && lane_s < KP - NKT * 16) { dq_s[NKT * 16 + lane_s] = 0.f; lse_s[NKT * 16 + lane_s] = 0.f; }
+    };
+    if constexpr (!OT) {
+      float dsum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += (float)ndo[ks][e] * (float)no[ks][e];
+      publish_rows(dsum);
     }
 #ifdef AVT_LAB
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     AVT_BWD1_STAMP(0);
 #endif
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // barrier S: scalars visible; every wave is done with the previous item
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // barrier S: (!OT: scalars visible;) every wave is done with the previous item, its share of this item's rows has landed
     AVT_BWD1_STAMP(1);
+    stage_head_dma(qkv + row0 * ld + D + head * HD, ld, S, Ks, KP, wv, NKT, lane);       // K tile: first read after barrier 0
+    if constexpr (OT) {
+      // D of the own strip from the dO and O tiles (B-operand layout = the layout of a row fragment)
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      float dsum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8_t a = frag_rm(dOs, wv, ks, lane_o), b = frag_rm(Os, wv, ks, lane_o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsum += (float)a[e] * (float)b[e];
+      }
+      publish_rows(dsum);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // barrier S2: scalars visible
+    }
     if (dbias && prev_head >= 0) {            // the previous item's sums, folded in tile order by the column's owner thread
       float* bh = bias_s + prev_head * 192;
       int tid_b = tid;                        // (opaque: the addresses below are formed here, not kept -- spilled -- across the item)
@@ -893,7 +923,6 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       }
     }
     prev_head = head;
-    stage_head_dma(qkv + row0 * ld + D + head * HD, ld, S, Ks, KP, wv, NKT, lane);       // K tile: first read after barrier 0
 
     f32x4_t adk[4], adv[4];
 #pragma unroll
@@ -974,6 +1003,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #endif
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // barrier c: dS chunk complete; the chunk's Q / dO rows are free
       AVT_BWD1_STAMP(3 + 3 * c);
+      // (OT: the next item's two per-row scalars are requested here, in front of the last chunk's dQ products -- the two waves that have one are
+      // the last to reach the next item's first barrier.  Unconditional, like the requests in the tail: keeps the counted wait at the loop top exact)
+      if constexpr (OT && AVT_ATTN_ROWS_EARLY && c == NP - 1) fetch_rows(nitem);
       // ---- dQ of the chunk's two query tiles: four (tile, half) products, one wave each ----
       static_for<0, 4>([&](auto hh_) __attribute__((always_inline)) {
         constexpr int h = 4 * c + decltype(hh_)::value;
@@ -1051,9 +1083,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #endif
       // the NEXT item's Q / dO rows of this chunk (4 + 4 LDS-DMA instructions of 8 rows), spread over the waves
       if (has_next) {
-        for (int j = wv; j < 8; j += NKT) {
+        for (int j = wv; j < (OT ? 12 : 8); j += NKT) {
           if (j < 4) dma_rows8(nrq, ld, S, Qs, 4 * c + j, lane);
-          else dma_rows8(nrdo, D, S, dOs, 4 * c + j - 4, lane);
+          else if (j < 8) dma_rows8(nrdo, D, S, dOs, 4 * c + j - 4, lane);
+          else if (4 * c + j - 8 < 2 * NKT) dma_rows8(nro, D, S, Os, 4 * c + j - 8, lane);      // (OT) the O tile ends with the last strip
         }
       }
     });
@@ -1061,9 +1094,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     // (scaled: this item's scale of the wave's own key rows, back from LDS -- kept in a register across the item it cost 14 spilled registers)
     float crs = 1.f;
     if (SCALED) crs = rs_s[key];
-#if !AVT_ATTN_ROWS_EARLY
+#if 1
     // next item's dO / O strips and per-row scalars: requested after the register-hungry loop, hidden behind the stores and the item's first barrier
-    fetch_rows(nitem);                          // unconditional (re-fetches this item at the end): keeps the counted wait at the loop top exact
+    if constexpr (!OT || !AVT_ATTN_ROWS_EARLY) fetch_rows(nitem);       // unconditional (re-fetches this item at the end): keeps the counted wait at the loop top exact
 #endif
 #if AVT_ATTN_WIDE_ST
     // 16-byte stores (see the forward kernel): lane (i, g) ends up with 8 consecutive columns of block dp + (g & 1); one tensor after the other
@@ -1109,7 +1142,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #ifdef AVT_LAB
   if (g_bwd1_stamps != 0 && lane == 0) {
     uint32_t* d = (uint32_t*)g_bwd1_stamps + ((size_t)blockIdx.x * 16 + wave) * 32;
-    for (int i = 0; i < 3 * NP + 3; ++i) d[i] = ((uint32_t*)(rs_s + KP))[wave * 32 + i];
+    for (int i = 0; i < 3 * NP + 3; ++i) d[i] = ((uint32_t*)((char*)(rs_s + KP) + OTB))[wave * 32 + i];
   }
 #endif
   if (dbias) {
@@ -1144,7 +1177,7 @@ template <int NKT> size_t fwd_smem() { constexpr int NP = (NKT + 1) / 2; return 
 template <int NKT> size_t bwd_smem(int H) { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128 + (size_t)(2 * NP * 32 + H * 192 + NKT * 192) * 4; }
 
 #ifdef AVT_LAB
-constexpr size_t BWD1_LAB_SMEM = 16 * 32 * 4;      // the stamps of AVT_BWD1_STAMP
+constexpr size_t BWD1_LAB_SMEM = 13 * 32 * 4;      // the stamps of AVT_BWD1_STAMP (32 words per wave; with the O tile 163 584 of the 163 840 bytes)
 #else
 constexpr size_t BWD1_LAB_SMEM = 0;
 #endif
@@ -1170,12 +1203,11 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
 #ifndef AVT_ATTN_BWD_TWO_PHASE
   {
     // single-pass kernel (default since round 4); the two-phase kernel stays selectable for A/B (-DAVT_ATTN_BWD_TWO_PHASE)
-    const size_t sm1 = bwd1_smem<NKT>(H);
+    size_t sm1 = bwd1_smem<NKT>(H);
     if (sm1 > 160 * 1024) { avt_set_error("avt_vit_attn_bwd: H = %d needs more LDS than a CU has", H); return -1; }
-    (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
-    (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
-    (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
-    (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1);
+    // the O tile (kernel comment) where it fits: H <= 12 at NKT = 13
+    const bool ot = sm1 + (size_t)NKT * 16 * 128 <= 160 * 1024;
+    if (ot) sm1 += (size_t)NKT * 16 * 128;
     const bool live = S > (NKT - 1) * 16;
     const int items1 = frames * H;
 #ifdef AVT_LAB
@@ -1191,9 +1223,12 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
     if (grid1 > items1) grid1 = items1;
     if (!dbias) part = nullptr;
     if (part && part_bytes < (size_t)grid1 * 3 * H * HD * 4) { avt_set_error("avt_vit_attn_bwd: partials workspace too small"); return -1; }
-#define AVT_BWD1(LIVE, SC) hipLaunchKernelGGL((vit_attn_bwd1_kernel<NKT, LIVE, SC>), dim3(grid1), dim3(64 * NKT), sm1, s, qkv, out, dout, lse, dqkv, dbias, part, S, H, items1, scale, row_scale)
+#define AVT_BWD1_(LIVE, SC, OTV) do { (void)hipFuncSetAttribute((const void*)vit_attn_bwd1_kernel<NKT, LIVE, SC, OTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm1); \
+    hipLaunchKernelGGL((vit_attn_bwd1_kernel<NKT, LIVE, SC, OTV>), dim3(grid1), dim3(64 * NKT), sm1, s, qkv, out, dout, lse, dqkv, dbias, part, S, H, items1, scale, row_scale); } while (0)
+#define AVT_BWD1(LIVE, SC) do { if (ot) AVT_BWD1_(LIVE, SC, true); else AVT_BWD1_(LIVE, SC, false); } while (0)
     if (row_scale) { if (live) AVT_BWD1(true, true); else AVT_BWD1(false, true); }
     else { if (live) AVT_BWD1(true, false); else AVT_BWD1(false, false); }
+#undef AVT_BWD1_
 #undef AVT_BWD1
     if (part) { float* outs[1] = {dbias}; return avt_reduce_partials(part, grid1, 3L * H * HD, outs, 1, s); }
     return 0;
