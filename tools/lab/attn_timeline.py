@@ -49,50 +49,23 @@ os.environ['AVT_BWD1_STAMPS_PTR'] = '0'
 run(); torch.cuda.synchronize()
 if not buf.any().item():
     print('no stamps (not the lab library): done'); sys.exit(0)
-st = buf.cpu().numpy().astype(np.int64).reshape(256, 16, 32)[:, :13, :24] & 0xffffffff
-NP = 7
+st = buf.cpu().numpy().astype(np.int64).reshape(256, 16, 32)[:, :13, :] & 0xffffffff
 ok = st[:, :, 0].min(axis=1) > 0
 print(f'workgroups with stamps: {int(ok.sum())} of 256')
 st = st[ok]
 t0 = st[:, :, 0].min(axis=1)[:, None, None]
-rel = (st - t0) & 0xffffffff                     # cycles (s_memtime: 100 MHz-independent shader clock counter) since the first wave reached barrier S
-A = lambda c: rel[:, :, 2 + 3 * c]
-R = lambda c: rel[:, :, 3 + 3 * c]
-Q = lambda c: rel[:, :, 4 + 3 * c]
-print('item = barrier S .. end: %.0f cycles (mean over workgroups of the last wave\'s end stamp)' % rel[:, :, 23].max(axis=1).mean())
-print('barrier S: arrival spread %.0f, release %.0f' % ((rel[:, :, 0].max(axis=1) - rel[:, :, 0].min(axis=1)).mean(), rel[:, :, 1].mean()))
-prev_end = np.broadcast_to(rel[:, :, 1], rel[:, :, 1].shape).copy()
-waves = np.arange(13)
-print('chunk |  work(all)  work(dq waves of c-1: their dq excluded) |  dq product |  wait(dq waves of c-1)  wait(others) | period (release c - release c-1)')
-prev_rel = rel[:, :, 1]
-for c in range(NP):
-    dqw_prev = np.zeros(13, bool)
-    if c > 0:
-        for h in range(4 * (c - 1), 4 * (c - 1) + 4):
-            if h < 26: dqw_prev[h % 13] = True
-    dqw = np.zeros(13, bool)
-    for h in range(4 * c, 4 * c + 4):
-        if h < 26: dqw[h % 13] = True
-    work = A(c) - prev_end
-    wait = R(c) - A(c)
-    dq = Q(c) - R(c)
-    period = (R(c) - prev_rel).mean()
-    w_all = work.mean()
-    w_dq = work[:, dqw_prev].mean() if dqw_prev.any() else float('nan')
-    wt_dq = wait[:, dqw_prev].mean() if dqw_prev.any() else float('nan')
-    wt_ot = wait[:, ~dqw_prev].mean()
-    last = A(c).argmax(axis=1)                   # which wave arrives last
-    frac_last_dq = dqw_prev[last].mean() if dqw_prev.any() else float('nan')
-    print(f'  {c}   | {w_all:8.0f} {w_dq:8.0f} | {dq[:, dqw].mean():8.0f} (others {dq[:, ~dqw].mean():5.0f}) | {wt_dq:8.0f} {wt_ot:8.0f} | {period:8.0f}   last arriver is a dq wave of c-1: {frac_last_dq:.2f}')
-    prev_end = Q(c).copy()
-    prev_rel = R(c)
-print('tail (end stamp - last dq / release): %.0f' % (rel[:, :, 23] - prev_end).mean())
-b = 0
-print('workgroup 0, per wave: A_c - R_(c-1)/Q_(c-1) [work], R_c - A_c [wait], Q_c - R_c [dq]')
-for w in range(13):
-    row = []
-    pe = rel[b, w, 1]
-    for c in range(NP):
-        row.append(f'{rel[b, w, 2 + 3 * c] - pe:5d}/{rel[b, w, 3 + 3 * c] - rel[b, w, 2 + 3 * c]:5d}/{rel[b, w, 4 + 3 * c] - rel[b, w, 3 + 3 * c]:5d}')
-        pe = rel[b, w, 4 + 3 * c]
-    print(f'  w{w:2d}: ' + '  '.join(row))
+rel = (st - t0) & 0xffffffff                     # cycles since the first wave reached barrier S
+have = lambda i: bool((st[:, :, i] != 0).any())
+m = lambda a: float(np.mean(a))
+print('stamps present:', [i for i in range(32) if have(i)])
+print(f'barrier S : arrival spread {m(rel[:, :, 0].max(axis=1)):.0f}, released {m(rel[:, :, 1]):.0f} after the first arrival')
+if have(24):
+    print(f'D of the strips from LDS: {m(rel[:, :, 24] - rel[:, :, 1]):.0f};  barrier S2 wait {m(rel[:, :, 25] - rel[:, :, 24]):.0f};  S2 released at {m(rel[:, :, 25]):.0f}')
+start = rel[:, :, 25] if have(24) else rel[:, :, 1]
+print(f'chunk 0   : work {m(rel[:, :, 2] - start):.0f}, wait {m(rel[:, :, 3] - rel[:, :, 2]):.0f};  barrier 0 released at {m(rel[:, :, 3]):.0f}')
+if have(20):
+    print(f'chunks 1-6: barrier 0 release -> barrier 6 arrival {m(rel[:, :, 20] - rel[:, :, 3]):.0f} (wait at 6: {m(rel[:, :, 21] - rel[:, :, 20]):.0f});  barrier 6 released at {m(rel[:, :, 21]):.0f}')
+    dq = rel[:, :, 22] - rel[:, :, 21]
+    print(f'after barrier 6: dQ products of waves 11 / 12 {m(dq[:, 11]):.0f} / {m(dq[:, 12]):.0f} (others {m(dq[:, :11]):.0f});  tail (-> stores issued) {m(rel[:, :, 23] - rel[:, :, 22]):.0f}')
+    print(f'end stamp: first wave {m(rel[:, :, 23].min(axis=1)):.0f}, last wave {m(rel[:, :, 23].max(axis=1)):.0f};  per wave w0..w12: ' + ' '.join(f'{m(rel[:, w, 23]):.0f}' for w in range(13)))
+print('(the item period is the launch time / items per workgroup: %.0f items)' % (frames * H / 256))
