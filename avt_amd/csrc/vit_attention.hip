@@ -24,6 +24,17 @@
 #ifndef AVT_ATTN_WIDE_ST
 #define AVT_ATTN_WIDE_ST 1
 #endif
+#ifndef AVT_ATTN_ABL               // timing-only ablations of the single-pass backward (WRONG results; tools/lab/job_r05p.sh): bit 0 no dK / dV stores,
+#define AVT_ATTN_ABL 0             // 1 no wait for the K tile in chunk 0, 2 no barrier S2, 3 no dQ products, 4 no K / V strip requests
+#endif
+// Start stagger: the persistent workgroups all start together and every item takes the same time, so all 256 CUs reach their items' ends -- the
+// dK / dV / dQ (forward: O) stores and the next strips' requests -- at the same moment; workgroup b sleeps (b mod 16) x AVT_ATTN_STAGGER_* x 64 cycles first.
+#ifndef AVT_ATTN_STAGGER_BWD
+#define AVT_ATTN_STAGGER_BWD 0
+#endif
+#ifndef AVT_ATTN_STAGGER_FWD
+#define AVT_ATTN_STAGGER_FWD 0
+#endif
 #ifndef AVT_ATTN_TAIL_FIRST
 #define AVT_ATTN_TAIL_FIRST 0      // 1: measured no better (backward 1849 vs 1842 us per launch, step 955.9 / 953.8 vs 957.0 / 954.6 clips/s; profiles/r05o_attention_boundary.txt)
 #endif
@@ -266,6 +277,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   };
   uint32_t troff[4];
   tr_lane_offsets(lane, troff);
+  if (AVT_ATTN_STAGGER_FWD > 0) {
+    for (int i = (int)(blockIdx.x & 15u); i > 0; --i) __builtin_amdgcn_s_sleep(AVT_ATTN_STAGGER_FWD);
+  }
   if (item < items) {
     const bf16_t* base = qkv + (size_t)(item / H) * S * ld + (item % H) * HD;
     stage_head_dma(base + D, ld, S, smem, KP, wv, NKT, lane);
@@ -842,6 +856,9 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #ifdef AVT_LAB
   if (lane < 32) ((uint32_t*)((char*)(rs_s + KP) + OTB))[wave * 32 + lane] = 0u;
 #endif
+  if (AVT_ATTN_STAGGER_BWD > 0) {
+    for (int i = (int)(blockIdx.x & 15u); i > 0; --i) __builtin_amdgcn_s_sleep(AVT_ATTN_STAGGER_BWD);
+  }
   int item = blockIdx.x;
   if (item < items) {
     const size_t r0 = (size_t)(item / H) * S;
@@ -871,7 +888,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     // (wide stores: 4)
 #define AVT_STRIPS_LANDED(N) do { if constexpr (OT) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(nlq), "+v"(nrs) :: "memory"); \
     else asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(ndo[0]), "+v"(ndo[1]), "+v"(no[0]), "+v"(no[1]), "+v"(nlq), "+v"(nrs) :: "memory"); } while (0)
-    if (ALL_LIVE) { if (AVT_ATTN_WIDE_ST) AVT_STRIPS_LANDED(4); else AVT_STRIPS_LANDED(8); }
+    if (ALL_LIVE && !(AVT_ATTN_ABL & 1)) { if (AVT_ATTN_WIDE_ST) AVT_STRIPS_LANDED(4); else AVT_STRIPS_LANDED(8); }
     else AVT_STRIPS_LANDED(0);
 #undef AVT_STRIPS_LANDED
     auto publish_rows = [&](float dsum) __attribute__((always_inline)) {
@@ -912,7 +929,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       AVT_BWD1_STAMP(24);
 #endif
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // barrier S2: scalars visible
+      if (!(AVT_ATTN_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // barrier S2: scalars visible
       AVT_BWD1_STAMP(25);
     }
     if (dbias && prev_head >= 0) {            // the previous item's sums, folded in tile order by the column's owner thread
@@ -969,7 +986,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
           sp[dp >> 1] = (u32x4_t){r0[0], r1[0], r0[1], r1[1]};
         }
         bf16_t* tb = dbase + (which + 1) * D;
-        if (key_t < S) {
+        if (key_t < S && !(AVT_ATTN_ABL & 1)) {
           bf16_t* rp = tb + (size_t)key_t * ld + (g_t >> 1) * 8;
           *(u32x4_t*)(rp + (g_t & 1) * 16) = sp[0];
           *(u32x4_t*)(rp + (2 + (g_t & 1)) * 16) = sp[1];
@@ -1036,7 +1053,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
         }
       }
       // (the last chunk's score products were the last readers of this item's K / V strips)
-      if constexpr (c == NP - 1) fetch_kv(nitem);
+      if constexpr (c == NP - 1 && !(AVT_ATTN_ABL & 16)) fetch_kv(nitem);
       const bf16x8_t bp = pack_pair(pv2[0], pv2[1]);
       union { bf16x8_t v; uint32_t w[4]; } bd;
       bd.v = pack_pair(ds2[0], ds2[1]);
@@ -1067,7 +1084,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       lgkm_wait4(tfq[0], tfq[1], tfq[2], tfq[3]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) adk[dt] = mfma16(tfq[dt], bd.v, adk[dt]);
-      if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the K tile has landed
+      if (c == 0 && !(AVT_ATTN_ABL & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the K tile has landed
 #ifdef AVT_LAB
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       AVT_BWD1_STAMP(2 + 3 * c);
@@ -1082,7 +1099,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       static_for<0, 4>([&](auto hh_) __attribute__((always_inline)) {
         constexpr int h = 4 * c + decltype(hh_)::value;
         if constexpr (h < 2 * NKT) {
-          if (wv == h % NKT) {
+          if (wv == h % NKT && !(AVT_ATTN_ABL & 8)) {
             constexpr int qt = h >> 1, half = h & 1, u = qt & 1;
             f32x4_t acc[2];
             acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
