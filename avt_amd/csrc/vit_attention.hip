@@ -762,7 +762,7 @@ __device__ unsigned long long g_bwd1_stamps = 0;
 #else
 #define AVT_BWD1_STAMP(i) do { } while (0)
 #endif
-// OT ("O tile", late round 5; chosen by the launcher when the LDS has room: H <= 12 at NKT = 13): the head's O rows get a row-major tile of their own
+// OT ("O tile", late round 5; chosen by the launcher when the LDS has room: H <= 21 at NKT = 13): the head's O rows get a row-major tile of their own
 // (NKT * 16 rows, filled by LDS-DMA chunk by chunk like the Q / dO rows), and D[q] = sum_d dO[q,d] O[q,d] of a wave's strip is formed from the two LDS
 // tiles after the item's first barrier instead of from 16 registers of global strips requested in the previous item's tail: those requests could not be
 // issued early enough (no registers) and their latency sat exposed in front of the first barrier of every item (tools/lab/attn_timeline.py); price: a
@@ -787,8 +787,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
   char* dSb = smem + 3 * RM;
   float* lse_s = (float*)(smem + 3 * RM + 2 * DSB);    // lse * log2(e)
   float* dq_s = lse_s + KP;                  // D[q] * scale,  D[q] = sum_d dO[q,d] O[q,d]
-  float* bias_s = dq_s + KP;                 // [H][3*64] column sums of dq | dk | dv, kept for the whole kernel
-  float* stq_s = bias_s + H * 192;           // [NKT][64] this item's dq sums per query tile
+  float* bias_s = dq_s + KP;                 // [H][2*64] column sums of dq | dv, kept for the whole kernel (those of dk are zero: every row of dS sums to zero)
+  float* stq_s = bias_s + H * 128;           // [NKT][64] this item's dq sums per query tile
   float* stv_s = stq_s + NKT * 64;           // [NP][64]  this item's dO sums per query pair (= the dv sums: every row of P sums to one)
   float* rs_s = stv_s + NP * 64;             // [KP] row_scale of this item's rows (read by the dQ products: query rows)
   char* Os = (char*)(rs_s + KP);             // OT: [NKT * 16][64] O rows, swizzled row-major like the Q / dO tiles
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
   const int g = lane >> 4, i16 = lane & 15;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const float sl = scale * LOG2E;
-  if (dbias) for (int i = tid; i < H * 192; i += nthr) bias_s[i] = 0.f;
+  if (dbias) for (int i = tid; i < H * 128; i += nthr) bias_s[i] = 0.f;
   // key rows past the last wave's strip exist in the dS buffers (the dQ products walk whole 32-key pairs) but are never written: zero
   // them once -- they meet all-zero K rows, and 0 x (whatever bits the LDS held) must not be a NaN
   constexpr int PADW = (KP - NKT * 16) * (DSP / 4);          // 32-bit words of padding rows per buffer (none when the strips fill the pairs)
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       AVT_BWD1_STAMP(25);
     }
     if (dbias && prev_head >= 0) {            // the previous item's sums, folded in tile order by the column's owner thread
-      float* bh = bias_s + prev_head * 192;
+      float* bh = bias_s + prev_head * 128;
       int tid_b = tid;                        // (opaque: the addresses below are formed here, not kept -- spilled -- across the item)
       asm volatile("" : "+v"(tid_b));
       for (int c = tid_b; c < 64; c += nthr) {
@@ -941,10 +941,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #pragma unroll
         for (int w = 0; w < NKT; ++w) t += stq_s[w * 64 + c];
         bh[c] = t;
-        float u = bh[128 + c];
+        float u = bh[64 + c];
 #pragma unroll
         for (int w = 0; w < NP; ++w) u += stv_s[w * 64 + c];
-        bh[128 + c] = u;
+        bh[64 + c] = u;
       }
     }
     prev_head = head;
@@ -1188,22 +1188,23 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
   if (dbias) {
     __syncthreads();
     if (prev_head >= 0) {
-      float* bh = bias_s + prev_head * 192;
+      float* bh = bias_s + prev_head * 128;
       for (int c = tid; c < 64; c += nthr) {
         float t = bh[c];
 #pragma unroll
         for (int w = 0; w < NKT; ++w) t += stq_s[w * 64 + c];
         bh[c] = t;
-        float u = bh[128 + c];
+        float u = bh[64 + c];
 #pragma unroll
         for (int w = 0; w < NP; ++w) u += stv_s[w * 64 + c];
-        bh[128 + c] = u;
+        bh[64 + c] = u;
       }
     }
     __syncthreads();
     for (int i = tid; i < H * 192; i += nthr) {
       const int hh = i / 192, c = i % 192;
-      const float v = bias_s[i];
+      const int pt = c >> 6;                                              // 0 = q, 1 = k (zero), 2 = v
+      const float v = pt == 1 ? 0.f : bias_s[hh * 128 + (pt >> 1) * 64 + (c & 63)];
       const int o = (c >> 6) * D + hh * HD + (c & 63);
       if (part) part[(size_t)blockIdx.x * (3 * D) + o] = v;
       else if (v != 0.f) unsafeAtomicAdd(&dbias[o], v);
@@ -1221,7 +1222,7 @@ constexpr size_t BWD1_LAB_SMEM = 13 * 32 * 4;      // the stamps of AVT_BWD1_STA
 #else
 constexpr size_t BWD1_LAB_SMEM = 0;
 #endif
-template <int NKT> size_t bwd1_smem(int H) { constexpr int NP = (NKT + 1) / 2, KP = NP * 32; return (size_t)3 * KP * 128 + (size_t)2 * KP * 72 + (size_t)(3 * KP + H * 192 + NKT * 64 + NP * 64) * 4 + BWD1_LAB_SMEM; }
+template <int NKT> size_t bwd1_smem(int H) { constexpr int NP = (NKT + 1) / 2, KP = NP * 32; return (size_t)3 * KP * 128 + (size_t)2 * KP * 72 + (size_t)(3 * KP + H * 128 + NKT * 64 + NP * 64) * 4 + BWD1_LAB_SMEM; }
 
 template <int NKT>
 int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, int H, float scale, hipStream_t s) {
@@ -1245,7 +1246,7 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
     // single-pass kernel (default since round 4); the two-phase kernel stays selectable for A/B (-DAVT_ATTN_BWD_TWO_PHASE)
     size_t sm1 = bwd1_smem<NKT>(H);
     if (sm1 > 160 * 1024) { avt_set_error("avt_vit_attn_bwd: H = %d needs more LDS than a CU has", H); return -1; }
-    // the O tile (kernel comment) where it fits: H <= 12 at NKT = 13
+    // the O tile (kernel comment) where it fits: H <= 21 at NKT = 13
     const bool ot = sm1 + (size_t)NKT * 16 * 128 <= 160 * 1024;
     if (ot) sm1 += (size_t)NKT * 16 * 128;
     const bool live = S > (NKT - 1) * 16;
