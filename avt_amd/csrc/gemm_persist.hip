@@ -428,6 +428,9 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wn = wave & 3;
+#if AVT_PK_STAGGER > 0        // A/B switch: the workgroups start spread over this many cycles (stagger_start, gemm_tile.hpp), so that their tiles' store tails do not coincide
+  stagger_start(AVT_PK_STAGGER, (int)blockIdx.x);
+#endif
   if constexpr (GELU) {       // the table: once per workgroup
     __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)g_gelu_tab, 0, GELU_TAB_BYTES, 0x00020000);
 #pragma unroll

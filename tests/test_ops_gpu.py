@@ -566,7 +566,7 @@ def test_layernorm_fold_backward_kernels(ops, rows, D):
     assert torch.equal(dW, dW2) and torch.equal(dg, dg2) and torch.equal(db, db2)
 
 
-@pytest.mark.parametrize('frames,S,H', [(3, 197, 12), (2, 50, 3), (2, 100, 2)])
+@pytest.mark.parametrize('frames,S,H', [(3, 197, 12), (2, 50, 3), (2, 100, 2), (20, 197, 16), (12, 197, 24)])   # H = 16: O tile at ViT-L's head count; H = 24: no room for it (register strips)
 def test_vit_attention_backward_scaled_rows(ops, frames, S, H):
     """avt_vit_attn_bwd_scaled: dqkv rows multiplied by row_stat[:, 0]; the bias gradient stays that of the unscaled dqkv."""
     D = H * 64
@@ -622,7 +622,7 @@ def test_layernorm_strided_rows(ops):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('frames,S,H', [(3, 197, 12), (2, 5, 4), (2, 17, 2), (1, 50, 3), (2, 100, 2), (1, 208, 1), (49, 197, 12), (70, 180, 4)])   # the last two: more (frame, head) items than persistent workgroups
+@pytest.mark.parametrize('frames,S,H', [(3, 197, 12), (2, 5, 4), (2, 17, 2), (1, 50, 3), (2, 100, 2), (1, 208, 1), (49, 197, 12), (70, 180, 4), (20, 197, 16), (12, 197, 24)])   # more (frame, head) items than persistent workgroups; H = 16 / 24: backward with / without the O tile
 def test_vit_attention(ops, frames, S, H):
     D = H * 64
     qkv = rnd((frames * S, 3 * D), 1.0, 30)
