@@ -28,7 +28,8 @@
 #define AVT_ATTN_ABL 0             // 1 no wait for the K tile in chunk 0, 2 no barrier S2, 3 no dQ products, 4 no K / V strip requests
 #endif
 // Start stagger: the persistent workgroups all start together and every item takes the same time, so all 256 CUs reach their items' ends -- the
-// dK / dV / dQ (forward: O) stores and the next strips' requests -- at the same moment; workgroup b sleeps (b mod 16) x AVT_ATTN_STAGGER_* x 64 cycles first.
+// dK / dV / dQ (forward: O) stores and the next strips' requests -- at the same moment; workgroup b sleeps ((b / 8) mod 32) x AVT_ATTN_STAGGER_* x 64 cycles first
+// (b mod 8 is the XCD: 32 phases inside every XCD).
 #ifndef AVT_ATTN_STAGGER_BWD
 #define AVT_ATTN_STAGGER_BWD 0
 #endif
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   uint32_t troff[4];
   tr_lane_offsets(lane, troff);
   if (AVT_ATTN_STAGGER_FWD > 0) {
-    for (int i = (int)(blockIdx.x & 15u); i > 0; --i) __builtin_amdgcn_s_sleep(AVT_ATTN_STAGGER_FWD);
+    for (int i = (int)((blockIdx.x >> 3) & 31u); i > 0; --i) __builtin_amdgcn_s_sleep(AVT_ATTN_STAGGER_FWD);
   }
   if (item < items) {
     const bf16_t* base = qkv + (size_t)(item / H) * S * ld + (item % H) * HD;
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
   if (lane < 32) ((uint32_t*)((char*)(rs_s + KP) + OTB))[wave * 32 + lane] = 0u;
 #endif
   if (AVT_ATTN_STAGGER_BWD > 0) {
-    for (int i = (int)(blockIdx.x & 15u); i > 0; --i) __builtin_amdgcn_s_sleep(AVT_ATTN_STAGGER_BWD);
+    for (int i = (int)((blockIdx.x >> 3) & 31u); i > 0; --i) __builtin_amdgcn_s_sleep(AVT_ATTN_STAGGER_BWD);
   }
   int item = blockIdx.x;
   if (item < items) {

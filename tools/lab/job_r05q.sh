@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05q_attn_stagger.txt
 : > $O
-for lib in hip stg16 stg32 stg64 hip; do
+for lib in hip stg8 stg17 stg34 hip; do
   [ -f avt_amd/libavt_$lib.so ] || continue
   echo "=== libavt_$lib.so" >> $O
   AVT_HIP_LIB=$GRAFT_REPO_ROOT/avt_amd/libavt_$lib.so timeout 300 python tools/lab/attn_timeline.py 2560 1 2>&1 | grep "us per" >> $O
