@@ -36,6 +36,9 @@
 #ifndef AVT_ATTN_STAGGER_FWD
 #define AVT_ATTN_STAGGER_FWD 0
 #endif
+#ifndef AVT_ATTN_S2_LATE
+#define AVT_ATTN_S2_LATE 0       // 1: measured no better (1872 / 1868 vs 1852 / 1862 us per launch)
+#endif
 #ifndef AVT_ATTN_TAIL_FIRST
 #define AVT_ATTN_TAIL_FIRST 0      // 1: measured no better (backward 1849 vs 1842 us per launch, step 955.9 / 953.8 vs 957.0 / 954.6 clips/s; profiles/r05o_attention_boundary.txt)
 #endif
@@ -930,7 +933,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       AVT_BWD1_STAMP(24);
 #endif
-      if (!(AVT_ATTN_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // barrier S2: scalars visible
+      // barrier S2 (scalars visible): AVT_ATTN_S2_LATE moves it into chunk 0, behind the first query tile's score products -- the first readers of the scalars
+      if (!(AVT_ATTN_ABL & 4) && !AVT_ATTN_S2_LATE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       AVT_BWD1_STAMP(25);
     }
     if (dbias && prev_head >= 0) {            // the previous item's sums, folded in tile order by the column's owner thread
@@ -1040,6 +1044,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
           s = mfma16(frag_rm(Qs, qt, 1, lane), bk[1], s);
           dp = mfma16(frag_rm(dOs, qt, 0, lane), bv[0], dp);
           dp = mfma16(frag_rm(dOs, qt, 1, lane), bv[1], dp);
+          if constexpr (OT && AVT_ATTN_S2_LATE && c == 0) { if (u == 0 && !(AVT_ATTN_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // barrier S2
           int g_s = g;                           // (opaque: the scalars' LDS address is formed per chunk, not kept -- spilled -- across the item)
           asm volatile("" : "+v"(g_s));
           const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g_s);    // pre-scaled by log2(e)
