@@ -4,7 +4,7 @@ the 4th item of every workgroup.  Printed: per chunk, averaged over the workgrou
    work   = arrival at barrier c  - (release of barrier c-1, or the end of the wave's dQ product of chunk c-1)
    wait   = release - arrival                     (split into waves that had a dQ product in the previous chunk and the others)
    dq     = end of the dQ product - release       (the 4 waves that have one)
-and the item's critical path.  usage: attn_timeline.py [frames] [scaled 0|1]"""
+and the item's critical path.  usage: attn_timeline.py [frames] [scaled 0|1] [heads]   (heads = 1 with 12 x the frames: the same items on rows of 384 contiguous bytes)"""
 import os, sys
 import numpy as np
 import torch
@@ -14,7 +14,8 @@ from avt_amd import ops
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2560
 scaled = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-S, H, D = 197, 12, 768
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+S, D = 197, H * 64
 dev = 'cuda'
 g = torch.Generator(device=dev).manual_seed(5)
 qkv = (torch.randn(frames * S, 3 * D, device=dev, generator=g) * 0.7).bfloat16()
