@@ -42,9 +42,6 @@
 #ifndef AVT_ATTN_TAIL_FIRST
 #define AVT_ATTN_TAIL_FIRST 0      // 1: measured no better (backward 1849 vs 1842 us per launch, step 955.9 / 953.8 vs 957.0 / 954.6 clips/s; profiles/r05o_attention_boundary.txt)
 #endif
-#ifndef AVT_ATTN_ROWS_EARLY
-#define AVT_ATTN_ROWS_EARLY 0      // 1: measured 20-25 spilled registers (the requests at the top of the last chunk)
-#endif
 #include "../../include/avt_hip.h"
 
 namespace {
@@ -971,10 +968,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       const int key_t = k0 + (lane_t & 15), g_t = lane_t >> 4;
       float crs = 1.f;
       if (SCALED) crs = rs_s[key_t];
-#if 1
-      // next item's dO / O strips and per-row scalars: requested after the register-hungry loop, hidden behind the stores and the item's first barrier
-      if constexpr (!OT || !AVT_ATTN_ROWS_EARLY) fetch_rows(nitem);       // unconditional (re-fetches this item at the end): keeps the counted wait at the loop top exact
-#endif
+      // next item's per-row scalars (!OT: and dO / O strips): requested after the register-hungry loop, hidden behind the stores and the item's first barrier.
+      // Unconditional (re-fetches this item at the end): keeps the counted wait at the loop top exact.  Every earlier place was tried and spills: the top
+      // of the last chunk 20-25 registers, behind the last barrier 9-12 (profiles/r05n_attention_boundary.txt)
+      fetch_rows(nitem);
 #if AVT_ATTN_WIDE_ST
       // 16-byte stores (see the forward kernel): lane (i, g) ends up with 8 consecutive columns of block dp + (g & 1); one tensor after the other
       // (eight registers of packed output at a time: the kernel sits at its 128-register limit)
@@ -1023,11 +1020,6 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     };
     static_for<0, NP>([&](auto c_) __attribute__((always_inline)) {
       constexpr int c = decltype(c_)::value;
-#if AVT_ATTN_ROWS_EARLY
-      // next item's dO / O strips and per-row scalars: requested at the top of the last chunk (one query tile only: the chunk with the fewest live
-      // registers), a whole chunk + the tail ahead of their use.  Unconditional (re-fetches this item at the end): keeps the counted wait at the loop top exact
-      if constexpr (c == NP - 1) fetch_rows(nitem);
-#endif
       // software pipeline: the transposing reads of the dO tile (for dV) are requested first and land under the score / softmax work;
       // those of the Q tile (for dK) are requested before the dV products and land under them
       bf16x8_t tfo[4], tfq[4];
@@ -1097,9 +1089,6 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #endif
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // barrier c: dS chunk complete; the chunk's Q / dO rows are free
       AVT_BWD1_STAMP(3 + 3 * c);
-      // (OT: the next item's two per-row scalars are requested here, in front of the last chunk's dQ products -- the two waves that have one are
-      // the last to reach the next item's first barrier.  Unconditional, like the requests in the tail: keeps the counted wait at the loop top exact)
-      if constexpr (OT && AVT_ATTN_ROWS_EARLY && c == NP - 1) fetch_rows(nitem);
       if constexpr (TF && c == NP - 1) { dma_next_rows(c); item_tail(); }
       // ---- dQ of the chunk's two query tiles: four (tile, half) products, one wave each ----
       static_for<0, 4>([&](auto hh_) __attribute__((always_inline)) {
