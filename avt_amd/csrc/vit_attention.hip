@@ -36,6 +36,9 @@
 #ifndef AVT_ATTN_STAGGER_FWD
 #define AVT_ATTN_STAGGER_FWD 0
 #endif
+#ifndef AVT_ATTN_LATE_ST           // A/B switch: the dK / dV of an item leave in chunk 0 of the NEXT item (packed, 16 registers that are free there: the new
+#define AVT_ATTN_LATE_ST 1         // accumulators are not live before the chunk's first dV product) instead of in the item's tail, next to the strip requests
+#endif
 #ifndef AVT_ATTN_S2_LATE
 #define AVT_ATTN_S2_LATE 0       // 1: measured no better (1872 / 1868 vs 1852 / 1862 us per launch)
 #endif
@@ -825,6 +828,22 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
   // compiler -- possibly in front of the wait)
   bf16x8_t bk[2], bv[2], ndo[2], no[2];
   float nlq = 0.f, nrs = 1.f;
+  constexpr bool LS = AVT_ATTN_LATE_ST && AVT_ATTN_WIDE_ST && OT && NP > 1;      // late dK / dV stores (see AVT_ATTN_LATE_ST)
+  u32x4_t hold[4];                           // LS: the previous item's packed dK | dV pieces
+  bf16_t* hold_base = nullptr;               // LS: ... and where they go (null: nothing held)
+  auto flush_hold = [&]() __attribute__((always_inline)) {
+    int lane_h = lane;                       // (opaque: the addresses are formed here, not kept across the item)
+    asm volatile("" : "+v"(lane_h));
+    const int key_h = k0 + (lane_h & 15), g_h = lane_h >> 4;
+    if (key_h < S && !(AVT_ATTN_ABL & 1)) {
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        bf16_t* rp = hold_base + (which + 1) * D + (size_t)key_h * ld + (g_h >> 1) * 8;
+        *(u32x4_t*)(rp + (g_h & 1) * 16) = hold[2 * which];
+        *(u32x4_t*)(rp + (2 + (g_h & 1)) * 16) = hold[2 * which + 1];
+      }
+    }
+  };
   auto fetch_kv = [&](int it) __attribute__((always_inline)) {
     const size_t r0 = (size_t)(it / H) * S;
     int lane_f = lane;                         // (opaque: the strips' per-lane offsets are recomputed here, not kept across the item)
@@ -889,8 +908,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     // (wide stores: 4)
 #define AVT_STRIPS_LANDED(N) do { if constexpr (OT) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(nlq), "+v"(nrs) :: "memory"); \
     else asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(ndo[0]), "+v"(ndo[1]), "+v"(no[0]), "+v"(no[1]), "+v"(nlq), "+v"(nrs) :: "memory"); } while (0)
-    if (ALL_LIVE && !(AVT_ATTN_ABL & 1)) { if (AVT_ATTN_WIDE_ST) AVT_STRIPS_LANDED(4); else AVT_STRIPS_LANDED(8); }
-    else AVT_STRIPS_LANDED(0);
+    if (ALL_LIVE && !(AVT_ATTN_ABL & 1) && !LS) { if (AVT_ATTN_WIDE_ST) AVT_STRIPS_LANDED(4); else AVT_STRIPS_LANDED(8); }
+    else AVT_STRIPS_LANDED(0);               // (LS: the stores are not issued yet -- the strips' requests are the youngest operations)
 #undef AVT_STRIPS_LANDED
     auto publish_rows = [&](float dsum) __attribute__((always_inline)) {
       dsum = gsum(dsum) * scale;
@@ -987,13 +1006,17 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
           const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false), r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
           sp[dp >> 1] = (u32x4_t){r0[0], r1[0], r0[1], r1[1]};
         }
-        bf16_t* tb = dbase + (which + 1) * D;
-        if (key_t < S && !(AVT_ATTN_ABL & 1)) {
-          bf16_t* rp = tb + (size_t)key_t * ld + (g_t >> 1) * 8;
-          *(u32x4_t*)(rp + (g_t & 1) * 16) = sp[0];
-          *(u32x4_t*)(rp + (2 + (g_t & 1)) * 16) = sp[1];
+        if constexpr (LS) { hold[2 * which] = sp[0]; hold[2 * which + 1] = sp[1]; }
+        else {
+          bf16_t* tb = dbase + (which + 1) * D;
+          if (key_t < S && !(AVT_ATTN_ABL & 1)) {
+            bf16_t* rp = tb + (size_t)key_t * ld + (g_t >> 1) * 8;
+            *(u32x4_t*)(rp + (g_t & 1) * 16) = sp[0];
+            *(u32x4_t*)(rp + (2 + (g_t & 1)) * 16) = sp[1];
+          }
         }
       });
+      if constexpr (LS) hold_base = dbase;
 #else
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -1060,6 +1083,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       *(u32x2_t*)(dswr + (c & 1) * DSB) = (u32x2_t){bd.w[0], bd.w[1]};
       *(u32x2_t*)(dswr + (c & 1) * DSB + 32) = (u32x2_t){bd.w[2], bd.w[3]};
       asm volatile("" ::: "memory");                                          // (the stores above are queued before the reads below)
+      bool held = false;
+      if constexpr (LS && c == 0) { held = hold_base != nullptr; if (held) flush_hold(); }        // the previous item's dK / dV (uniform branch)
       frag4_tr_na<0, NP>(tfq, tr0, c);                                       // Q tile: 8 reads, the youngest LDS operations of this wave
       asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(tfo[0]), "+v"(tfo[1]), "+v"(tfo[2]), "+v"(tfo[3]));   // everything older has returned: the dO fragments
 #pragma unroll
@@ -1082,7 +1107,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       lgkm_wait4(tfq[0], tfq[1], tfq[2], tfq[3]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) adk[dt] = mfma16(tfq[dt], bd.v, adk[dt]);
-      if (c == 0 && !(AVT_ATTN_ABL & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of the K tile has landed
+      if (c == 0 && !(AVT_ATTN_ABL & 2)) {                                   // this wave's share of the K tile has landed
+        if (LS && ALL_LIVE && held) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // (all but the four dK / dV stores just issued)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
 #ifdef AVT_LAB
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       AVT_BWD1_STAMP(2 + 3 * c);
@@ -1174,6 +1202,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     AVT_BWD1_STAMP(3 * NP + 2);
 #endif
   }
+  // the last item re-requested its own strips (that keeps the counted waits exact): retire those requests before anything below reuses their registers --
+  // the compiler considers them dead here, and a load landing in a register that meanwhile holds an address is a wild store (tools/isa_async_check.py found it)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(ndo[0]), "+v"(ndo[1]), "+v"(no[0]), "+v"(no[1]), "+v"(nlq), "+v"(nrs) :: "memory");
+  if constexpr (LS) { if (hold_base != nullptr) flush_hold(); }
 #ifdef AVT_LAB
   if (g_bwd1_stamps != 0 && lane == 0) {
     uint32_t* d = (uint32_t*)g_bwd1_stamps + ((size_t)blockIdx.x * 16 + wave) * 32;
