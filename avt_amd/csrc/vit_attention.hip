@@ -25,7 +25,7 @@
 #define AVT_ATTN_WIDE_ST 1
 #endif
 #ifndef AVT_ATTN_ABL               // timing-only ablations of the single-pass backward (WRONG results; tools/lab/job_r05p.sh): bit 0 no dK / dV stores,
-#define AVT_ATTN_ABL 0             // 1 no wait for the K tile in chunk 0, 2 no barrier S2, 3 no dQ products, 4 no K / V strip requests
+#define AVT_ATTN_ABL 0             // 1 no wait for the K tile in chunk 0, 2 no barrier S2, 3 no dQ products, 4 no K / V strip requests, 5 no row requests of the last chunk, 6 no scalar requests
 #endif
 // Start stagger: the persistent workgroups all start together and every item takes the same time, so all 256 CUs reach their items' ends -- the
 // dK / dV / dQ (forward: O) stores and the next strips' requests -- at the same moment; workgroup b sleeps ((b / 8) mod 32) x AVT_ATTN_STAGGER_* x 64 cycles first
@@ -870,8 +870,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     }
     // per-row scalars of rows past the sequence: the last row's (finite; they only ever meet zeros -- D[q] of such a row is 0 through the zero strips)
     const int kc = in ? key_f : S - 1;
-    nlq = dword_ld_na(lse + ((size_t)fr * H + hd) * S, (uint32_t)(kc * 4));              // raw: `* log2(e)` where it is stored to LDS
-    if (SCALED) nrs = dword_ld_na(row_scale + 2 * r0, (uint32_t)(kc * 8));
+    if (!(AVT_ATTN_ABL & 64)) {
+      nlq = dword_ld_na(lse + ((size_t)fr * H + hd) * S, (uint32_t)(kc * 4));              // raw: `* log2(e)` where it is stored to LDS
+      if (SCALED) nrs = dword_ld_na(row_scale + 2 * r0, (uint32_t)(kc * 8));
+    }
   };
 #ifdef AVT_LAB
   if (lane < 32) ((uint32_t*)((char*)(rs_s + KP) + OTB))[wave * 32 + lane] = 0u;
@@ -1031,7 +1033,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     };
     auto dma_next_rows = [&](int c) __attribute__((always_inline)) {
       // the NEXT item's Q / dO (OT: / O) rows of this chunk (4 + 4 (+ 4) LDS-DMA instructions of 8 rows), spread over the waves
-      if (has_next) {
+      if (has_next && !((AVT_ATTN_ABL & 32) && c == NP - 1)) {
         int lane_r = lane;                      // (opaque: the rows' per-lane offsets are formed here, not kept -- spilled -- across the item)
         asm volatile("" : "+v"(lane_r));
         for (int j = wv; j < (OT ? 12 : 8); j += NKT) {
