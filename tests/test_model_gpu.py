@@ -267,14 +267,15 @@ def _full_arch_vs_oracle(vitc, T, B, seed, std=0.03, tol=3e-2):
 def test_config2_full_arch_T10_every_gradient_vs_oracle():
     """BASELINE config 2 at its full architecture and T = 10 (ViT-B/16 + AVT-h 2048x6x4, C = 3806), B = 1: outputs, the three
     losses, and EVERY parameter gradient in three metrics.  Stated tolerance (bf16 activations / weights in the GEMMs, fp32
-    accumulate, vs the fp32 oracle): max-abs <= 4e-2 of the gradient's max-abs, relative L2 <= 3e-2, cosine >= 0.999 (measured worst:
+    accumulate, vs the fp32 oracle; tightened at the end of round 5): max-abs <= 3e-2 of the gradient's max-abs, relative L2 <= 2.5e-2, cosine >= 0.9995 (measured worst,
+    profiles/r05y_parity_margins.txt: 1.96e-2 / 1.72e-2 / 0.99986; round 4:
     2.7e-2 / 1.9e-2 / 0.99984)."""
     model, orc = _full_arch_vs_oracle((768, 12, 12, 224), T=10, B=1, seed=21)
     rows = _grad_report(model, orc)
     assert len(rows) > 200
     worst = (max(rows, key=lambda r: r[1]), max(rows, key=lambda r: r[2]), min(rows, key=lambda r: r[3]))
     print('worst max-abs %s\nworst rel-L2 %s\nworst cosine %s' % worst)
-    bad = [r for r in rows if r[1] > 4e-2 or r[2] > 3e-2 or r[3] < 0.999]
+    bad = [r for r in rows if r[1] > 3e-2 or r[2] > 2.5e-2 or r[3] < 0.9995]
     assert not bad, bad[:10]
 
 
@@ -287,7 +288,7 @@ def test_config4_full_arch_T15_vs_oracle():
              'backbone.model.blocks.0.norm1.weight', 'backbone.model.patch_embed.proj.weight', 'backbone.model.cls_token'}
     rows = _grad_report(model, orc, names)
     assert len(rows) == len(names)
-    bad = [r for r in rows if r[1] > 6e-2 or r[2] > 6e-2 or r[3] < 0.998]
+    bad = [r for r in rows if r[1] > 3.5e-2 or r[2] > 3e-2 or r[3] < 0.9995]      # (measured worst: 2.2e-2 / 1.8e-2 / 0.99985, profiles/r05y_parity_margins.txt; 6e-2 / 6e-2 / 0.998 until round 5)
     assert not bad, bad
 
 
@@ -311,7 +312,7 @@ def test_config5_vitl_arch_step_vs_oracle():
     """ViT-L/16 block shapes (D = 1024, H = 16, MLP 4096) x 3 layers + the full-size head, one training step, B = 1, T = 3."""
     model, orc = _full_arch_vs_oracle((1024, 3, 16, 224), T=3, B=1, seed=23)
     rows = _grad_report(model, orc)
-    bad = [r for r in rows if r[1] > 6e-2 or r[2] > 6e-2 or r[3] < 0.998]
+    bad = [r for r in rows if r[1] > 3.5e-2 or r[2] > 3e-2 or r[3] < 0.9995]      # (measured worst: 2.2e-2 / 1.8e-2 / 0.99985, profiles/r05y_parity_margins.txt; 6e-2 / 6e-2 / 0.998 until round 5)
     assert not bad, bad[:10]
 
 
