@@ -702,6 +702,7 @@ int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
     int rc = launch_8p<false, false, 2>(p, s);
     return rc ? rc : launch_reduce<4, 2, 2, 4>(p, s);
   }
+  if (!persist && (p.c2_frag || p.aux_frag)) { avt_set_error("avt_gemm_bf16: a fragment-major C2 / aux (ldc2 == 0 / ldaux == 0) needs the persistent kernel (tile 0 or 809)"); return -1; }
   if (persist) {
     // the persistent form (gemm_persist.hip) where it covers the shape and the epilogue: 0 = not covered
     int mask = 0xF;
@@ -710,6 +711,7 @@ int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
 #endif
     const int rc = (epi == 0 && a_kmajor && b_kmajor && splitk == 1) ? avt_gemm_persist(p, mask, persist == 2, s) : 0;
     if (rc != 0) return rc < 0 ? rc : 0;
+    if (p.c2_frag || p.aux_frag) { avt_set_error("avt_gemm_bf16: a fragment-major C2 / aux (ldc2 == 0 / ldaux == 0) needs the persistent kernel: ask avt_gemm_frag_ok(M, N, K) first"); return -1; }
     if (persist == 2) { avt_set_error("avt_gemm_bf16: tile 809 (persistent 8-phase kernel) covers bf16 outputs of k-major operands with N %% 256 == 0, K %% 128 == 0, >= 512 tiles and a bias / GELU / residual / saved-derivative epilogue"); return -1; }
   }
   if (epi == 0) {
@@ -1146,6 +1148,14 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
   p.res_period = res_period; p.act = act; p.out_f32 = (out_mode == 1);
   p.drop_thresh = drop_threshold(drop_p); p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed;
   p.ln_stat = ln_stat; p.ln_c = ln_c; p.stat_part = stat_part;
+  // ldc2 == 0 / ldaux == 0: the fragment-major private layout of the persistent kernel (include/avt_hip.h, gemm_persist.hip)
+  p.c2_frag = (C2 && ldc2 == 0) ? 1 : 0; p.aux_frag = (aux && ldaux == 0) ? 1 : 0;
+  if (p.c2_frag || p.aux_frag) {
+    AVT_CHECK(out_mode == 0 && a_kmajor && b_kmajor && (tile == 0 || tile == 809), "avt_gemm_bf16: a fragment-major C2 / aux needs a bf16 output, k-major operands and tile 0 | 809");
+    AVT_CHECK(!p.c2_frag || act == 1, "avt_gemm_bf16: a fragment-major C2 goes with the erf-GELU epilogue (act 1)");
+    AVT_CHECK(!p.aux_frag || act == 3, "avt_gemm_bf16: a fragment-major aux goes with the saved-derivative epilogue (act 3)");
+    AVT_CHECK(avt_gemm_frag_bytes(M, N) < 0xFFFFFFF0ull && aligned16(C2) && aligned16(aux), "avt_gemm_bf16: fragment-major tensor misaligned or larger than 4 GiB");
+  }
   if (ln_stat || ln_c || stat_part) {
     // LayerNorm folded into the GEMMs around it (avt_gemm_ln_bf16): activation epilogue of k-major operands only
     AVT_CHECK(out_mode <= 1 && a_kmajor && b_kmajor, "avt_gemm_ln_bf16: the LayerNorm-fold modes need out_mode 0 | 1 and both operands k-major");
@@ -1190,6 +1200,8 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
   if (tile == 0 && bm == 256 && (K % 64 == 0 || (!a_kmajor && !b_kmajor))) bm = 8080;      // default big-tile kernel: the 8-phase schedule, persistent where that is faster
   if (tile == 0 && bm == 8080 && epi == 2) bm = 2565;                                          // weight gradients: 4 waves of 128x128 (+2-3 % over the 8-phase kernel)
   if (tile == 0 && bm == 64 && epi == 0 && a_kmajor && b_kmajor) bm = 643;                   // all-k-major small outputs: 3-deep ring (+15-25 % on the head's data gradients)
+  AVT_CHECK(!(p.c2_frag || p.aux_frag) || bm == 8080 || bm == 809,
+            "avt_gemm_bf16: a fragment-major C2 / aux (ldc2 == 0 / ldaux == 0) needs the persistent kernel, which does not take this shape: ask avt_gemm_frag_ok(M, N, K) first");
   int nslots = 0;
   if (colsum && part) {
     // one partial row per wave row of the grid: every tile shape here has two wave rows per tile

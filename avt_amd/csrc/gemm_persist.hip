@@ -43,6 +43,21 @@ namespace {
 #ifndef PK_FULLPF
 #define PK_FULLPF 0
 #endif
+// Fragment-major second output / second operand (late round 5; EPK 8 / 9 write it, EPK 10 / 11 read it; chosen by ldc2 == 0 / ldaux == 0 in the C ABI):
+// the saved GELU' of fc1 forward (C2) is only ever read back by the fc2 data gradient (aux), a launch with the same M, N and the same 128 x 64 wave
+// tiles -- a private tensor between two such kernels needs no row-major form.  Layout: per (128-row strip, 64-column group) 4 blocks x 4 KB, block i =
+// [4 stores][64 lanes][16 B] straight from the accumulator layout (store st of lane l = rows' (j, q) pieces (st / 2, 2 (st % 2)) and (st / 2, 2 (st % 2) + 1)):
+// no LDS patch round trip for the writer, 1-KB contiguous requests and conflict-free 16-byte LDS reads for the reader.  Same-box A/B
+// (profiles/r05s_auxfrag.txt): fc1 forward -0.7 %, fc2 data gradient -2.5 % per launch, the step +0.3 %.
+constexpr bool epk_gelu(int e) { return e == 1 || e == 6 || e == 8 || e == 9; }
+constexpr bool epk_fold(int e) { return e == 5 || e == 6 || e == 9; }
+constexpr bool epk_aux(int e) { return e == 3 || e == 7 || e == 10 || e == 11; }
+constexpr bool epk_scale(int e) { return e == 7 || e == 11; }
+constexpr bool epk_fragw(int e) { return e == 8 || e == 9; }
+constexpr bool epk_fragr(int e) { return e == 10 || e == 11; }
+#ifndef AVT_PK_ABL      // timing-only ablations of the epilogues (lab builds: 1 = no GELU table gathers, 2 = the output stores stay in L2, 4 = no LDS patch round trip)
+#define AVT_PK_ABL 0
+#endif
 constexpr int PK_HALF = 128 * 64 * 2;                      // one half-tile slot of the ring: 16 KB
 // Longer reductions stay with gemm_8p_kernel unless the caller forces tile 809: what the persistent form removes is per-TILE time (fill,
 // store drain, workgroup turn-over: 12-20 % of a K = 768 tile, 2-4 % of a K = 3072 tile), and the step runs at the board's power limit --
@@ -110,6 +125,9 @@ struct PkStore {
     voff = (uint32_t)(lane >> 3) * ld2 + (uint32_t)(lane & 7) * 16u;
   }
   __device__ __forceinline__ void st(int row8, u32x4_t v) const {      // row8 = first row of the 8-row group (wave-uniform)
+#if AVT_PK_ABL & 2      // timing-only ablation: every output store lands in the tile's first 8 rows (no HBM write stream: the lines stay in L2)
+    row8 = 0;
+#endif
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + (uint32_t)row8 * ld2, 0, AVT_ST_AUX);
   }
 };
@@ -121,7 +139,11 @@ __device__ __forceinline__ void pk_store_block(const char* patch_c, const char* 
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + rl;
+#if AVT_PK_ABL & 4
+    const u32x2_t lo = {(uint32_t)row, (uint32_t)pc}, hi = {(uint32_t)lane, (uint32_t)i32};
+#else
     const u32x2_t lo = *(const u32x2_t*)(patch_c + patch_rd(row, pc, 0)), hi = *(const u32x2_t*)(patch_c + patch_rd(row, pc, 1));
+#endif
     u32x2_t lo2 = lo, hi2 = hi;
     if (TWO) { lo2 = *(const u32x2_t*)(patch_d + patch_rd(row, pc, 0)); hi2 = *(const u32x2_t*)(patch_d + patch_rd(row, pc, 1)); }
     sc.st(i32 + it * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
@@ -187,7 +209,7 @@ __device__ __forceinline__ void pk_gelu_fix(const f32x16_t* blk, const float* bi
 }
 // EPK 1: C = GELU(acc + bias), C2 = GELU'(acc + bias), both by the LDS table (see gemm_tile.hpp: epi_fast_block, TAB)
 // (one patch, used twice: GELU rows out, then GELU' rows out)
-template <bool FOLD>
+template <bool FOLD, bool FRAGW>
 __device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const EpiBlk<2> blk_, char* patch, const float* bias_l,
                                                   int lane, int i32, const PkStore& sc, const PkStore& sd, const char* tab, f32x2_t rs) {
   const f32x2_t rr = (f32x2_t){rs[0], rs[0]}, tt = (f32x2_t){rs[1], rs[1]};
@@ -216,8 +238,12 @@ __device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const Epi
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+#if AVT_PK_ABL & 1      // timing-only ablation: no table gathers (wrong values)
+      e[2 * k] = off[k]; e[2 * k + 1] = off[k] ^ 0x55u;
+#else
       e[2 * k] = *(const uint32_t*)(tab + (off[k] & 0xffffu));
       e[2 * k + 1] = *(const uint32_t*)(tab + (off[k] >> 16));
+#endif
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -231,7 +257,25 @@ __device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const Epi
   const bool big = __any((mx[0] > HI) | (mx[1] > HI));          // some value of this block lies above the table: patch those elements
   if (__builtin_expect(big, 0)) pk_gelu_fix<0, FOLD>(blk, bias_l, patch, ml, h, rs);
   pk_store_block<false>(patch, patch, lane, i32, sc, sc);
-  if (p.C2) {                                                    // the same patch again for the derivative (the LDS pipe runs a wave's operations in order)
+  if constexpr (FRAGW) {                                         // fragment-major derivative: straight from the registers (file comment)
+    if (__builtin_expect(big, 0)) {                              // (rare: the exact values of the elements above the table, through the lane's own patch positions)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *(u32x2_t*)(patch + patch_wr(ml, h, j, q)) = dd[j][q];
+      pk_gelu_fix<1, FOLD>(blk, bias_l, patch, ml, h, rs);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dd[j][q] = *(const u32x2_t*)(patch + patch_wr(ml, h, j, q));
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int j = st >> 1, q0 = 2 * (st & 1);
+      __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){dd[j][q0][0], dd[j][q0][1], dd[j][q0 + 1][0], dd[j][q0 + 1][1]}, sd.r,
+                                             sd.voff + (uint32_t)(i32 * 128 + st * 1024), 0, AVT_ST_AUX);
+    }
+  } else if (p.C2) {                                                    // the same patch again for the derivative (the LDS pipe runs a wave's operations in order)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -240,17 +284,23 @@ __device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const Epi
     pk_store_block<false>(patch, patch, lane, i32, sd, sd);
   }
 }
-template <bool FOLD>
+template <bool FOLD, bool FRAGW>
 __device__ __forceinline__ void pk_epi_gelu(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, const float* bias_l,
                                             int lane, int row0, int col0, const char* tab, int mrem, const f32x2_t (&rst)[4]) {
   PkStore sc, sd;
   sc.init((bf16_t*)p.C + (size_t)row0 * p.ldc + col0, p.ldc, lane, mrem);
-  sd.init(p.C2 ? p.C2 + (size_t)row0 * p.ldc2 + col0 : (bf16_t*)p.C, p.ldc2, lane, mrem);
+  if constexpr (FRAGW) {
+    // the wave's 16 KB of the fragment-major tensor; a strip wholly past M writes nothing (empty descriptor)
+    sd.r = pk_uniform_rsrc((const char*)p.C2 + ((size_t)(row0 >> 7) * (size_t)(p.N >> 6) + (size_t)(col0 >> 6)) * 16384, mrem > 0 ? 16384u : 0u);
+    sd.voff = (uint32_t)lane * 16u; sd.ld2 = 0u;
+  } else {
+    sd.init(p.C2 ? p.C2 + (size_t)row0 * p.ldc2 + col0 : (bf16_t*)p.C, p.ldc2, lane, mrem);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {          // (unrolled: a single copy of the block's code would need the block moved into place -- 32 more registers)
     EpiBlk<2> b;
     b.t[0] = acc[i][0]; b.t[1] = acc[i][1];
-    pk_epi_gelu_block<FOLD>(p, b, patch, bias_l, lane, i * 32, sc, sd, tab, rst[i]);
+    pk_epi_gelu_block<FOLD, FRAGW>(p, b, patch, bias_l, lane, i * 32, sc, sd, tab, rst[i]);
   }
 }
 
@@ -259,7 +309,18 @@ __device__ __forceinline__ void pk_epi_gelu(const GemmParams& p, const f32x16_t 
 struct PkOperand {
   __amdgpu_buffer_rsrc_t r; int ld;
   __device__ __forceinline__ void init(const bf16_t* ptr, int ld_) { r = __builtin_amdgcn_make_buffer_rsrc((void*)ptr, 0, 0xFFFFFFF0u, 0x00020000); ld = ld_; }
+  // FRAG: the operand is stored fragment-major (file comment): block i of the wave's (strip, column group) is 4 KB, instruction itr takes 1 KB of it
+  int nq;                                                      // N / 64 (FRAG)
+  template <bool FRAG = false>
   __device__ __forceinline__ void dma_block(char* buf, int lane, int row0, int col0, int i, int mrem) const {
+    if constexpr (FRAG) {
+      uint32_t off = (uint32_t)((((size_t)(row0 >> 7) * (size_t)nq + (size_t)(col0 >> 6)) * 4 + (size_t)i) * 4096) + (uint32_t)lane * 16u;
+      if (mrem <= 0) off = 0xFFFFFFF0u;                        // a strip wholly past M: zeros
+#pragma unroll
+      for (int itr = 0; itr < 4; ++itr)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(buf + itr * 1024), 16, off == 0xFFFFFFF0u ? off : off + (uint32_t)(itr * 1024), 0, 0, AVT_LDP_AUX);
+      return;
+    }
     const int rl = lane >> 3, pc = lane & 7;
 #pragma unroll
     for (int itr = 0; itr < 4; ++itr) {
@@ -283,7 +344,7 @@ struct PkOperand {
 template <int EPK>
 __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&acc)[4][2], char* patch, char* buf0, char* buf1,
                                           const PkOperand& op, float bias_v, int lane, int row0, int col0, int* tkt, int mrem) {
-  constexpr bool RES = (EPK == 2 || EPK == 4), STATS = (EPK == 4), SCALE = (EPK == 7);
+  constexpr bool RES = (EPK == 2 || EPK == 4), STATS = (EPK == 4), SCALE = epk_scale(EPK), FRAGR = epk_fragr(EPK);
   constexpr int NST = STATS ? 5 : 4;       // stores per block
   int tk = 0x7fffffff;
   const int ml = lane & 31, h = lane >> 5;
@@ -298,7 +359,7 @@ __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&
       rst[i] = *(const f32x2_t*)(p.ln_stat + 2 * (size_t)(mrow < p.M ? mrow : p.M - 1));
     }
   }
-  op.dma_block(buf1, lane, row0, col0, 1, mrem);
+  op.template dma_block<FRAGR>(buf1, lane, row0, col0, 1, mrem);
   f32x4_t bb[2][4];
   if (RES) {          // the bias strip goes through the (still unused) patch once: lane l holds bias[col0 + l]
     ((float*)patch)[lane] = bias_v;
@@ -344,14 +405,22 @@ __device__ __forceinline__ int pk_epi_ext(const GemmParams& p, const f32x16_t (&
     }
     const char* buf = (i & 1) ? buf1 : buf0;
     u32x2_t opv[2][4];
+    if constexpr (FRAGR) {
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const u32x4_t v = *(const u32x4_t*)(buf + st * 1024 + lane * 16);
+        opv[st >> 1][2 * (st & 1)] = (u32x2_t){v[0], v[1]}; opv[st >> 1][2 * (st & 1) + 1] = (u32x2_t){v[2], v[3]};
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         opv[j][q] = *(const u32x2_t*)(buf + ml * 128 + (((j * 4 + q) ^ ((ml >> 1) & 7)) * 16) + h * 8);
+    }
     if (i + 2 < 4) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the buffer's previous contents are in registers
-      op.dma_block((i & 1) ? buf1 : buf0, lane, row0, col0, i + 2, mrem);
+      op.template dma_block<FRAGR>((i & 1) ? buf1 : buf0, lane, row0, col0, i + 2, mrem);
     }
     const f32x2_t rr = SCALE ? (f32x2_t){rst[SCALE ? i : 0][0], rst[SCALE ? i : 0][0]} : (f32x2_t){1.f, 1.f};
     u32x4_t stw = {0u, 0u, 0u, 0u};
@@ -417,9 +486,9 @@ __device__ __forceinline__ uint32_t pk_div(uint32_t n, uint32_t d, uint32_t mg) 
 template <int EPK>
 __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_arg, int* __restrict__ sched) {
   constexpr int BK = 64, HALF = PK_HALF;
-  constexpr bool GELU = (EPK == 1 || EPK == 6), FOLD = (EPK == 5 || EPK == 6), AUX = (EPK == 3 || EPK == 7);
+  constexpr bool GELU = epk_gelu(EPK), FOLD = epk_fold(EPK), AUX = epk_aux(EPK);
   constexpr int TABB = GELU ? GELU_TAB_BYTES : 0;
-  constexpr bool HAS_OP = (EPK == 2 || EPK == 3 || EPK == 4 || EPK == 7);
+  constexpr bool HAS_OP = (EPK == 2 || EPK == 4 || AUX);
   constexpr bool FULLPF = !HAS_OP && PK_FULLPF;
   extern __shared__ __attribute__((aligned(16))) char smem8[];
   char* const lds = smem8 + TABB;                       // the ring: 8 half-tile slots (kind x K-tile parity), as in gemm_8p_kernel
@@ -566,7 +635,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
 
   const bool two_outputs = p.C2 != nullptr;
   PkOperand op;
-  if (HAS_OP) op.init(AUX ? p.aux : p.res, AUX ? p.ldaux : p.ldres);
+  if (HAS_OP) { op.init(AUX ? p.aux : p.res, AUX ? p.ldaux : p.ldres); op.nq = p.N >> 6; }
 
 #define P8_BARRIER() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define P8_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -673,7 +742,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
       read_a(fa, 1, 1); P8_PIN();
       if (!last || FULLPF) { stage_a(0, t + 3); wait_vmcnt<6>(); }
       else {
-        if (HAS_OP) op.dma_block(P2, pk_lane_id(), m0_e, n0_e, 0, mrem);          // the epilogue's second operand, block 0 -> behind the ring
+        if (HAS_OP) op.template dma_block<epk_fragr(EPK)>(P2, pk_lane_id(), m0_e, n0_e, 0, mrem);          // the epilogue's second operand, block 0 -> behind the ring
       }
       P8_BARRIER();
       P8_MFMA(fa, fb1, 2, 1); P8_BARRIER();
@@ -714,7 +783,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
         tk = pk_ticket(tkt, lane_e);
         ((float*)P2)[lane_e] = bias_v;
         if (FOLD) ((float*)P2)[64 + lane_e] = c_v;
-        pk_epi_gelu<FOLD>(pe, acc, P1, (const float*)P2, lane_e, m0_e, n0_e, smem8, mrem, rst);
+        pk_epi_gelu<FOLD, epk_fragw(EPK)>(pe, acc, P1, (const float*)P2, lane_e, m0_e, n0_e, smem8, mrem, rst);
       } else {
         tk = pk_epi_ext<EPK>(pe, acc, P1, P2, P1 + 4096, op, bias_v, lane_e, m0_e, n0_e, tkt, mrem);
       }
@@ -804,7 +873,7 @@ int* sched_block(hipStream_t s) {
 
 template <int EPK>
 int launch_8pp(const GemmParams& p, int grid, hipStream_t s) {
-  constexpr int smem = 8 * PK_HALF + ((EPK == 1 || EPK == 6) ? GELU_TAB_BYTES + 8192 : 32768);
+  constexpr int smem = 8 * PK_HALF + (epk_gelu(EPK) ? GELU_TAB_BYTES + 8192 : 32768);
   static_assert(smem <= 160 * 1024, "persistent 8-phase kernel: LDS");
   static bool attr_set = false;
   if (!attr_set) {
@@ -847,21 +916,40 @@ int avt_gemm_persist(GemmParams& p, int kinds, bool force, hipStream_t s) {
   const bool fold = p.ln_c != nullptr, scale = !fold && p.ln_stat != nullptr, stats = p.stat_part != nullptr;
   if (fold) {                                                // LayerNorm fold: bias | GELU epilogues only
     if (scale || stats || p.res || p.colsum) return 0;
+    if (p.aux_frag) return 0;
     if ((kinds & 1) && p.act == 0 && !p.C2) return launch_8pp<5>(p, grid, s);
-    if ((kinds & 2) && p.act == 1) return launch_8pp<6>(p, grid, s);
+    if ((kinds & 2) && p.act == 1) return p.c2_frag ? launch_8pp<9>(p, grid, s) : launch_8pp<6>(p, grid, s);
     return 0;
   }
   if (scale) {                                               // rows scaled by rstd: saved-derivative epilogue only
-    if ((kinds & 8) && !stats && p.act == 3 && p.aux && !p.res && !p.bias && !p.C2) return launch_8pp<7>(p, grid, s);
+    if ((kinds & 8) && !stats && p.act == 3 && p.aux && !p.res && !p.bias && !p.C2) return p.aux_frag ? launch_8pp<11>(p, grid, s) : launch_8pp<7>(p, grid, s);
     return 0;
   }
   if (stats) {                                               // row statistics out: bias + residual epilogue only
+    if (p.c2_frag || p.aux_frag) return 0;
     if ((kinds & 4) && p.act == 0 && p.res && !p.colsum && !p.C2 && p.N % 64 == 0) return launch_8pp<4>(p, grid, s);
     return 0;
   }
-  if ((kinds & 1) && p.act == 0 && !p.res && !p.colsum && !p.C2) return launch_8pp<0>(p, grid, s);
-  if ((kinds & 2) && p.act == 1 && !p.res && !p.colsum) return launch_8pp<1>(p, grid, s);
+  if ((kinds & 1) && p.act == 0 && !p.res && !p.colsum && !p.C2 && !p.aux_frag) return launch_8pp<0>(p, grid, s);
+  if ((kinds & 2) && p.act == 1 && !p.res && !p.colsum && !p.aux_frag) return p.c2_frag ? launch_8pp<8>(p, grid, s) : launch_8pp<1>(p, grid, s);
+  if (p.c2_frag) return 0;
   if ((kinds & 4) && p.act == 0 && p.res && !p.colsum && !p.C2) return launch_8pp<2>(p, grid, s);
-  if ((kinds & 8) && p.act == 3 && p.aux && !p.res && !p.bias && !p.C2) return launch_8pp<3>(p, grid, s);
+  if ((kinds & 8) && p.act == 3 && p.aux && !p.res && !p.bias && !p.C2) return p.aux_frag ? launch_8pp<10>(p, grid, s) : launch_8pp<3>(p, grid, s);
   return 0;
+}
+
+// The fragment-major private layout (file comment): bytes of such a tensor, and whether a call of this shape is taken by the persistent kernel
+// (the shape part of avt_gemm_persist's conditions and of the automatic tile choice in gemm.hip, for contiguous operands: lda = ldb = K).
+extern "C" size_t avt_gemm_frag_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (size_t)((M + 127) / 128) * 128 * (size_t)((N + 63) / 64) * 64 * 2;
+}
+extern "C" int avt_gemm_frag_ok(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (N % 256 || K % 128 || K < 256 || K > PK_KMAX) return 0;
+  const long tm = (M + 255) / 256, tn = N / 256, ntile = tm * tn;
+  if (ntile < 512 || ntile >= 65536) return 0;               // (>= 200 tiles: the automatic tile choice is the 8-phase schedule)
+  if (((uint64_t)M + 256) * (uint64_t)K * 2 >= (1ull << 32) || ((uint64_t)N + 256) * (uint64_t)K * 2 >= (1ull << 32)) return 0;
+  if (avt_gemm_frag_bytes(M, N) >= 0xFFFFFFF0ull || (uint64_t)M * (uint64_t)N * 2 >= 0xFFFFFFF0ull) return 0;
+  return 1;
 }

@@ -34,6 +34,8 @@ struct GemmParams {
   //                          sums are taken over the UNscaled values (weights ln_stat[m][1] = 1 / rstd): dY' = rstd o dY for the folded backward;
   //   stat_part != NULL: per-row partial (sum, sum of squares) of the output over each 32-column slot, [ceil(N / 64)][M][2 slots][2] fp32 -- the next LayerNorm's statistics.
   const float* ln_stat; const float* ln_c; float* stat_part;
+  // fragment-major second output / second operand (ldc2 == 0 / ldaux == 0 in the C ABI; gemm_persist.hip: the persistent kernel only)
+  int c2_frag, aux_frag;
 #ifdef AVT_LAB
   long long* dbg;                // lab only: per-block phase timestamps (s_memtime)
 #endif

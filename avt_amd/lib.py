@@ -9,7 +9,7 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AVT_HIP_LIB') or os.path.join(_HERE, 'libavt_hip.so')      # AVT_HIP_LIB: A/B a differently built library (lab use)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _P, _I, _F, _L, _U64, _SZ = c_void_p, c_int, c_float, c_long, c_uint64, ctypes.c_size_t
 
@@ -57,6 +57,7 @@ SIGNATURES = {
     'avt_video_preproc_jitter_u8': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P, _SZ, _P, _P],
     'avt_xent_fwd': [_P, _I, _P, _P, _P, _P, _I, _I, _L, _P],
     'avt_xent_bwd': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _L, _P],
+    'avt_gemm_frag_ok': [_I, _I, _I],              # (returns 1 / 0, not an error code: called through load(), not call())
     'avt_sgd_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _I, _I, _P],
     'avt_linear_softmax_xent_fwd': [_P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _L, _P],
     'avt_linear_softmax_xent_bwd': [_P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _U64, _I, _I, _I, _I, _L, _P, _SZ, _P, _SZ, _P],
@@ -70,6 +71,7 @@ N_CALLS = 0          # C-ABI calls made by this process (bench.py reports calls 
 SIZE_QUERIES = {
     'avt_gemm_accum_workspace_bytes': [_I, _I, _I],
     'avt_gemm_colsum_workspace_bytes': [_I, _I, _I],
+    'avt_gemm_frag_bytes': [_I, _I],
     'avt_layernorm_bwd_workspace_bytes': [_I, _I],
     'avt_layernorm_bwd_folded_workspace_bytes': [_I, _I],
     'avt_ln_fold_wgrad_workspace_bytes': [_I, _I],

@@ -64,6 +64,11 @@ class HipViT(nn.Module):
     # the stream.  No normalised copy is written or kept: one read + one write of [tokens, D] per LayerNorm less (ln_fwd2_kernel: 6.3 ms of a
     # 256-clip step).  False = a LayerNorm kernel in front of every projection (kept for the parity tests; the CLS-only last block always does that).
     fold_layernorm = True
+    # The GELU derivative saved by fc1 forward is read once, by the fc2 data gradient on the same kernel: where the persistent GEMM takes the shape it is
+    # kept in that kernel's fragment-major order (ops.FragTensor; include/avt_hip.h ABI 7) -- no LDS patch round trip for the writer, contiguous requests
+    # for the reader: fc1 forward -0.7 %, fc2 data gradient -2.5 % per launch, the step +0.3 % (profiles/r05s_auxfrag.txt).  Same values bit for bit.
+    # False = the row-major tensor everywhere (kept for the parity tests).
+    frag_gelu_derivative = True
 
     def __init__(self, embed_dim=768, depth=12, num_heads=12, img_size=224):
         super().__init__()
@@ -93,6 +98,13 @@ class HipViT(nn.Module):
         return _ViTFn.apply(self, arena, keep, frames, self.cls_token)   # one parameter stands in for all of them
 
 
+def _deriv_buffer(m, M, N, K, device):
+    """Where fc1 forward saves GELU'(pre): fragment-major when the persistent kernel takes both the writer and the reader (same M, N, K), else row-major."""
+    if m.frag_gelu_derivative and not ops.FORCE_TILE and ops.gemm_frag_ok(M, N, K):
+        return ops.FragTensor(M, N, device)
+    return torch.empty((M, N), device=device, dtype=torch.bfloat16)
+
+
 def _vit_forward(m: HipViT, arena, frames, keep):
     D, H, S = m.embed_dim, m.num_heads, m.seq
     N = frames.size(0)
@@ -114,7 +126,7 @@ def _vit_forward(m: HipViT, arena, frames, keep):
             att, lse = ops.vit_attn_fwd(qkv, N, S, H)
             x1 = ops.linear_fwd(att, sh(blk.attn.proj.weight), bias=blk.attn.proj.bias, res=x, stat_part=part)
             sf2, sb2 = ops.ln_stats_finalize(part, D, m.EPS, want_bwd=keep)
-            pre = torch.empty((M, 4 * D), device=x.device, dtype=torch.bfloat16) if keep else None
+            pre = _deriv_buffer(m, M, 4 * D, D, x.device) if keep else None
             act = ops.linear_fwd(x1, f2.G, bias=f2.b2, act=ops.ACT_GELU_ERF, c2=pre, ln_stat=sf2, ln_c=f2.c)
             more = bi + 1 < len(full_blocks)                                  # another folded block follows: it needs the statistics of x2
             x2 = ops.linear_fwd(act, sh(blk.mlp.fc2.weight), bias=blk.mlp.fc2.bias, res=x1, stat_part=part if more else None)
@@ -127,7 +139,7 @@ def _vit_forward(m: HipViT, arena, frames, keep):
         att, lse = ops.vit_attn_fwd(qkv, N, S, H)
         x1 = ops.linear_fwd(att, sh(blk.attn.proj.weight), bias=blk.attn.proj.bias, res=x)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, blk.norm2.weight, blk.norm2.bias, m.EPS)
-        pre = torch.empty((M, 4 * D), device=x.device, dtype=torch.bfloat16) if keep else None
+        pre = _deriv_buffer(m, M, 4 * D, D, x.device) if keep else None
         act = ops.linear_fwd(ln2, sh(blk.mlp.fc1.weight), bias=blk.mlp.fc1.bias, act=ops.ACT_GELU_ERF, c2=pre)
         x2 = ops.linear_fwd(act, sh(blk.mlp.fc2.weight), bias=blk.mlp.fc2.bias, res=x1)
         if keep:

@@ -119,6 +119,34 @@ def _ld(t):
     return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
 
 
+class FragTensor:
+    """A [M, N] bf16 tensor in the persistent GEMM's fragment-major private order (include/avt_hip.h, ABI 7: ldc2 == 0 / ldaux == 0): written by
+    gemm(act=ACT_GELU_ERF, c2=FragTensor) and read back by gemm(act=ACT_MUL_AUX, aux=FragTensor) of the same M, N -- nothing else reads it
+    (``gemm_frag_unpack`` restates the order for the tests)."""
+    __slots__ = ('buf', 'M', 'N')
+
+    def __init__(self, M, N, device):
+        self.M, self.N = M, N
+        self.buf = torch.empty(_lib.load().avt_gemm_frag_bytes(M, N) // 2, device=device, dtype=BF16)
+
+
+def gemm_frag_ok(M, N, K):
+    """Does a contiguous k-major [M, K] x [N, K] call with the automatic tile choice land on the persistent kernel (the only one that knows the
+    fragment-major order)?  Asked of the library, not mirrored here."""
+    return bool(_lib.load().avt_gemm_frag_ok(M, N, K))
+
+
+def gemm_frag_unpack(ft):
+    """Row-major [M, N] copy of a FragTensor (tests / debugging): per (128-row strip s, 64-column group c) four blocks i of [4 stores st][64 lanes l][8 values e];
+    value e of (st, l) is row 128 s + 32 i + l % 32, column 64 c + 32 (st // 2) + 8 (2 (st % 2) + e // 4) + 4 (l // 32) + e % 4."""
+    M, N = ft.M, ft.N
+    S, C = (M + 127) // 128, N // 64
+    v = ft.buf.view(S, C, 4, 4, 64, 8)                                  # s, c, i, st, l, e
+    v = v.view(S, C, 4, 2, 2, 2, 32, 2, 4)                              # s, c, i, j, qh (= st % 2), h (= l // 32), ml, ql (= e // 4), e4
+    v = v.permute(0, 2, 6, 1, 3, 4, 7, 5, 8)                            # s, i, ml | c, j, qh, ql, h, e4
+    return v.reshape(S * 128, N)[:M].contiguous()
+
+
 def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_BF16, bias=None, act=ACT_NONE,
          aux=None, c2=None, res=None, res_period=0, drop_p=0.0, seed=0, colsum=None, splitk=0, tile=0,
          ln_stat=None, ln_c=None, stat_part=None):
@@ -136,8 +164,12 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     part, part_bytes = _partials(A.device, 'avt_gemm_colsum_workspace_bytes', M, N, tile) if colsum is not None else (None, 0)
+    aux_frag, c2_frag = type(aux) is FragTensor, type(c2) is FragTensor
+    for ft in ((aux,) if aux_frag else ()) + ((c2,) if c2_frag else ()):
+        assert (ft.M, ft.N) == (M, N), 'fragment-major tensor of another shape'
     args = (_p(A), int(a_kmajor), _ld(A), _p(B), int(b_kmajor), _ld(B), _p(out), _ld(out), M, N, K,
-            _p(bias), act, _p(aux), _ld(aux) if aux is not None else 0, _p(c2), _ld(c2) if c2 is not None else 0,
+            _p(bias), act, _p(aux.buf if aux_frag else aux), 0 if aux is None or aux_frag else _ld(aux),
+            _p(c2.buf if c2_frag else c2), 0 if c2 is None or c2_frag else _ld(c2),
             _p(res), _ld(res) if res is not None else 0, res_period, float(drop_p), int(seed), _p(colsum),
             out_mode, splitk, tile, part, part_bytes)
     ln = ln_stat is not None or ln_c is not None or stat_part is not None
@@ -155,6 +187,8 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
                                       drop_p, res_period)
         if ep_ok is not None and ln:          # the LayerNorm-fold variants of the persistent kernel: 4 = 2 + statistics, 5 / 6 = 0 / 1 folded, 7 = 3 scaled
             ep_ok = {0: 5, 1: 6}.get(ep_ok) if ln_c is not None else ({3: 7}.get(ep_ok) if ln_stat is not None else ({2: 4}.get(ep_ok) if N % 64 == 0 else None))
+        if c2_frag or aux_frag:               # the fragment-major forms: 8 / 9 = 1 / 6 writing it, 10 / 11 = 3 / 7 reading it
+            ep_ok = {1: 8, 6: 9, 3: 10, 7: 11}.get(ep_ok)
         trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, ep_ok), 2.0 * M * N * K, ev0, ev1, (M, N, K)))
     return out
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 6
+#define AVT_ABI_VERSION 7
 
 const char* avt_last_error(void);
 int avt_abi_version(void);
@@ -63,6 +63,15 @@ int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kma
                   float drop_p, uint64_t drop_seed, float* colsum,
                   int out_mode, int splitk, int tile, float* partials, size_t partials_bytes, void* stream);
 size_t avt_gemm_colsum_workspace_bytes(int M, int N, int tile);
+/* Fragment-major private tensors (ABI 7).  The derivative that fc1 forward saves (C2 of act 1) is read exactly once, by the fc2 data gradient (aux of
+ * act 3) -- a launch with the same M and N on the same kernel: [timm] Mlp.fc1 + GELU and its autograd backward (models/video_classification.py:224).
+ * Such a tensor needs no row-major form.  ldc2 == 0 (with C2 != NULL, act 1) writes it, and ldaux == 0 (with aux != NULL, act 3) reads it, in the
+ * persistent kernel's own order: per (128-row strip, 64-column group) four 4-KB blocks of [4 stores][64 lanes][16 bytes] in the MFMA accumulator
+ * layout (csrc/gemm_persist.hip; avt_amd/ops.py::gemm_frag_unpack restates it for the tests).  The buffer holds avt_gemm_frag_bytes(M, N) bytes
+ * (rows padded to 128); the values are bit-identical to those of the row-major form.  Only the persistent 8-phase kernel knows the layout:
+ * avt_gemm_frag_ok(M, N, K) says whether a call of this shape (contiguous k-major operands, tile 0) lands there; a call that does not is an error. */
+size_t avt_gemm_frag_bytes(int M, int N);
+int avt_gemm_frag_ok(int M, int N, int K);
 
 /* ---- "partials": run-to-run identical parameter gradients ----------------------------------------------------------
  * Every entry point that folds many workgroups into one fp32 vector (colsum of avt_gemm_bf16, dgamma / dbeta / colsum of

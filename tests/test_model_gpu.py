@@ -620,6 +620,46 @@ def test_layernorm_fold_equals_the_layernorm_kernel_path(cls_only):
         assert e < 5e-2 and cosine(g1[n], gref) > 0.998, (n, e)
 
 
+
+def test_fragment_major_gelu_derivative_changes_no_bit_of_the_step():
+    """HipViT.frag_gelu_derivative (ABI 7: GELU' kept in the persistent GEMM's fragment-major order between fc1 forward and the fc2 data gradient) on a
+    batch large enough for the persistent kernel (170 frames x 197 tokens, width 256): the fragment-major tensors are really used, and outputs, loss
+    and EVERY parameter gradient equal those of the row-major path bit for bit."""
+    from avt_amd.models import vit as vit_mod
+    from avt_amd import ops
+    torch.manual_seed(11)
+    vit = (256, 3, 4, 224)
+    g = torch.Generator().manual_seed(12)
+    video = (torch.rand((17, 10, 3, 1, 224, 224), generator=g) * 2 - 1).cuda()
+    target = torch.randint(0, 17, (17,), generator=g).cuda()
+    sub = torch.randint(-1, 17, (17, 10, 1), generator=g).cuda()
+    ref_model = build_hip_model('vit', 256, 64, 2, 4, 17, vit=vit)
+    state = {k: v.clone() for k, v in ref_model.state_dict().items()}
+    res, kinds = {}, {}
+    old, real = vit_mod.HipViT.frag_gelu_derivative, vit_mod._deriv_buffer
+    try:
+        for frag in (False, True):
+            vit_mod.HipViT.frag_gelu_derivative = frag
+            seen = []
+            vit_mod._deriv_buffer = lambda *a, _s=seen: (_s.append(type(real(*a))), real(*a))[1]
+            model = build_hip_model('vit', 256, 64, 2, 4, 17, vit=vit)
+            model.load_state_dict(state)
+            out, losses, _, tot = hip_step(model, video, target, sub)
+            res[frag] = ({k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v)}, float(tot),
+                         {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+            kinds[frag] = seen
+    finally:
+        vit_mod.HipViT.frag_gelu_derivative, vit_mod._deriv_buffer = old, real
+    assert kinds[True] and all(k is ops.FragTensor for k in kinds[True]), kinds[True]
+    assert kinds[False] and all(k is torch.Tensor for k in kinds[False]), kinds[False]
+    (o0, t0, g0), (o1, t1, g1) = res[False], res[True]
+    assert t0 == t1
+    for k in o0:
+        assert torch.equal(o0[k], o1[k]), k
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+
+
 def test_cls_only_last_block_equals_all_token_path():
     """The last ViT block computed for the CLS rows only gives the same features and gradients as the all-token path."""
     from avt_amd.models.vit import HipViT

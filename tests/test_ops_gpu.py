@@ -303,6 +303,48 @@ def test_persistent_gemm_bit_equal_to_one_tile_per_workgroup(ops, M):
         ops.gemm(a, rnd((776, K), 0.05, 46), M, 776, K, tile=809)        # N % 256 != 0: not covered, and 809 does not fall back
 
 
+
+@pytest.mark.parametrize('M,N,K', [(43 * 256 + 77, 3072, 768),       # ragged: the last row tile has 77 live rows (one partial strip, one strip wholly past M)
+                                   (43 * 256 + 200, 3072, 768),      # ... 200 live rows (a full strip and a partial one)
+                                   (44 * 256, 3072, 768),
+                                   (33 * 256 + 5, 4096, 1024)])      # ViT-L widths
+def test_fragment_major_gelu_derivative(ops, M, N, K):
+    """ABI 7: the derivative saved by the erf-GELU epilogue in the persistent kernel's fragment-major order (ldc2 == 0; ops.FragTensor) holds the same
+    bits as the row-major C2 (ops.gemm_frag_unpack restates the order), with and without the LayerNorm fold, and the saved-derivative epilogue that
+    reads it back (ldaux == 0) gives the same bits -- outputs and column sums, plain and with the rows scaled -- as the one reading the row-major tensor."""
+    from avt_amd.lib import AvtHipError
+    assert ops.gemm_frag_ok(M, N, K)
+    a, b = rnd((M, K), 0.5, 71), rnd((N, K), 0.05, 72)
+    bias = rnd((N,), 1.0, 73, torch.float32)
+    rstd = (torch.rand(M, generator=torch.Generator().manual_seed(74)) + 0.5).cuda()
+    sf = torch.stack([rstd, -0.1 * rstd], 1).contiguous(); sb = torch.stack([rstd, 1 / rstd], 1).contiguous()
+    cvec = rnd((N,), 1.0, 75, torch.float32)
+    dy, wt = rnd((M, K), 0.5, 76), rnd((N, K), 0.05, 77)
+    for fold in (False, True):
+        kw = dict(ln_stat=sf, ln_c=cvec) if fold else {}
+        c_rm = torch.empty((M, N), device='cuda', dtype=torch.bfloat16); d_rm = torch.empty_like(c_rm)
+        ops.gemm(a, b, M, N, K, out=c_rm, bias=bias, act=ops.ACT_GELU_ERF, c2=d_rm, **kw)
+        ft = ops.FragTensor(M, N, a.device)
+        ft.buf.fill_(float('nan'))                                       # whatever the writer leaves unwritten must not matter to the reader
+        c_fr = torch.empty_like(c_rm)
+        ops.gemm(a, b, M, N, K, out=c_fr, bias=bias, act=ops.ACT_GELU_ERF, c2=ft, **kw)
+        assert torch.equal(c_fr.view(torch.int16), c_rm.view(torch.int16)), fold
+        assert torch.equal(ops.gemm_frag_unpack(ft).view(torch.int16), d_rm.view(torch.int16)), fold
+        for scaled in (False, True):
+            kw2 = dict(ln_stat=sb) if scaled else {}
+            cs0, cs1 = torch.zeros(N, device='cuda'), torch.zeros(N, device='cuda')
+            o0 = ops.gemm(dy, wt, M, N, K, act=ops.ACT_MUL_AUX, aux=d_rm, colsum=cs0, **kw2)
+            o1 = ops.gemm(dy, wt, M, N, K, act=ops.ACT_MUL_AUX, aux=ft, colsum=cs1, **kw2)
+            assert torch.equal(o1.view(torch.int16), o0.view(torch.int16)), (fold, scaled)
+            assert torch.equal(cs1, cs0) and bool(torch.isfinite(cs1).all()), (fold, scaled)
+    # a shape the persistent kernel does not take: refused by the query, and the call itself fails loudly instead of writing another layout
+    assert not ops.gemm_frag_ok(2048, N, K)
+    with pytest.raises(AvtHipError):
+        ops.gemm(a[:2048], b, 2048, N, K, bias=bias, act=ops.ACT_GELU_ERF, c2=ops.FragTensor(2048, N, a.device))
+    with pytest.raises(AvtHipError):
+        ops.gemm(a, b, M, N, K, bias=bias, act=ops.ACT_GELU_ERF, c2=ops.FragTensor(M, N, a.device), tile=808)
+
+
 CU_MASK_WORKER = r"""
 import sys, torch
 sys.path.insert(0, sys.argv[1])
