@@ -371,6 +371,39 @@ def test_gpu_clip_transform_draws_follow_the_reference_rules():
         GpuClipTransform(248, -1, 224, train=True, color_jitter_hue=0.7)
 
 
+def test_fragment_major_layout_queries_and_unpack():
+    """ABI 7 on the host: avt_gemm_frag_ok / avt_gemm_frag_bytes answer without a GPU (the shape part of the persistent kernel's routing), and
+    ops.gemm_frag_unpack is the inverse of the order csrc/gemm_persist.hip writes -- restated here element by element from the kernel's addressing
+    (strip, column group, block, store, lane, value) -> (row, column)."""
+    from avt_amd import ops, lib
+    L = lib.load()
+    assert L.avt_gemm_frag_ok(504320, 3072, 768) == 1 and L.avt_gemm_frag_ok(96 * 10 * 197, 4096, 1024) == 1      # config 2 / ViT-L at the bench's batches
+    assert L.avt_gemm_frag_ok(3 * 10 * 197, 3072, 768) == 0          # 3 clips/GPU: too few tiles for the persistent kernel
+    assert L.avt_gemm_frag_ok(504320, 3000, 768) == 0 and L.avt_gemm_frag_ok(504320, 3072, 8192) == 0 and L.avt_gemm_frag_ok(0, 3072, 768) == 0
+    assert L.avt_gemm_frag_bytes(300, 128) == 384 * 128 * 2 and L.avt_gemm_frag_bytes(256, 64) == 256 * 64 * 2
+    M, N = 300, 128
+    ft = ops.FragTensor.__new__(ops.FragTensor)
+    ft.M, ft.N = M, N
+    S, C = (M + 127) // 128, N // 64
+    buf = torch.full((S * C * 4 * 4 * 64 * 8,), -1.0)
+    want = torch.zeros((S * 128, N))
+    for s_ in range(S):
+        for c in range(C):
+            for i in range(4):
+                for st in range(4):
+                    for l in range(64):
+                        for e in range(8):
+                            j, q = st >> 1, 2 * (st & 1) + e // 4                      # pk_epi_gelu_block: store st = pieces (j, q0), (j, q0 + 1) of 4 values each
+                            row = s_ * 128 + i * 32 + (l & 31)                         # accumulator layout: lane % 32 = row of the 32-row block
+                            col = c * 64 + j * 32 + 8 * q + 4 * (l >> 5) + e % 4       # ... lane / 32 = which 4 of a piece's 8 columns
+                            idx = ((((s_ * C + c) * 4 + i) * 4 + st) * 64 + l) * 8 + e
+                            val = float(row * N + col)
+                            buf[idx] = val; want[row, col] = val
+    ft.buf = buf.to(torch.bfloat16).float()           # (values up to 49152 are not all bf16-exact: compare after the same rounding)
+    got = ops.gemm_frag_unpack(ft)
+    assert got.shape == (M, N) and torch.equal(got, want.to(torch.bfloat16).float()[:M])
+
+
 def test_gemm_variant_names_mirror_the_library_routing():
     """ops.gemm_variant names the kernel a GEMM lands on (the bench's per-kernel rows): the persistent 8-phase kernel for the big k-major
     contractions with K <= 4096 and a covered epilogue (csrc/gemm_persist.hip: avt_gemm_persist), gemm_8p_kernel for longer reductions,
