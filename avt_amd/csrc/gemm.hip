@@ -1191,7 +1191,21 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
   if (bm == 0) {
     long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (epi == 0) bm = (t256 >= 200) ? 256 : (t128 >= 192 ? 128 : 64);   // epi 1 | 2: below
+    if (epi == 0) {                                                       // epi 1 | 2: below
+      // Small token counts (late round 5, profiles/r05z_small_batch_gemm_sweep.txt: the ViT GEMMs at 3 / 8 / 16 clips per GPU, the head's at 2560 rows).
+      // All-k-major contractions: from 96 output tiles of 256 x 256 on the 8-phase kernel wins even though it leaves CUs idle (186 tiles: 27 / 66 us
+      // against 43 / 96 us on 744 tiles of 128 x 128); below that, with K <= 3072, the 3-deep 64 x 64 ring beats the 128 x 128 tiles whose 1.1-1.25
+      // rounds waste most of a second round (72 / 282 / 1116 tiles: 23.4 / 27.2 / 17.7 us at K = 768).  Longer reductions and the other layouts keep
+      // the 128 x 128 tiles there (head, 2560 x 2048 x 8192: 115 us against 125 on the 8-phase kernel and 191 on 64 x 64).
+      const bool kk = a_kmajor && b_kmajor;
+#if defined(AVT_OLD_SMALL_TILE_RULE)      // A/B build: the rule of rounds 1-5
+      bm = (t256 >= 200) ? 256 : (t128 >= 192 ? 128 : 64); (void)kk;
+#else
+      if (t256 >= 200 || (kk && K % 64 == 0 && t256 >= 96)) bm = 256;
+      else if (t128 >= 192 && !(kk && K <= 3072)) bm = 128;
+      else bm = 64;
+#endif
+    }
     else {
       long sk = ((K + 63) / 64) / 4; if (sk < 1) sk = 1; if (sk > 64) sk = 64;
       bm = (t256 * sk >= 256 && t256 < 4096) ? 256 : 128;
@@ -1219,8 +1233,9 @@ extern "C" size_t avt_gemm_colsum_workspace_bytes(int M, int N, int tile) {
   // mirrors gemm_impl's automatic tile choice for the activation epilogue; two wave rows per tile
   int BM = (tile == 64 || tile == 643) ? 64 : (tile == 128 ? 128 : 256);
   if (tile == 0) {
-    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256), t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    BM = (t256 >= 200) ? 256 : (t128 >= 192 ? 128 : 64);
+    // (the choice below 200 tiles depends on K and the layouts, which this query does not see: the 64-row bound covers every tile there)
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    BM = (t256 >= 200) ? 256 : 64;
   }
   return (size_t)(((M + BM - 1) / BM) * 2) * (size_t)N * 4;
 }

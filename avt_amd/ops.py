@@ -56,7 +56,13 @@ def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False)
         t256 = ((M + 255) // 256) * ((N + 255) // 256)
         t128 = ((M + 127) // 128) * ((N + 127) // 128)
         if epi == 0:
-            bm = 256 if t256 >= 200 else (128 if t128 >= 192 else 64)
+            kk = bool(a_kmajor) and bool(b_kmajor)
+            if t256 >= 200 or (kk and K % 64 == 0 and t256 >= 96):
+                bm = 256
+            elif t128 >= 192 and not (kk and K <= 3072):
+                bm = 128
+            else:
+                bm = 64
         else:
             sk = min(max(((K + 63) // 64) // 4, 1), 64)
             bm = 256 if (t256 * sk >= 256 and t256 < 4096) else 128

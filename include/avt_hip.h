@@ -54,7 +54,9 @@ int avt_abi_version(void);
  * an error otherwise; the automatic choice takes it for K <= 4096) | 2564 (256x128 tile, 4 waves, two workgroups per CU: k-major
  * operands, K % 32 == 0; bit-identical to 808, measured slower -- kept for experiments) force a kernel.  The automatic choice walks the
  * tiles of an activation GEMM whose B operand exceeds an XCD's 4-MB L2 (N*K*2 > 4 MB, e.g. the fc1 weight) in column strips, so that
- * the strip of B stays L2-resident (results do not depend on the tile order).  Requirements: 16-B aligned pointers, lda/ldb % 8 == 0,
+ * the strip of B stays L2-resident (results do not depend on the tile order).  Small outputs (fewer than 200 tiles of 256 x 256; the reference's own
+ * 3 clips per GPU, expts/01_ek100_avt.txt:5): all-k-major contractions take the 8-phase kernel from 96 such tiles and 64 x 64 tiles with a 3-deep ring
+ * below that when K <= 3072; everything else 128 x 128 tiles (>= 192 of them) or 64 x 64.  Requirements: 16-B aligned pointers, lda/ldb % 8 == 0,
  * K % 8 == 0 when an operand is k-major, N % 4 == 0 and ldc % 4 == 0 for out_mode 0/1. */
 int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,
                   void* C, int ldc, int M, int N, int K,

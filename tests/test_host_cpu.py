@@ -419,6 +419,13 @@ def test_gemm_variant_names_mirror_the_library_routing():
     assert ops.gemm_variant(M, 776, 768, True, True, ops.OUT_BF16, 0, True).startswith('gemm_8p_kernel')     # N % 256 != 0
     assert ops.gemm_variant(3940, 768, 768, True, True, ops.OUT_BF16, 0, True) != 'gemm_8pp_kernel'          # too few tiles
     assert ops.gemm_variant(M, 2304, 768, True, True, ops.OUT_BF16, 808, True).startswith('gemm_8p_kernel')  # forced one-tile-per-workgroup
+    # small token counts (late round 5, profiles/r05z_small_batch_gemm_sweep.txt): all-k-major outputs of 96 .. 199 tiles of 256 x 256 take the 8-phase kernel,
+    # below that the 3-deep 64 x 64 ring when K <= 3072; long reductions and the other layouts keep 128 x 128 tiles
+    assert ops.gemm_variant(8 * 1970, 768, 768, True, True, ops.OUT_BF16, 0, True).startswith('gemm_8p_kernel')       # 8 clips: 186 tiles
+    assert ops.gemm_variant(3 * 1970, 768, 3072, True, True, ops.OUT_BF16, 0, True).startswith('gemm_kernel<64,64,2,2,64,3')   # 3 clips: 72 tiles
+    assert ops.gemm_variant(2560, 2048, 8192, True, True, ops.OUT_BF16, 0, True).startswith('gemm_kernel<128,128')     # head, K = 8192
+    assert ops.gemm_variant(2560, 2048, 8192, True, False, ops.OUT_BF16, 0, True).startswith('gemm_kernel<128,128')    # head forward: B stored [K][N]
+    assert ops.gemm_variant(2560, 3072, 768, True, True, ops.OUT_BF16, 0, True).startswith('gemm_8p_kernel')           # CLS-only last block's fc1: 120 tiles
     # the epilogue kind is part of the persistent kernel's name (rocprof shows gemm_8pp_kernel<EPK>)
     ek = ops.persist_epilogue_kind
     assert ek(ops.OUT_BF16, ops.ACT_NONE, True, False, False, False, False) == 0
