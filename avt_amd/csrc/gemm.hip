@@ -1213,7 +1213,7 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
   }
   if (tile == 0 && bm == 256 && (K % 64 == 0 || (!a_kmajor && !b_kmajor))) bm = 8080;      // default big-tile kernel: the 8-phase schedule, persistent where that is faster
   if (tile == 0 && bm == 8080 && epi == 2) bm = 2565;                                          // weight gradients: 4 waves of 128x128 (+2-3 % over the 8-phase kernel)
-  if (tile == 0 && bm == 64 && epi == 0 && a_kmajor && b_kmajor) bm = 643;                   // all-k-major small outputs: 3-deep ring (+15-25 % on the head's data gradients)
+  if (tile == 0 && bm == 64 && epi == 0 && a_kmajor && (b_kmajor || (long)((M + 63) / 64) * ((N + 63) / 64) <= 256)) bm = 643;                                // small outputs of k-major rows: 3-deep ring (+15-25 % on the head's data gradients; late round 5: also with B stored [K][N] while the tiles fit one round -- the head's forward at 30 .. 160 rows: 60 -> 46 us at K = 8192; at 2560 rows the 2-deep ring is the faster one there)
   AVT_CHECK(!(p.c2_frag || p.aux_frag) || bm == 8080 || bm == 809,
             "avt_gemm_bf16: a fragment-major C2 / aux (ldc2 == 0 / ldaux == 0) needs the persistent kernel, which does not take this shape: ask avt_gemm_frag_ok(M, N, K) first");
   int nslots = 0;
@@ -1245,6 +1245,7 @@ static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kma
     case 64:  return dispatch_epi<64, 64, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 128: return dispatch_epi<128, 128, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 643: return dispatch_epi<64, 64, 2, 2, 64, 3>(p, epi, a_kmajor, b_kmajor, splitk, s);     // 3-deep ring
+    // (4- and 6-deep rings measured no better than the 3-deep one on the head's 30 .. 160-row GEMMs: profiles/r05zc_tiny_m_gemm_sweep.txt)
     case 256:                                                                                     // one barrier per K tile, dribbled LDS-DMA issued by 4 loader waves
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_epi<256, 256, 2, 4, 64, 2, true, 0, 1, 4>(p, epi, a_kmajor, b_kmajor, splitk, s);
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);

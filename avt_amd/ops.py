@@ -72,7 +72,7 @@ def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False)
             if (epi == 0 and a_kmajor and b_kmajor and epilogue_ok and N % 256 == 0 and K % 128 == 0 and 256 <= K <= PERSIST_KMAX
                     and 512 <= t256 < 65536):
                 bm = 809          # the persistent form (csrc/gemm_persist.hip: avt_gemm_persist)
-        if bm == 64 and epi == 0 and a_kmajor and b_kmajor:
+        if bm == 64 and epi == 0 and a_kmajor and (b_kmajor or ((M + 63) // 64) * ((N + 63) // 64) <= 256):
             bm = 643
     shape = {2564: '4w', 64: '64,64,2,2,64,2,0', 128: '128,128,2,2,64,2,0', 256: '256,256,2,4,64,2,1', 512: 'pp', 258: 'deepa', 2568: '256,256,2,4,64,2,1,l8', 808: '8p', 809: '8pp', 643: '64,64,2,2,64,3,0'}[bm]
     if bm == 2564:
