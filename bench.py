@@ -17,7 +17,8 @@ synthetic batch already resident in HBM.  Rank 0 prints ONE JSON lin
              of every launch in the timed region / their summed HIP-event durations.  ``traffic`` = HBM bytes per step from
              the committed rocprofv3 PMC pass over the same workload (profiles/pmc_step.json; null when none matches)
   also       (N = 1) short runs of BASELINE configs 4 and 5 at their own architecture on this GPU, carried inside the same line:
-             T = 15 frames (128 clips) and ViT-L/16 (96 clips), 2 warm-up + 5 timed steps each -> value, ms_per_step, frac
+             T = 15 frames (128 clips) and ViT-L/16 (96 clips), config 2 at 64 clips and at the reference's own 3 clips per GPU,
+             2 warm-up + 5 timed steps each -> value, ms_per_step, frac
   comm       (N > 1) per-rank exchange accounting, the RCCL / NCCL environment knobs in effect, and the GEMM family's time per
              step with and without collectives in flight (CU contention from RCCL's kernels shows up as the difference)
   cpu_baseline  the fp32 CPU oracle (a port of the reference's timm/HF path, oracle/avt_oracle.py) timed on this box's
@@ -409,20 +410,24 @@ def main(argv=None):
         for label, kw in (('config 4: ViT-B/16 + AVT-h, T = 15', dict(frames=15, batch=max(1, args.batch // 2))),
                           ('config 5: ViT-L/16 + AVT-h, T = 10', dict(model='vit_large_patch16_224', batch=max(1, args.batch * 3 // 8))),
                           # SURVEY 8d's batch list for config 2 ends at 64 clips per GPU (the reference's own runs use 3): the same model at a quarter of the headline's clips
-                          ('config 2 at a quarter of the clips: ViT-B/16 + AVT-h, T = 10', dict(batch=max(1, args.batch // 4)))):
+                          ('config 2 at a quarter of the clips: ViT-B/16 + AVT-h, T = 10', dict(batch=max(1, args.batch // 4))),
+                          # ... and at the batch the reference itself trains with (expts/01_ek100_avt.txt:5: 3 clips per GPU) -- weight-sized work (SGD, weight-gradient
+                          # slabs, the head's weights) is most of that step
+                          ('config 2 at the reference\'s own batch: ViT-B/16 + AVT-h, T = 10', dict(batch=3))):
             a2 = argparse.Namespace(**{**vars(args), **kw})
+            st2, wu2 = (20, 5) if a2.batch <= 8 and a2.batch < args.batch else (5, 2)      # (a 14-ms step needs more of them to leave its warm-up behind)
             try:
-                m2 = measure(a2, 5, 2)
+                m2 = measure(a2, st2, wu2)
             except Exception as e:                # the headline number must survive a failure of the extra runs (e.g. a box with less free HBM)
                 also.append({'config': f'{label}, {a2.batch} clips/GPU', 'error': f'{type(e).__name__}: {e}'[:300]})
                 import gc
                 gc.collect()
                 torch.cuda.empty_cache()
                 continue
-            c2 = a2.batch * 5 / m2['elapsed_local']
-            r2 = roofline_of(a2, c2, m2['trace'], max(m2['trace_steps'], 1), m2['trace_elapsed'] / max(m2['trace_steps'], 1) if m2['trace'] else m2['elapsed_local'] / 5)
+            c2 = a2.batch * st2 / m2['elapsed_local']
+            r2 = roofline_of(a2, c2, m2['trace'], max(m2['trace_steps'], 1), m2['trace_elapsed'] / max(m2['trace_steps'], 1) if m2['trace'] else m2['elapsed_local'] / st2)
             entry = {'config': f'{label}, {a2.batch} clips/GPU', 'model': a2.model, 'frames': a2.frames, 'clips_per_gpu': a2.batch,
-                     'value': round(c2, 2), 'unit': 'clips/s', 'ms_per_step': round(m2['elapsed_local'] / 5 * 1e3, 3), 'steps': 5, 'warmup': 2,
+                     'value': round(c2, 2), 'unit': 'clips/s', 'ms_per_step': round(m2['elapsed_local'] / st2 * 1e3, 3), 'steps': st2, 'warmup': wu2,
                      'frac': r2['frac'], 'executed_frac': r2['executed_frac'], 'final_loss': round(m2['loss'], 4)}
             if 'gemm_family' in r2:
                 entry['gemm_family_frac'] = r2['gemm_family']['frac']

@@ -209,7 +209,7 @@ def test_bench_two_ranks_end_to_end_over_gloo():
 
 
 def test_bench_single_gpu_line_carries_configs_4_and_5():
-    """`python bench.py` at N = 1 appends short runs of BASELINE configs 4 (T = 15) and 5 (ViT-L/16) to the ONE JSON line (`also`), and
+    """`python bench.py` at N = 1 appends short runs of BASELINE configs 4 (T = 15) and 5 (ViT-L/16) and of config 2 at two smaller batches to the ONE JSON line (`also`), and
     names the worst large GEMM row next to the family number.  Tiny batch here: a functional check of the line's shape."""
     import json
     if not torch.cuda.is_available():
@@ -222,7 +222,9 @@ def test_bench_single_gpu_line_carries_configs_4_and_5():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 1 and d['config']['clips_per_gpu'] == 8 and d['value'] > 0
     also = d['also']
-    assert [a['frames'] for a in also] == [15, 10, 10] and [a['model'] for a in also] == ['vit_base_patch16_224', 'vit_large_patch16_224', 'vit_base_patch16_224']
-    assert [a['clips_per_gpu'] for a in also] == [4, 3, 2] and all(a['value'] > 0 and 0 < a['executed_frac'] < a['frac'] for a in also)
+    # (configs 4 and 5 at half / three eighths of the clips, config 2 at a quarter of them and at the reference's own 3 clips per GPU)
+    assert [a['frames'] for a in also] == [15, 10, 10, 10]
+    assert [a['model'] for a in also] == ['vit_base_patch16_224', 'vit_large_patch16_224', 'vit_base_patch16_224', 'vit_base_patch16_224']
+    assert [a['clips_per_gpu'] for a in also] == [4, 3, 2, 3] and all(a['value'] > 0 and 0 < a['executed_frac'] < a['frac'] for a in also)
     w = d['roofline']['worst_large_gemm_row']
     assert w['tflops'] > 0 and len(w['MNK']) == 3 and w['share_of_step_time'] >= 0.02
