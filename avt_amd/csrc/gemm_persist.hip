@@ -910,7 +910,7 @@ int avt_gemm_persist(GemmParams& p, int kinds, bool force, hipStream_t s) {
 #endif
   if (p.K > kmax && !force) return 0;
   const int ntile = p.tiles_m * p.tiles_n;
-  if (ntile < 512 || ntile >= 65536) return 0;              // fewer than two tiles per CU: nothing to overlap; (the walk's reciprocals: n, d < 2^16)
+  if (ntile < 512 || ntile >= 65536) return 0;              // fewer than two tiles per CU: nothing to overlap (measured at 288 tiles: 122-133 us against 64-104 us for the one-tile kernel's GELU epilogues -- table load and set-up per workgroup for one tile each); (the walk's reciprocals: n, d < 2^16)
   if ((uint64_t)p.a_bytes + 256ull * p.lda * 2 >= (1ull << 32) || (uint64_t)p.b_bytes + 256ull * p.ldb * 2 >= (1ull << 32)) return 0;
   const int grid = 256;                                     // one workgroup per CU (a multiple of the 8 XCDs)
   const bool fold = p.ln_c != nullptr, scale = !fold && p.ln_stat != nullptr, stats = p.stat_part != nullptr;

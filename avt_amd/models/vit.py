@@ -64,6 +64,11 @@ class HipViT(nn.Module):
     # the stream.  No normalised copy is written or kept: one read + one write of [tokens, D] per LayerNorm less (ln_fwd2_kernel: 6.3 ms of a
     # 256-clip step).  False = a LayerNorm kernel in front of every projection (kept for the parity tests; the CLS-only last block always does that).
     fold_layernorm = True
+    # ... from this many token rows on.  Below, the fold loses (late round 5, profiles/r05zh_fold_small_batch.txt, same-box A/B of the whole step: without it +8.4 % at the
+    # reference's own 3 clips per GPU, +7 % at 5, +3.8 % at 8, +1 % at 16, equal at 32 = 63040 rows, -0.7 ... -0.9 % from 48 clips on): its own kernels (statistics,
+    # weight folding, the folded weight gradients' second pass: 0.7 ms per step) are batch-independent, and under the persistent GEMM's range the folded GELU epilogue
+    # of the one-tile kernel reads its table from global memory (100 against 65 us per fc1 forward at 5910 rows).  0 = fold at every size (what the parity tests run).
+    fold_min_rows = 60000
     # The GELU derivative saved by fc1 forward is read once, by the fc2 data gradient on the same kernel: where the persistent GEMM takes the shape it is
     # kept in that kernel's fragment-major order (ops.FragTensor; include/avt_hip.h ABI 7) -- no LDS patch round trip for the writer, contiguous requests
     # for the reader: fc1 forward -0.7 %, fc2 data gradient -2.5 % per launch, the step +0.3 % (profiles/r05s_auxfrag.txt).  Same values bit for bit.
@@ -98,6 +103,11 @@ class HipViT(nn.Module):
         return _ViTFn.apply(self, arena, keep, frames, self.cls_token)   # one parameter stands in for all of them
 
 
+def use_fold(m, M, D, n_full_blocks):
+    """Is the LayerNorm fold taken for ``M`` token rows of width ``D``?  (HipViT.fold_layernorm / fold_min_rows)"""
+    return bool(m.fold_layernorm) and n_full_blocks > 0 and D % 32 == 0 and D <= 2048 and M >= int(m.fold_min_rows)
+
+
 def _deriv_buffer(m, M, N, K, device):
     """Where fc1 forward saves GELU'(pre): fragment-major when the persistent kernel takes both the writer and the reader (same M, N, K), else row-major."""
     if m.frag_gelu_derivative and not ops.FORCE_TILE and ops.gemm_frag_ok(M, N, K):
@@ -111,7 +121,7 @@ def _vit_forward(m: HipViT, arena, frames, keep):
     M = N * S
     sh = arena.sh
     full_blocks = m.blocks[:-1] if m.cls_only_last_block else m.blocks
-    fold = bool(m.fold_layernorm) and len(full_blocks) > 0 and D % 32 == 0 and D <= 2048
+    fold = use_fold(m, M, D, len(full_blocks))
     patches = ops.im2col_patch16(frames)
     R = ops.posres_prep(m.pos_embed, m.cls_token, m.patch_embed.proj.bias, S, D)
     part = ops.ln_stat_part(M, D, frames.device) if fold else None          # the next LayerNorm's statistics, emitted by the GEMM that writes its input

@@ -404,6 +404,24 @@ def test_fragment_major_layout_queries_and_unpack():
     assert got.shape == (M, N) and torch.equal(got, want.to(torch.bfloat16).float()[:M])
 
 
+def test_layernorm_fold_threshold():
+    """HipViT folds LayerNorm into the qkv / fc1 GEMMs from fold_min_rows token rows on (measured crossover: 32 clips x 10 frames x 197 tokens; below it the
+    unfolded path is faster, profiles/r05zh_fold_small_batch.txt); fold_layernorm = False switches it off everywhere, fold_min_rows = 0 on everywhere."""
+    from avt_amd.models import vit
+    class M: pass
+    m = M(); m.fold_layernorm = True; m.fold_min_rows = 60000          # the product's defaults, restated (the autouse fixture zeroes the class attribute in here)
+    assert vit.HipViT.fold_layernorm is True and vit.HipViT.fold_min_rows == 0
+    assert not vit.use_fold(m, 3 * 10 * 197, 768, 11) and not vit.use_fold(m, 24 * 10 * 197, 768, 11)
+    assert vit.use_fold(m, 32 * 10 * 197, 768, 11) and vit.use_fold(m, 256 * 10 * 197, 768, 11) and vit.use_fold(m, 96 * 10 * 197, 1024, 23)
+    assert not vit.use_fold(m, 256 * 10 * 197, 768, 0) and not vit.use_fold(m, 256 * 10 * 197, 4096, 11)
+    m.fold_layernorm = False
+    assert not vit.use_fold(m, 256 * 10 * 197, 768, 11)
+    m.fold_layernorm, m.fold_min_rows = True, 0
+    assert vit.use_fold(m, 20, 256, 2)
+    import inspect
+    assert 'fold_min_rows = 60000' in inspect.getsource(vit.HipViT)
+
+
 def test_gemm_variant_names_mirror_the_library_routing():
     """ops.gemm_variant names the kernel a GEMM lands on (the bench's per-kernel rows): the persistent 8-phase kernel for the big k-major
     contractions with K <= 4096 and a covered epilogue (csrc/gemm_persist.hip: avt_gemm_persist), gemm_8p_kernel for longer reductions,
