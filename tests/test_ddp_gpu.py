@@ -54,6 +54,19 @@ if rank == 0:
     torch.save({k: v.cpu() for k, v in model.state_dict().items()}, sys.argv[2])
 if world > 1:
     assert tr.reducer is not None and tr.reducer.launched >= 1
+    if os.environ.get('AVT_TEST_CHECK_COMM'):
+        # world-size arithmetic of the exchange (bucket edges on 64 * world elements, at most one early tail flush, every gradient byte sent exactly once,
+        # every rank ends on the same parameters bit for bit)
+        r, a = tr.reducer, model.arena
+        st = r.stats()
+        assert r.bucket_elems % (64 * world) == 0 and r.bucket_elems == (64 << 10) // 4 // (64 * world) * (64 * world), r.bucket_elems
+        assert st['bytes_per_step'] == a.total * 4, (st, a.total)
+        full = a.total // r.bucket_elems
+        assert full - 1 <= st['buckets_per_step'] <= full + 2, (st, full, r._tail_sent)      # full buckets (+ the early tail flush) + finish()'s head
+        assert st['mode'] == os.environ.get('AVT_TEST_REDUCE_MODE', 'all_reduce') and st['comm_exposed_ms'] >= 0.0, st
+        hi, lo = a.master.detach().clone(), a.master.detach().clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX); dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        assert torch.equal(hi, lo), 'the replicas drifted apart'
     if backend == 'nccl':                  # the ranks RCCL connected, counted on the devices
         one = torch.ones(1, device='cuda'); dist.all_reduce(one); assert int(one.item()) == world
     dist.barrier(); dist.destroy_process_group()
@@ -83,6 +96,40 @@ def test_two_rank_training_matches_single_process(tmp_path):
         e = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-12))
         worst = max(worst, e)
         assert e < 2e-2, (k, e)          # bf16 activations; batch split changes rounding, not the maths
+
+
+@pytest.mark.parametrize('mode', ['all_reduce', 'rs_ag'])
+def test_eight_rank_training_on_one_gpu_matches_single_process(tmp_path, mode):
+    """BASELINE config 3's world size without its node: EIGHT ranks of the real Trainer share cuda:0 over gloo, 2 clips per rank, both exchange forms --
+    the parameters after three steps equal the single-process run on the 16 clips, and every rank checks the exchange's world-8 arithmetic itself
+    (AVT_TEST_CHECK_COMM in the worker: bucket edges on 64 * 8 elements, the bucket count, arena.total * 4 payload bytes, identical replicas).
+    The first RCCL run on a real node then cannot fail on world-size arithmetic (func/train.py:771-778)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    _run(1, tmp_path / 'single.pt', tmp_path, 29581, AVT_TEST_CLIPS='16')
+    _run(8, tmp_path / 'ddp8.pt', tmp_path, 29582 + (mode == 'rs_ag'), AVT_TEST_CLIPS='16', AVT_TEST_REDUCE_MODE=mode, AVT_TEST_CHECK_COMM='1')
+    a, b = torch.load(tmp_path / 'single.pt'), torch.load(tmp_path / 'ddp8.pt')
+    for k in a:
+        e = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-12))
+        assert e < 2e-2, (k, e, mode)
+
+
+def test_bench_eight_ranks_end_to_end_over_gloo():
+    """`python bench.py --gpus 8 --backend gloo --batch 2`: the driver's 8-GPU command line with the ranks sharing the one device -- ONE JSON line with
+    n_gpus = 8, global batch 16, dp8, eight per-rank rates and eight exchange records.  A functional check, not a measurement."""
+    import json
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--backend', 'gloo', '--batch', '2', '--steps', '2',
+                        '--warmup', '1', '--no-cpu-baseline'], capture_output=True, text=True, timeout=1800)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['config']['global_batch'] == 16 and d['config']['parallelism'] == 'dp8' and len(d['per_rank_clips_per_s']) == 8
+    assert d['value'] > 0 and d['scaling'] == 'weak' and d['comm']['rccl_ranks_seen'] == 8 and len(d['comm']['per_rank']) == 8
+    total = d['comm']['per_rank'][0]['bytes_per_step']
+    assert all(c['buckets_per_step'] >= 1 and c['bytes_per_step'] == total for c in d['comm']['per_rank'])
 
 
 def _devices():
