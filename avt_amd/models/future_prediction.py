@@ -123,8 +123,10 @@ class AVTh(nn.Module):
     def output_dim(self):
         return self.in_features
 
-    def _decode_all(self, feats):
-        """(B, T, C) fp32 -> decoder(GPT-2(encoder(feats))) (B, T, C) fp32 through one fused autograd node."""
+    def _decode_all(self, feats, extra=None, group=None):
+        """(B, T, C) fp32 -> decoder(GPT-2(encoder(feats))) (B, T, C) fp32 through one fused autograd node.
+        extra (B, k, E): input embeddings appended behind the encoded frames (the fed-back hidden states of a roll-out WITH gradients);
+        then returns (decoded (B, T + k, C), last hidden state of the newest token (B, E))."""
         arena = get_arena(self)
         arena.refresh_shadow()
         if torch.is_grad_enabled():
@@ -133,12 +135,29 @@ class AVTh(nn.Module):
         # dropout masks are a pure function of (seed, element index): the seed mixes the process's torch seed (torch.manual_seed)
         # with a call counter, so a seeded run repeats and differently seeded runs differ
         seed = ((next(AVTh._seed_counter) * 1000003 + torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF) if self.training else 0
-        return _HeadFn.apply(self, arena, keep, self.training, seed, feats, self.encoder.weight)
+        dec, last = _HeadFn.apply(self, arena, keep, self.training, seed, feats, self.encoder.weight, extra, group or _NodeGroup(1))
+        return dec if (extra is None and group is None) else (dec, last)
 
     def _rollout(self, feats, output_len):
         arena = get_arena(self)
         arena.refresh_shadow()
         return _head_rollout(self, arena, feats.float(), output_len)
+
+    def _rollout_with_grad(self, feats, output_len):
+        """Roll-out WITH gradients (reference :168-202 in training mode, e.g. a (B, Z, C) target_shape or output_len > 1 in the config): step i
+        re-runs the differentiable head node on the T observed frames + the i fed-back hidden states instead of attending over a key / value
+        cache -- the same maths for a causal model (oracle/avt_oracle.py restates it the same way), every step's gradients accumulate into the
+        same arena ranges, and the segment is reported to the gradient exchange once, by the LAST of the nodes to run backward (_NodeGroup).
+        With dropout on, each step draws fresh masks for every position (the reference's cache keeps the masks of the step that first computed
+        a position): the same distribution, not the same stream -- parity tests run it with dropout off, as everywhere."""
+        group = _NodeGroup(output_len)
+        extra, decs = None, []
+        for step in range(output_len):
+            dec, last = self._decode_all(feats, extra=extra, group=group)                # dec (B, T + step, C)
+            decs.append(dec if step == 0 else dec[:, -1:])
+            if step + 1 < output_len:
+                extra = last.unsqueeze(1) if extra is None else torch.cat([extra, last.unsqueeze(1)], dim=1)
+        return torch.cat(decs, dim=1)
 
     def forward(self, feats, target_shape):
         addl_endpoints = {}
@@ -155,8 +174,11 @@ class AVTh(nn.Module):
             all_outputs = self._decode_all(feats)                                # reference :163-203, one GPT-2 call
         elif output_len > 1:
             if torch.is_grad_enabled():
-                raise NotImplementedError('roll-out with output_len > 1 is implemented forward-only (eval, torch.no_grad)')
-            all_outputs = self._rollout(feats, output_len)                       # reference :168-202 with the KV cache
+                if output_len + orig_len - 1 > self.gpt_model.wpe.weight.size(0):
+                    raise ValueError('roll-out longer than n_positions')
+                all_outputs = self._rollout_with_grad(feats, output_len)         # reference :168-202 with gradients: no cache, same maths
+            else:
+                all_outputs = self._rollout(feats, output_len)                   # reference :168-202 with the KV cache
         else:
             raise NotImplementedError('output_len <= 0 (no GPT-2 call) is not a configuration of the AVT experiments')
         losses = {}
@@ -177,6 +199,13 @@ class AVTh(nn.Module):
             final = torch.mean(final[:, -self.avg_last_n:, :], dim=1)
         updated_past = torch.cat([prev[:, :1, :], all_outputs[:, :(orig_len - 1)]], dim=1)   # reference :249-250
         return updated_past, final, losses, addl_endpoints
+
+
+class _NodeGroup:
+    """The head nodes of ONE AVTh.forward (1, or ``output_len`` for a roll-out with gradients): the backward that brings ``left`` to zero
+    reports the finished gradient segment."""
+    def __init__(self, n):
+        self.left = n
 
 
 class _MseShiftFn(torch.autograd.Function):
@@ -241,18 +270,25 @@ def _head_rollout(m: AVTh, arena, x, output_len):
     return torch.cat(outs, dim=1)
 
 
-def _head_forward(m: AVTh, arena, x, keep, training, seed):
-    B, T, C = x.shape
+def _head_forward(m: AVTh, arena, x, keep, training, seed, extra=None):
+    B, T0, C = x.shape
     E, H = m.inter_dim, m.n_head
     hd = E // H
     sh = arena.sh
     pe = m.embd_pdrop if training else 0.0
     pa = m.attn_pdrop if training else 0.0
     pr = m.resid_pdrop if training else 0.0
-    xb = x.reshape(B * T, C).to(torch.bfloat16).contiguous()
+    xb = x.reshape(B * T0, C).to(torch.bfloat16).contiguous()
     enc = ops.linear_fwd(xb, sh(m.encoder.weight))
+    T = T0
+    if extra is not None:                                      # fed-back hidden states behind the encoded frames (roll-out with gradients)
+        T = T0 + extra.size(1)
+        emb = torch.empty((B, T, E), device=x.device, dtype=torch.bfloat16)
+        emb[:, :T0].copy_(enc.view(B, T0, E))
+        emb[:, T0:].copy_(extra)
+        enc = emb.view(B * T, E)
     h = ops.embed_pos_fwd(enc, m.gpt_model.wpe.weight, B, T, E, pe, seed)
-    saved = {'xb': xb, 'layers': [], 'p': (pe, pa, pr), 'seed': seed}
+    saved = {'xb': xb, 'layers': [], 'p': (pe, pa, pr), 'seed': seed, 'T0': T0}
     for li, blk in enumerate(m.gpt_model.h):
         s0 = seed + 16 * (li + 1)
         l1, m1, r1 = ops.layernorm_fwd(h, blk.ln_1.weight, blk.ln_1.bias, m.ln_eps)
@@ -269,10 +305,12 @@ def _head_forward(m: AVTh, arena, x, keep, training, seed):
     lf, mf, rf = ops.layernorm_fwd(h, m.gpt_model.ln_f.weight, m.gpt_model.ln_f.bias, m.ln_eps)
     dec = ops.linear_fwd(lf, sh(m.decoder.weight), out_mode=ops.OUT_F32)
     saved['final'] = (h, mf, rf, lf)
-    return dec.view(B, T, C), (saved if keep else None)
+    return dec.view(B, T, C), lf.view(B, T, E)[:, -1].float(), (saved if keep else None)
 
 
-def _head_backward(m: AVTh, arena, saved, ddec):
+def _head_backward(m: AVTh, arena, saved, ddec, dlast=None, fire_hook=True):
+    """ddec (B, T, C): gradient of the decoded features; dlast (B, E) | None: gradient of the newest token's last hidden state (roll-out with
+    gradients).  Returns (d feats (B, T0, C), d extra (B, T - T0, E) | None)."""
     B, T, C = ddec.shape
     E, H = m.inter_dim, m.n_head
     hd = E // H
@@ -284,6 +322,8 @@ def _head_backward(m: AVTh, arena, saved, ddec):
     h, mf, rf, lf = saved['final']
     ops.linear_wgrad(dd, lf, gr(m.decoder.weight))
     dlf = ops.linear_dgrad(dd, sh(m.decoder.weight))
+    if dlast is not None:                                      # + the gradient that arrives through the next roll-out step's input
+        ops.add_rows(dlf.view(B, T * E)[:, (T - 1) * E:], dlast.to(torch.bfloat16).contiguous())
     g = m.gpt_model
     dh = ops.layernorm_bwd(dlf, h, mf, rf, g.ln_f.weight, gr(g.ln_f.weight), gr(g.ln_f.bias))
     for li in range(len(g.h) - 1, -1, -1):
@@ -308,23 +348,35 @@ def _head_backward(m: AVTh, arena, saved, ddec):
         dl1 = ops.conv1d_dgrad(dqkv, sh(blk.attn.c_attn.weight))
         dh = ops.layernorm_bwd(dl1, h, m1, r1, blk.ln_1.weight, gr(blk.ln_1.weight), gr(blk.ln_1.bias), dres=dh1)
     denc = ops.embed_pos_bwd(dh, gr(g.wpe.weight), B, T, E, pe, seed)
+    T0, dextra = saved['T0'], None
+    if T0 != T:
+        d3 = denc.view(B, T, E)
+        dextra = d3[:, T0:].float()
+        denc = d3[:, :T0].contiguous().view(B * T0, E)
     ops.linear_wgrad(denc, saved['xb'], gr(m.encoder.weight))
     dx = ops.linear_dgrad(denc, sh(m.encoder.weight), out_mode=ops.OUT_F32)
-    if hook:
+    if hook and fire_hook:
         hook(m.encoder.weight, g.ln_f.bias)
-    return dx.view(B, T, C)
+    return dx.view(B, T0, C), dextra
 
 
 class _HeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, arena, keep, training, seed, feats, anchor):
-        dec, saved = _head_forward(module, arena, feats.float(), keep, training, seed)
-        ctx.module, ctx.arena, ctx.saved = module, arena, saved
-        return dec
+    def forward(ctx, module, arena, keep, training, seed, feats, anchor, extra, group):
+        dec, last, saved = _head_forward(module, arena, feats.float(), keep, training, seed, extra)
+        ctx.module, ctx.arena, ctx.saved, ctx.group = module, arena, saved, group
+        ctx.set_materialize_grads(False)  # an unused output (the last hidden state outside a roll-out) hands backward None, not zeros
+        return dec, last
 
     @staticmethod
-    def backward(ctx, ddec):
+    def backward(ctx, ddec, dlast):
         ctx.arena.attach_grads()          # .grad views dropped between forward and backward (optimizer.zero_grad())
-        dx = _head_backward(ctx.module, ctx.arena, ctx.saved, ddec)
+        saved = ctx.saved
+        if ddec is None:                  # (only the fed-back hidden state of this roll-out step was used)
+            h = saved['final'][0]
+            B = dlast.size(0)
+            ddec = torch.zeros((B, h.size(0) // B, ctx.module.in_features), device=dlast.device, dtype=torch.float32)
+        ctx.group.left -= 1
+        dx, dextra = _head_backward(ctx.module, ctx.arena, saved, ddec, dlast, fire_hook=ctx.group.left <= 0)
         ctx.saved = None
-        return None, None, None, None, None, dx, None
+        return None, None, None, None, None, dx, None, dextra, None

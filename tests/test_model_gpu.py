@@ -393,6 +393,41 @@ def test_g8b_real_width_heads_vs_reference_golden(golden_dir, tag, H):
     assert rel(params[k].grad, g[f'grad/{k}']) < TOL_GRAD
 
 
+@pytest.mark.parametrize('tag', ['full', 'tiny'])
+def test_g12_rollout_with_gradients_vs_reference_golden(golden_dir, tag):
+    """Roll-out WITH gradients (models/future_prediction.py:168-202 in training mode; output_len 3 at the full head size, 4 at a tiny one) against the
+    reference's BaseModel + AVTh + Basic op run with HF's key / value cache: outputs, total loss, EVERY parameter's gradient norm, sampled gradients
+    (AVTh._rollout_with_grad re-runs the differentiable head node per step instead of caching: the same maths)."""
+    g = load_golden(os.path.join(golden_dir, f'g12_rollout_train_{tag}.npz'))
+    from oracle.make_golden import synth_batch
+    IN, DH, L, H, T, C, B, OL, seed = {'full': (768, 2048, 6, 4, 10, 3806, 2, 3, 61), 'tiny': (32, 64, 2, 4, 6, 17, 3, 4, 62)}[tag]
+    model = build_hip_model('feat', IN, DH, L, H, C)
+    model.future_predictor.output_len = OL
+    _fill(model)
+    video, target, sub = synth_batch(B, T, C, (IN, 1, 1, 1), seed=seed)
+    out, losses, accs, tot = hip_step(model, video.cuda(), target.cuda(), sub.cuda())
+    step = 16 if C > 64 else 1
+    assert rel(out['logits/action'], g['out/logits/action']) < TOL_OUT
+    assert rel(out['past_logits/action'][:, :, ::step], g['out/past_logits/action_sub']) < TOL_OUT
+    assert rel(out['future'], g['out/future']) < TOL_OUT and rel(out['past'], g['out/past']) < TOL_OUT
+    assert abs(float(tot) - float(g['total_loss'])) / abs(float(g['total_loss'])) < 3e-2
+    params = dict(model.named_parameters())
+    for name, p in params.items():
+        gn, ref = float(p.grad.float().norm()), float(g[f'gradnorm/{name}'])
+        assert abs(gn - ref) / (ref + 1e-12) < 6e-2, (name, gn, ref)
+    rows = T + OL - 1
+    wpe = params['future_predictor.gpt_model.wpe.weight'].grad
+    assert rel(wpe[:rows + 2, ::(8 if DH > 64 else 1)], g['grad/future_predictor.gpt_model.wpe.weight_rows']) < TOL_GRAD
+    assert float(wpe[rows:].abs().max()) == 0.0 and float(wpe[rows - 1].abs().max()) > 0.0      # the last fed-back token sits at position T + OL - 2
+    se, sc = (64, 32) if DH > 64 else (1, 1)
+    assert rel(params['future_predictor.encoder.weight'].grad[::se, ::sc], g['grad/future_predictor.encoder.weight_sub']) < TOL_GRAD
+    assert rel(params['future_predictor.decoder.weight'].grad[::sc, ::se], g['grad/future_predictor.decoder.weight_sub']) < TOL_GRAD
+    k = f'future_predictor.gpt_model.h.{L - 1}.attn.c_attn.weight'
+    assert rel(params[k].grad[::se, ::(96 if DH > 64 else 1)], g[f'grad/{k}_sub']) < TOL_GRAD
+    k = 'future_predictor.gpt_model.h.0.attn.c_attn.bias'
+    assert rel(params[k].grad, g[f'grad/{k}']) < TOL_GRAD
+
+
 def test_config5_vitl_full_depth_backward_vs_oracle(route):
     """BASELINE config 5 at its FULL depth (ViT-L/16: D = 1024, 24 layers, 16 heads + the full-size head), B = 1, T = 2: one
     training step against the fp32 oracle with gradients sampled over the whole depth (first / middle / last blocks, every kind

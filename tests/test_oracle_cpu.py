@@ -113,6 +113,33 @@ def test_g8b_real_width_heads(golden_dir, tag, H):
     assert rel(orc.future_predictor.gpt_model.h[0].attn.c_attn.bias.grad, g['grad/future_predictor.gpt_model.h.0.attn.c_attn.bias']) < 1e-4
 
 
+G12_CASES = {'full': (768, 2048, 6, 4, 10, 3806, 2, 3, 61), 'tiny': (32, 64, 2, 4, 6, 17, 3, 4, 62)}      # IN, DH, L, H, T, C, B, output_len, seed (oracle/make_golden_r6.py)
+
+
+@pytest.mark.parametrize('tag', ['full', 'tiny'])
+def test_g12_rollout_with_gradients(golden_dir, tag):
+    """models/future_prediction.py:168-202 in TRAINING mode (output_len 3 / 4: GPT-2 calls chained through HF's past_key_values, gradients through
+    every step): the oracle's cache-free restatement against the reference-generated golden -- outputs, total loss, every gradient norm, sampled gradients."""
+    g = load_golden(os.path.join(golden_dir, f'g12_rollout_train_{tag}.npz'))
+    from oracle.make_golden import synth_batch
+    IN, DH, L, H, T, C, B, OL, seed = G12_CASES[tag]
+    orc = build_oracle_model('feat', IN, DH, L, H, C, output_len=OL)
+    O.closed_form_fill_(list(orc.named_parameters()))
+    orc.train()
+    video, target, sub = synth_batch(B, T, C, (IN, 1, 1, 1), seed=seed)
+    out, losses, accs, tot = oracle_step(orc, video, target, sub)
+    assert rel(out['logits/action'], g['out/logits/action']) < 1e-4
+    assert rel(out['future'], g['out/future']) < 1e-4 and rel(out['past'], g['out/past']) < 1e-4
+    assert abs(float(tot) - float(g['total_loss'])) / abs(float(g['total_loss'])) < 1e-5
+    for n, p in orc.named_parameters():
+        assert abs(float(p.grad.norm()) - float(g[f'gradnorm/{n}'])) / (float(g[f'gradnorm/{n}']) + 1e-12) < 1e-3, n
+    wpe = orc.future_predictor.gpt_model.wpe.weight.grad
+    rows = T + OL - 1
+    assert rel(wpe[:rows + 2, ::(8 if DH > 64 else 1)], g['grad/future_predictor.gpt_model.wpe.weight_rows']) < 1e-4
+    assert float(wpe[rows:].abs().max()) == 0.0 and float(wpe[rows - 1].abs().max()) > 0.0      # the last fed-back token sits at position T + OL - 2
+    assert rel(orc.future_predictor.gpt_model.h[0].attn.c_attn.bias.grad, g['grad/future_predictor.gpt_model.h.0.attn.c_attn.bias']) < 1e-4
+
+
 def test_g6_eval_rollout_and_multicrop(golden_dir):
     """Eval path: multi-crop averaging + roll-out, oracle vs the reference's BaseModel / AVTh (HF KV cache)."""
     g = load_golden(os.path.join(golden_dir, 'g6a_rollout_multicrop_tiny.npz'))
