@@ -20,12 +20,16 @@ import random
 import torch
 
 from .. import ops
+from .patch_video import PatchVideo
 
 
 class GpuClipTransform:
     def __init__(self, scale_h, scale_w=-1, crop_size=224, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), flip_p=0.5,
                  scale_pix_val=1.0, reverse_channels=False, train=True, eval_num_crops=1, eval_flip_crops=False, color_jitter_brightness=0.0, color_jitter_contrast=0.0,
-                 color_jitter_saturation=0.0, color_jitter_hue=0.0, **_unused):
+                 color_jitter_saturation=0.0, color_jitter_hue=0.0, emit_patches=False, **_unused):
+        # emit_patches: hand the model the patch-embedding GEMM's bf16 rows (common/patch_video.py::PatchVideo) instead of the fp32 clip tensor -- the
+        # same pixels, neither the fp32 frames nor the im2col pass; single-crop outputs only (multi-crop evaluation keeps the 7-D tensor)
+        self.emit_patches = bool(emit_patches)
         # torchvision ColorJitter._check_input: value v -> range [max(0, 1 - v), 1 + v] (hue: [-v, v], v <= 0.5); None when it is a no-op
         def _rng(v, center=1.0, clip0=True):
             if isinstance(v, (tuple, list)):
@@ -136,10 +140,15 @@ class GpuClipTransform:
                     fac[b, k] = float(int(float(f) * 255) & 255) if op == 3 else float(f)   # hue: np.uint8(hue_factor * 255), the 8-bit shift
             slot_mask = sum(((1 << s) if bool((op_ids[:, s] >= 0).any()) else 0) | ((16 << s) if bool((op_ids[:, s] == 1).any()) else 0)
                             for s in range(4))                                       # host tensors: nothing is read back from the device
-            return ops.video_preproc_jitter(clips_u8.contiguous(), p, op_ids.to(clips_u8.device, non_blocking=True),
-                                            fac.to(clips_u8.device, non_blocking=True), self.crop, self.scale_pix_val, self.mean, self.std,
-                                            self.reverse_channels, max_hw=(max(q[0] for q in params), max(q[1] for q in params)),
-                                            slot_mask=slot_mask)
+            as_patches = self.emit_patches and not multi
+            out = ops.video_preproc_jitter(clips_u8.contiguous(), p, op_ids.to(clips_u8.device, non_blocking=True),
+                                           fac.to(clips_u8.device, non_blocking=True), self.crop, self.scale_pix_val, self.mean, self.std,
+                                           self.reverse_channels, max_hw=(max(q[0] for q in params), max(q[1] for q in params)),
+                                           slot_mask=slot_mask, patches=as_patches)
+            return PatchVideo(out, (len(params), T, 3, 1) + self.crop) if as_patches else out
+        if self.emit_patches and not multi:
+            return PatchVideo(ops.video_preproc(clips_u8.contiguous(), p, self.crop, self.scale_pix_val, self.mean, self.std, self.reverse_channels,
+                                                quantize_u8=self.quantize_u8, patches=True), (len(params), T, 3, 1) + self.crop)
         out = ops.video_preproc(clips_u8.contiguous(), p, self.crop, self.scale_pix_val, self.mean, self.std, self.reverse_channels,
                                 quantize_u8=self.quantize_u8)
         if multi:                                   # (B * crops, T, 3, 1, h, w) -> the model's 7-D (B, #clips, #crops, C, T', H, W)

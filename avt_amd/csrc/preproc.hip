@@ -43,39 +43,81 @@ __device__ __forceinline__ float bilerp_u8(int a00, int a01, int a10, int a11, f
   return __fmaf_rn(top, wy0, __fmul_rn(bot, wy1));
 }
 
-__global__ __launch_bounds__(256) void video_preproc_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
-                                                            const int* __restrict__ params, int T, int H, int W, int OH, int OW,
-                                                            float scale_pix, float m0, float m1, float m2, float is0, float is1,
-                                                            float is2, int reverse, int quantize, long total) {
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int x = (int)(idx % OW);
-    long r = idx / OW;
-    const int y = (int)(r % OH); r /= OH;
-    const int t = (int)(r % T);
-    const int b = (int)(r / T);
-    const int* pp = params + b * 6;
-    const int new_h = pp[0], new_w = pp[1], flip = pp[2], ci = pp[3], cj = pp[4], sb = pp[5];      // sb: source clip (several crops may share one)
-    const int yr = y + ci;
-    int xr = x + cj;
-    if (flip) xr = new_w - 1 - xr;
-    int y0, y1, x0, x1; float hy, ly, hx, lx;
-    src_index(H, new_h, yr, y0, y1, hy, ly);
-    src_index(W, new_w, xr, x0, x1, hx, lx);
-    const uint8_t* f = src + ((size_t)sb * T + t) * (size_t)H * W * 3;
-    const uint8_t* p00 = f + ((size_t)y0 * W + x0) * 3;
-    const uint8_t* p01 = f + ((size_t)y0 * W + x1) * 3;
-    const uint8_t* p10 = f + ((size_t)y1 * W + x0) * 3;
-    const uint8_t* p11 = f + ((size_t)y1 * W + x1) * 3;
-    float* o = dst + (((size_t)b * T + t) * 3) * (size_t)OH * OW + (size_t)y * OW + x;
+// one output pixel (b, t, y, x) of the crop, all three channels: traced back through crop, flip and resize to its four source pixels
+struct PreprocArgs { int T, H, W, OH, OW; float scale_pix, m0, m1, m2, is0, is1, is2; int reverse, quantize; };
+__device__ __forceinline__ void preproc_pixel(const uint8_t* __restrict__ src, const int* __restrict__ pp, const PreprocArgs& a, int t, int y, int x, float (&out)[3]) {
+  const int new_h = pp[0], new_w = pp[1], flip = pp[2], ci = pp[3], cj = pp[4], sb = pp[5];      // sb: source clip (several crops may share one)
+  const int yr = y + ci;
+  int xr = x + cj;
+  if (flip) xr = new_w - 1 - xr;
+  int y0, y1, x0, x1; float hy, ly, hx, lx;
+  src_index(a.H, new_h, yr, y0, y1, hy, ly);
+  src_index(a.W, new_w, xr, x0, x1, hx, lx);
+  const uint8_t* f = src + ((size_t)sb * a.T + t) * (size_t)a.H * a.W * 3;
+  const uint8_t* p00 = f + ((size_t)y0 * a.W + x0) * 3;
+  const uint8_t* p01 = f + ((size_t)y0 * a.W + x1) * 3;
+  const uint8_t* p10 = f + ((size_t)y1 * a.W + x0) * 3;
+  const uint8_t* p11 = f + ((size_t)y1 * a.W + x1) * 3;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int sc = reverse ? 2 - c : c;
-      float v = bilerp_u8(p00[sc], p01[sc], p10[sc], p11[sc], hx, lx, hy, ly);
-      if (quantize) v = floorf(__fmul_rn(v, 255.f)) / 255.f;
-      const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), is = c == 0 ? is0 : (c == 1 ? is1 : is2);
-      o[(size_t)c * OH * OW] = (v * scale_pix - m) * is;
-    }
+  for (int c = 0; c < 3; ++c) {
+    const int sc = a.reverse ? 2 - c : c;
+    float v = bilerp_u8(p00[sc], p01[sc], p10[sc], p11[sc], hx, lx, hy, ly);
+    if (a.quantize) v = floorf(__fmul_rn(v, 255.f)) / 255.f;
+    const float m = c == 0 ? a.m0 : (c == 1 ? a.m1 : a.m2), is = c == 0 ? a.is0 : (c == 1 ? a.is1 : a.is2);
+    out[c] = (v * a.scale_pix - m) * is;
   }
+}
+
+__global__ __launch_bounds__(256) void video_preproc_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                            const int* __restrict__ params, PreprocArgs a, long total) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int x = (int)(idx % a.OW);
+    long r = idx / a.OW;
+    const int y = (int)(r % a.OH); r /= a.OH;
+    const int t = (int)(r % a.T);
+    const int b = (int)(r / a.T);
+    float v[3];
+    preproc_pixel(src, params + b * 6, a, t, y, x, v);
+    float* o = dst + (((size_t)b * a.T + t) * 3) * (size_t)a.OH * a.OW + (size_t)y * a.OW + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[(size_t)c * a.OH * a.OW] = v[c];
+  }
+}
+
+// The same pixels written straight as the patch-embedding GEMM's rows (round 6): bf16 [frames * (P + 1)][768], row n (P + 1) = the zero CLS slot,
+// row n (P + 1) + 1 + py PW + px = patch (py, px) flattened as k = c 256 + ky 16 + kx (the Conv2d weight's (3, 16, 16) order) -- exactly what
+// avt_im2col_patch16 makes of the fp32 frames (same fp32 value, same round-to-nearest-even), without the 0.95 MB per frame of fp32 in between.
+// One thread = 8 consecutive pixels of one patch row (ky) x 3 channels: three 16-byte stores; a patch's 16 ky x 2 halves are 32 neighbouring
+// threads, so each channel's stores of a patch cover 512 contiguous bytes.  PIX(t, y, x, v[3]) yields the normalised fp32 pixel.
+template <typename PIX>
+__device__ __forceinline__ void emit_patch_rows(bf16_t* __restrict__ patches, int T, int OH, int OW, long total, PIX pix) {
+  const int PW = OW / 16, P = PW * (OH / 16);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int half = (int)(idx & 1), ky = (int)((idx >> 1) & 15);
+    const long row = idx >> 5;                                  // frame * (P + 1) + s
+    const int s = (int)(row % (P + 1));
+    const long n = row / (P + 1);                               // frame = b * T + t
+    u32x4_t w[3] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    if (s > 0) {
+      const int p = s - 1, py = p / PW, px = p % PW;
+      const int b = (int)(n / T), t = (int)(n % T);
+      const int y = py * 16 + ky, x0 = px * 16 + half * 8;
+      float v[8][3];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pix(b, t, y, x0 + i, v[i]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[c][i] = pack2bf(v[2 * i][c], v[2 * i + 1][c]);
+    }
+    bf16_t* dst = patches + (size_t)row * 768 + ky * 16 + half * 8;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *(u32x4_t*)(dst + c * 256) = w[c];
+  }
+}
+__global__ __launch_bounds__(256) void video_preproc_patches_kernel(const uint8_t* __restrict__ src, bf16_t* __restrict__ patches,
+                                                                    const int* __restrict__ params, PreprocArgs a, long total) {
+  emit_patch_rows(patches, a.T, a.OH, a.OW, total, [&](int b, int t, int y, int x, float (&v)[3]) { preproc_pixel(src, params + b * 6, a, t, y, x, v); });
 }
 // ---- ColorJitterVideo with non-zero strengths (common/transforms.py:399-421) ------------------------------------------------------
 // The reference converts the flipped, resized clip -- all frames stacked into one tall image -- to an 8-bit PIL image, runs
@@ -218,36 +260,47 @@ __global__ __launch_bounds__(256) void jitter_op_kernel(uint8_t* __restrict__ sc
     px[0] = (uint8_t)R; px[1] = (uint8_t)G; px[2] = (uint8_t)B;
   }
 }
-__global__ __launch_bounds__(256) void crop_norm_u8_kernel(const uint8_t* __restrict__ scratch, float* __restrict__ dst, const int* __restrict__ params,
-                                                           int T, int SH, int SW, int OH, int OW, float scale_pix, float m0, float m1, float m2,
-                                                           float is0, float is1, float is2, int reverse, long total) {
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int x = (int)(idx % OW);
-    long r = idx / OW;
-    const int y = (int)(r % OH); r /= OH;
-    const int t = (int)(r % T);
-    const int b = (int)(r / T);
-    const int ci = params[b * 6 + 3], cj = params[b * 6 + 4];
-    const uint8_t* px = scratch + ((((size_t)b * T + t) * SH + (y + ci)) * SW + (x + cj)) * 3;
-    float* o = dst + (((size_t)b * T + t) * 3) * (size_t)OH * OW + (size_t)y * OW + x;
+__device__ __forceinline__ void crop_norm_pixel(const uint8_t* __restrict__ scratch, const int* __restrict__ pp, const PreprocArgs& a, int SH, int SW,
+                                                int b, int t, int y, int x, float (&out)[3]) {
+  const int ci = pp[3], cj = pp[4];
+  const uint8_t* px = scratch + ((((size_t)b * a.T + t) * SH + (y + ci)) * SW + (x + cj)) * 3;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float v = (float)px[reverse ? 2 - c : c] / 255.f;
-      const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), is = c == 0 ? is0 : (c == 1 ? is1 : is2);
-      o[(size_t)c * OH * OW] = (v * scale_pix - m) * is;
-    }
+  for (int c = 0; c < 3; ++c) {
+    const float v = (float)px[a.reverse ? 2 - c : c] / 255.f;
+    const float m = c == 0 ? a.m0 : (c == 1 ? a.m1 : a.m2), is = c == 0 ? a.is0 : (c == 1 ? a.is1 : a.is2);
+    out[c] = (v * a.scale_pix - m) * is;
   }
+}
+__global__ __launch_bounds__(256) void crop_norm_u8_kernel(const uint8_t* __restrict__ scratch, float* __restrict__ dst, const int* __restrict__ params,
+                                                           PreprocArgs a, int SH, int SW, long total) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int x = (int)(idx % a.OW);
+    long r = idx / a.OW;
+    const int y = (int)(r % a.OH); r /= a.OH;
+    const int t = (int)(r % a.T);
+    const int b = (int)(r / a.T);
+    float v[3];
+    crop_norm_pixel(scratch, params + b * 6, a, SH, SW, b, t, y, x, v);
+    float* o = dst + (((size_t)b * a.T + t) * 3) * (size_t)a.OH * a.OW + (size_t)y * a.OW + x;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[(size_t)c * a.OH * a.OW] = v[c];
+  }
+}
+__global__ __launch_bounds__(256) void crop_norm_u8_patches_kernel(const uint8_t* __restrict__ scratch, bf16_t* __restrict__ patches, const int* __restrict__ params,
+                                                                   PreprocArgs a, int SH, int SW, long total) {
+  emit_patch_rows(patches, a.T, a.OH, a.OW, total, [&](int b, int t, int y, int x, float (&v)[3]) { crop_norm_pixel(scratch, params + b * 6, a, SH, SW, b, t, y, x, v); });
 }
 }  // namespace
 
 extern "C" size_t avt_video_jitter_scratch_bytes(int B, int T, int max_h, int max_w) { return (size_t)B * T * max_h * max_w * 3 + 256; }
 
-extern "C" int avt_video_preproc_jitter_u8(const void* src, float* dst, const int* params, const int* jitter_ops, const float* jitter_factors,
+extern "C" int avt_video_preproc_jitter_u8(const void* src, float* dst, void* patches, const int* params, const int* jitter_ops, const float* jitter_factors,
                                            int B, int T, int H, int W, int OH, int OW, int max_h, int max_w, float scale_pix,
                                            const float* mean3, const float* std3, int reverse_channels, int slot_mask,
                                            void* scratch, size_t scratch_bytes, unsigned long long* luma_sums, void* stream) {
-  AVT_CHECK(src && dst && params && jitter_ops && jitter_factors && mean3 && std3 && scratch && luma_sums, "avt_video_preproc_jitter_u8: null argument");
+  AVT_CHECK(src && (dst || patches) && params && jitter_ops && jitter_factors && mean3 && std3 && scratch && luma_sums, "avt_video_preproc_jitter_u8: null argument");
   AVT_CHECK(B > 0 && T > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && max_h >= OH && max_w >= OW, "avt_video_preproc_jitter_u8: bad shape");
+  AVT_CHECK(!patches || (OH % 16 == 0 && OW % 16 == 0 && aligned16(patches)), "avt_video_preproc_jitter_u8: patch rows need a crop that is a multiple of 16 and a 16-byte aligned buffer");
   AVT_CHECK(scratch_bytes >= (size_t)B * T * max_h * max_w * 3, "avt_video_preproc_jitter_u8: scratch too small (%zu bytes needed)", (size_t)B * T * max_h * max_w * 3);
   AVT_CHECK(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "avt_video_preproc_jitter_u8: zero std");
   hipStream_t s = (hipStream_t)stream;
@@ -265,27 +318,40 @@ extern "C" int avt_video_preproc_jitter_u8(const void* src, float* dst, const in
     }
     hipLaunchKernelGGL(jitter_op_kernel, dim3((int)g), dim3(256), 0, s, (uint8_t*)scratch, params, jitter_ops, jitter_factors, slot, luma_sums, T, max_h, max_w, total);
   }
-  const long tot_out = (long)B * T * OH * OW;
-  long g2 = (tot_out + 255) / 256; if (g2 > 16384) g2 = 16384;
-  hipLaunchKernelGGL(crop_norm_u8_kernel, dim3((int)g2), dim3(256), 0, s, (const uint8_t*)scratch, dst, params, T, max_h, max_w, OH, OW, scale_pix,
-                     mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2], reverse_channels, tot_out);
+  const PreprocArgs a{T, H, W, OH, OW, scale_pix, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2], reverse_channels, 0};
+  if (dst) {
+    const long tot_out = (long)B * T * OH * OW;
+    long g2 = (tot_out + 255) / 256; if (g2 > 16384) g2 = 16384;
+    hipLaunchKernelGGL(crop_norm_u8_kernel, dim3((int)g2), dim3(256), 0, s, (const uint8_t*)scratch, dst, params, a, max_h, max_w, tot_out);
+  }
+  if (patches) {
+    const long tot_p = (long)B * T * ((OH / 16) * (OW / 16) + 1) * 32;
+    long g3 = (tot_p + 255) / 256; if (g3 > 16384) g3 = 16384;
+    hipLaunchKernelGGL(crop_norm_u8_patches_kernel, dim3((int)g3), dim3(256), 0, s, (const uint8_t*)scratch, (bf16_t*)patches, params, a, max_h, max_w, tot_p);
+  }
   AVT_LAUNCH_CHECK();
   return 0;
 }
 
-namespace {
-}  // namespace
 
-extern "C" int avt_video_preproc_u8(const void* src, float* dst, const int* params, int B, int T, int H, int W, int OH, int OW,
+extern "C" int avt_video_preproc_u8(const void* src, float* dst, void* patches, const int* params, int B, int T, int H, int W, int OH, int OW,
                                     float scale_pix, const float* mean3, const float* std3, int reverse_channels, int quantize_u8,
                                     void* stream) {
-  AVT_CHECK(src && dst && params && mean3 && std3, "avt_video_preproc_u8: null argument");
+  AVT_CHECK(src && (dst || patches) && params && mean3 && std3, "avt_video_preproc_u8: null argument");
   AVT_CHECK(B > 0 && T > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "avt_video_preproc_u8: bad shape");
   AVT_CHECK(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, "avt_video_preproc_u8: zero std");
-  const long total = (long)B * T * OH * OW;
-  long g = (total + 255) / 256; if (g > 16384) g = 16384;
-  hipLaunchKernelGGL(video_preproc_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, dst, params, T, H, W,
-                     OH, OW, scale_pix, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2], reverse_channels, quantize_u8, total);
+  AVT_CHECK(!patches || (OH % 16 == 0 && OW % 16 == 0 && aligned16(patches)), "avt_video_preproc_u8: patch rows need a crop that is a multiple of 16 and a 16-byte aligned buffer");
+  const PreprocArgs a{T, H, W, OH, OW, scale_pix, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2], reverse_channels, quantize_u8};
+  if (dst) {
+    const long total = (long)B * T * OH * OW;
+    long g = (total + 255) / 256; if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(video_preproc_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, dst, params, a, total);
+  }
+  if (patches) {
+    const long tot_p = (long)B * T * ((OH / 16) * (OW / 16) + 1) * 32;
+    long g = (tot_p + 255) / 256; if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(video_preproc_patches_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (bf16_t*)patches, params, a, tot_p);
+  }
   AVT_LAUNCH_CHECK();
   return 0;
 }

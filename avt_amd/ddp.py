@@ -19,7 +19,7 @@ from .arena import ParamArena
 
 class GradReducer:
     def __init__(self, model, bucket_bytes=64 << 20, process_group=None, overlap=True, always=False, mode='all_reduce',
-                 wire_dtype=torch.float32, tail_bytes=None):
+                 wire_dtype=torch.float32, tail_bytes=None, transport='torch', comm=None):
         self.model = model
         self.arena: ParamArena = model.arena
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -31,6 +31,18 @@ class GradReducer:
         if mode not in ('all_reduce', 'rs_ag'):
             raise ValueError(f"GradReducer mode must be 'all_reduce' or 'rs_ag' (got {mode!r})")
         self.mode = mode
+        # transport 'torch': torch.distributed collectives (backend 'nccl' = RCCL; gloo for the functional checks).  'abi': the same exchange through
+        # the library's own RCCL entry points (avt_allreduce_bucket / avt_reduce_scatter_bucket / avt_allgather_bucket, include/avt_hip.h) -- what a
+        # maintainer who binds only the .so runs; ``comm`` = an avt_amd.comm.RcclComm, or None to build one over the torch group's side channel.
+        if transport not in ('torch', 'abi'):
+            raise ValueError(f"GradReducer transport must be 'torch' or 'abi' (got {transport!r})")
+        self.transport = transport
+        self.comm = comm
+        if transport == 'abi' and comm is None:
+            from .comm import RcclComm
+            self.comm = RcclComm.from_torch_group(self.arena.grad.device.index, process_group)
+        if transport == 'abi' and self.comm.nranks != max(self.world, 1):
+            raise ValueError(f'GradReducer: the RCCL communicator has {self.comm.nranks} ranks, the job {self.world}')
         # wire_dtype=torch.bfloat16: each bucket is cast to bf16, summed on the wire in bf16 and widened back into the fp32
         # buffer (half the xGMI bytes: 0.79 GB instead of 1.58 GB per step) -- an OPTION, because a bf16 sum over the
         # ranks keeps 8 bits of the gradient's mantissa; the default exchanges fp32.
@@ -75,6 +87,11 @@ class GradReducer:
         arena = model.arena
         dist.broadcast(arena.master, src=src)
         arena.refresh_shadow(force=True)
+
+    def broadcast_parameters_abi(self, src=0):
+        """The same through the C ABI's communicator (transport 'abi')."""
+        self.comm.broadcast(self.arena.master, root=src)
+        self.arena.refresh_shadow(force=True)
 
     @staticmethod
     def broadcast_optimizer_state(optimizer, src=0):
@@ -145,6 +162,13 @@ class GradReducer:
     def _exchange(self, buf):
         n = buf.numel()
         self.bytes_on_wire += n * buf.element_size()
+        if self.transport == 'abi':                             # stream-ordered RCCL calls through the C ABI, in place
+            if self.mode == 'rs_ag' and n % self.world == 0 and (n // self.world * buf.element_size()) % 16 == 0:
+                self.comm.reduce_scatter(buf)
+                self.comm.all_gather(buf)
+            else:
+                self.comm.all_reduce(buf)
+            return _Done()
         if self.mode == 'rs_ag' and n % self.world == 0:
             # (bucket edges are multiples of 64 * world, so finish()'s bucket [0, lo) and every full bucket divide; the bucket that can fail
             #  to is the one whose upper end is the arena's end -- the first full bucket or the early-tail bucket [lo, total): the arena's size
@@ -179,7 +203,7 @@ class GradReducer:
         """Per-rank exchange accounting for the bench line: buckets and payload bytes of the last step, and how long the
         optimizer had to wait for the collectives after backward had finished (``comm_exposed_ms``: mean / max over the last
         ``last`` steps; 0 when the exchange was fully hidden behind backward).  Synchronises the device."""
-        out = {'mode': self.mode, 'wire_dtype': str(self.wire_dtype).replace('torch.', ''), 'buckets_per_step': self.launched,
+        out = {'mode': self.mode, 'transport': self.transport, 'wire_dtype': str(self.wire_dtype).replace('torch.', ''), 'buckets_per_step': self.launched,
                'bytes_per_step': self.bytes_on_wire, 'bucket_bytes': self.bucket_elems * 4}
         if self._timing:
             torch.cuda.synchronize()

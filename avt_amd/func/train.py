@@ -174,7 +174,7 @@ class Trainer:
     optional (``sync_loss``) because they stall the launch queue."""
     def __init__(self, model, train_eval_op, optimizer, lr_scheduler=None, loss_wts=None, distributed=False,
                  bucket_bytes=64 << 20, grad_clip=None, force_reducer=False, reduce_mode='all_reduce',
-                 wire_dtype=torch.float32, tail_bytes=None):
+                 wire_dtype=torch.float32, tail_bytes=None, reduce_transport='torch'):
         self.model, self.op, self.optimizer, self.lr_scheduler = model, train_eval_op, optimizer, lr_scheduler
         self.loss_wts = dict(loss_wts or {})
         self.fused = isinstance(optimizer, FusedSGD)
@@ -183,9 +183,12 @@ class Trainer:
         self.norm_type = float(gc.get('norm_type', 2.0))
         self.world = utils.get_world_size() if distributed else 1
         self.reducer = GradReducer(model, bucket_bytes=bucket_bytes, always=force_reducer, mode=reduce_mode, wire_dtype=wire_dtype,
-                                   tail_bytes=tail_bytes) if (self.world > 1 or force_reducer) else None
+                                   tail_bytes=tail_bytes, transport=reduce_transport) if (self.world > 1 or force_reducer) else None
         if self.reducer is not None:
-            GradReducer.broadcast_parameters(model)
+            if reduce_transport == 'abi':                        # (the C ABI's own communicator: avt_broadcast_bucket)
+                self.reducer.broadcast_parameters_abi()
+            else:
+                GradReducer.broadcast_parameters(model)
         self.last_losses = {}
 
     def total_loss(self, losses):
@@ -261,7 +264,8 @@ def main(cfg, steps=10, batch_size=None, log_every=1, ckpt=None):
         from ..common.gpu_transforms import GpuClipTransform
         dt = cfg.data_train
         gpu_tf = GpuClipTransform(dt.scale_h, dt.scale_w, dt.crop_size, dt.mean, dt.std, dt.get('flip_p', 0.5),
-                                  dt.get('scale_pix_val', 1.0), dt.get('reverse_channels', False), train=True)
+                                  dt.get('scale_pix_val', 1.0), dt.get('reverse_channels', False), train=True,
+                                  emit_patches=cfg.get('synthetic', Cfg()).get('emit_patches', True))     # patch rows straight from the input kernel (no fp32 frames, no im2col)
         g = torch.Generator(device=device).manual_seed(cfg.get('seed', 42) + rank)
         clips_u8 = torch.randint(0, 256, (B, T, int(u8_hw[0]), int(u8_hw[1]), 3), device=device, dtype=torch.uint8, generator=g)
     start = 0
@@ -278,6 +282,10 @@ def main(cfg, steps=10, batch_size=None, log_every=1, ckpt=None):
         if rank == 0 and it % log_every == 0:
             logging.info('iter %d loss %.4f clips/s %.1f lr %.3g', it, loss, B * world / dt, optimizer.param_groups[0]['lr'])
             print(f'iter {it} loss {loss:.4f} clips/s {B * world / dt:.1f} lr {optimizer.param_groups[0]["lr"]:.3g}', flush=True)
+    if rank == 0 and gpu_tf is not None:                      # (which input kernels the run used: the uint8 pipeline's patch rows leave no im2col call)
+        from .. import lib as _abi
+        print('abi calls: avt_im2col_patch16 %d avt_video_preproc_u8 %d' % (_abi.CALLS_BY_NAME.get('avt_im2col_patch16', 0),
+                                                                            _abi.CALLS_BY_NAME.get('avt_video_preproc_u8', 0)), flush=True)
     if ckpt:
         store_checkpoint(ckpt, model, optimizer, lr_sched, start + steps / float(iters_per_epoch))
     return trainer

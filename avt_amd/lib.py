@@ -9,7 +9,7 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AVT_HIP_LIB') or os.path.join(_HERE, 'libavt_hip.so')      # AVT_HIP_LIB: A/B a differently built library (lab use)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _P, _I, _F, _L, _U64, _SZ = c_void_p, c_int, c_float, c_long, c_uint64, ctypes.c_size_t
 
@@ -53,18 +53,28 @@ SIGNATURES = {
     'avt_cls_attn_fwd': [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P],
     'avt_cls_attn_bwd': [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P],
     'avt_causal_attn_decode': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
-    'avt_video_preproc_u8': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P],
-    'avt_video_preproc_jitter_u8': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P, _SZ, _P, _P],
+    'avt_video_preproc_u8': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P],
+    'avt_video_preproc_jitter_u8': [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P, _SZ, _P, _P],
     'avt_xent_fwd': [_P, _I, _P, _P, _P, _P, _I, _I, _L, _P],
     'avt_xent_bwd': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _L, _P],
     'avt_gemm_frag_ok': [_I, _I, _I],              # (returns 1 / 0, not an error code: called through load(), not call())
     'avt_sgd_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _I, _I, _P],
     'avt_linear_softmax_xent_fwd': [_P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _L, _P],
+    # gradient exchange over RCCL (ABI 8): comm handles are void*, sizes size_t
+    'avt_comm_unique_id': [_P],
+    'avt_comm_init_rank': [_P, _I, _I, _I, _P],
+    'avt_comm_destroy': [_P],
+    'avt_comm_size': [_P, _P, _P],
+    'avt_allreduce_bucket': [_P, _P, _SZ, _I, _P],
+    'avt_reduce_scatter_bucket': [_P, _P, _SZ, _I, _P],
+    'avt_allgather_bucket': [_P, _P, _SZ, _I, _P],
+    'avt_broadcast_bucket': [_P, _P, _SZ, _I, _I, _P],
     'avt_linear_softmax_xent_bwd': [_P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _F, _U64, _I, _I, _I, _I, _L, _P, _SZ, _P, _SZ, _P],
 }
 
 _lib = None
 N_CALLS = 0          # C-ABI calls made by this process (bench.py reports calls per step: every call is one or two kernel launches)
+CALLS_BY_NAME = {}    # ... per entry point
 
 
 # workspace-size queries (return size_t, cannot fail)
@@ -116,6 +126,7 @@ def load():
 def call(name, *args):
     global N_CALLS
     N_CALLS += 1
+    CALLS_BY_NAME[name] = CALLS_BY_NAME.get(name, 0) + 1
     lib = load()
     rc = getattr(lib, name)(*args)
     if rc != 0:

@@ -4,6 +4,7 @@ network underneath is the HIP ViT (``avt_amd.models.vit.HipViT``) instead of ``t
 BNInception builders of the reference file are outside the accelerated path."""
 import torch.nn as nn
 
+from ..common.patch_video import PatchVideo
 from .vit import HipViT
 
 VIT_CONFIGS = {
@@ -18,7 +19,10 @@ VIT_CONFIGS = {
 def process_each_frame(model, video, *args, **kwargs):
     """(B, C, T, H, W) -> run ``model`` on every frame -> (B, C', T, 1, 1)   (reference :213-227)"""
     batch_size, time_dim = video.size(0), video.size(2)
-    flat = video.transpose(1, 2).flatten(0, 1)
+    if isinstance(video, PatchVideo):            # T' == 1: the frames are already in (clip, frame) order, as patch rows
+        flat = video
+    else:
+        flat = video.transpose(1, 2).flatten(0, 1)
     feats = model(flat, *args, **kwargs)
     return feats.view((batch_size, time_dim) + feats.shape[1:]).transpose(1, 2).unsqueeze(-1).unsqueeze(-1)
 
@@ -55,4 +59,6 @@ class IdentityFeatures(FrameLevelModel):
         super().__init__(num_classes)
 
     def forward(self, video):
+        if isinstance(video, PatchVideo):
+            raise TypeError('pre-extracted features cannot arrive as patch rows')
         return video

@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..arena import get_arena
+from ..common.patch_video import PatchVideo
 
 
 class _Affine(nn.Module):
@@ -91,8 +92,9 @@ class HipViT(nn.Module):
         self.grad_ready_hook = None          # callable(first_param, last_param) fired as backward finishes a segment
 
     def forward(self, frames):
-        """frames fp32 (N, 3, H, W) -> CLS features fp32 (N, D)."""
-        if tuple(frames.shape[-2:]) != (self.img_size, self.img_size) or frames.size(1) != 3:
+        """frames fp32 (N, 3, H, W) -> CLS features fp32 (N, D).  A ``PatchVideo`` (the input pipeline's patch rows) is taken as it is."""
+        patch_rows = isinstance(frames, PatchVideo)
+        if tuple(frames.shape[-2:]) != (self.img_size, self.img_size) or frames.size(-4 if patch_rows else 1) != 3:
             raise ValueError(f'HipViT was built for 3x{self.img_size}x{self.img_size} frames (pos_embed has {self.seq} '
                              f'positions), got {tuple(frames.shape[1:])}')
         arena = get_arena(self)
@@ -100,7 +102,7 @@ class HipViT(nn.Module):
         if torch.is_grad_enabled():
             arena.attach_grads()
         keep = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        return _ViTFn.apply(self, arena, keep, frames, self.cls_token)   # one parameter stands in for all of them
+        return _ViTFn.apply(self, arena, keep, frames.patches if patch_rows else frames, self.cls_token)   # one parameter stands in for all of them
 
 
 def use_fold(m, M, D, n_full_blocks):
@@ -117,12 +119,13 @@ def _deriv_buffer(m, M, N, K, device):
 
 def _vit_forward(m: HipViT, arena, frames, keep):
     D, H, S = m.embed_dim, m.num_heads, m.seq
-    N = frames.size(0)
-    M = N * S
+    # bf16 [frames * S, 768] = the input pipeline's patch rows (PatchVideo); fp32 (N, 3, H, W) = frames, cut into rows here
+    patches = frames if (frames.dim() == 2 and frames.dtype == torch.bfloat16) else ops.im2col_patch16(frames)
+    M = patches.size(0)
+    N = M // S
     sh = arena.sh
     full_blocks = m.blocks[:-1] if m.cls_only_last_block else m.blocks
     fold = use_fold(m, M, D, len(full_blocks))
-    patches = ops.im2col_patch16(frames)
     R = ops.posres_prep(m.pos_embed, m.cls_token, m.patch_embed.proj.bias, S, D)
     part = ops.ln_stat_part(M, D, frames.device) if fold else None          # the next LayerNorm's statistics, emitted by the GEMM that writes its input
     x = ops.gemm(patches, sh(m.patch_embed.proj.weight).view(D, 768), M, D, 768, res=R, res_period=S, stat_part=part)
@@ -311,7 +314,7 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
 class _ViTFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, arena, keep, frames, anchor):
-        feat, saved = _vit_forward(module, arena, frames.float().contiguous(), keep=keep)
+        feat, saved = _vit_forward(module, arena, frames.contiguous() if (frames.dim() == 2 and frames.dtype == torch.bfloat16) else frames.float().contiguous(), keep=keep)
         ctx.module, ctx.arena, ctx.saved = module, arena, saved
         return feat.float()
 

@@ -543,11 +543,16 @@ def add_rows(dst, src):
 
 
 # ---- input pipeline ------------------------------------------------------------------------------------------------------------
+def _patch_rows(B, T, OH, OW, device):
+    return torch.empty((B * T * ((OH // 16) * (OW // 16) + 1), 768), device=device, dtype=BF16)
+
+
 def video_preproc(src_u8, params, out_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5), reverse_channels=False,
-                  quantize_u8=False):
+                  quantize_u8=False, patches=False):
     """uint8 (B,T,H,W,3) -> fp32 (B,T,3,1,OH,OW): /255, bilinear resize, flip, scale, normalise, crop in one kernel.
     params: int32 (Bout,6) = new_h, new_w, flip, crop_i, crop_j, source clip per OUTPUT clip (on the device).
-    quantize_u8: cut the resized pixels to 8 bits first (the training chain's zero-strength ColorJitterVideo round trip)."""
+    quantize_u8: cut the resized pixels to 8 bits first (the training chain's zero-strength ColorJitterVideo round trip).
+    patches=True: the same pixels as the patch-embedding GEMM's bf16 rows [B T 197, 768] instead (= im2col_patch16 of the fp32 result, bit for bit)."""
     import ctypes
     _chk(src_u8, torch.uint8, 'src'); _chk(params, torch.int32, 'params')
     assert src_u8.dim() == 5 and src_u8.size(-1) == 3 and src_u8.is_contiguous() and params.is_contiguous()
@@ -555,15 +560,15 @@ def video_preproc(src_u8, params, out_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), s
     OH, OW = out_hw
     assert params.dim() == 2 and params.size(1) == 6
     B = params.size(0)
-    out = torch.empty((B, T, 3, 1, OH, OW), device=src_u8.device, dtype=torch.float32)
+    out = _patch_rows(B, T, OH, OW, src_u8.device) if patches else torch.empty((B, T, 3, 1, OH, OW), device=src_u8.device, dtype=torch.float32)
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
-    _lib.call('avt_video_preproc_u8', _p(src_u8), _p(out), _p(params), B, T, H, W, OH, OW, float(scale_pix),
+    _lib.call('avt_video_preproc_u8', _p(src_u8), None if patches else _p(out), _p(out) if patches else None, _p(params), B, T, H, W, OH, OW, float(scale_pix),
               ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p), int(reverse_channels), int(quantize_u8), _stream())
     return out
 
 
 def video_preproc_jitter(src_u8, params, jitter_ops, jitter_factors, out_hw, scale_pix=1.0, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5),
-                         reverse_channels=False, max_hw=None, slot_mask=None):
+                         reverse_channels=False, max_hw=None, slot_mask=None, patches=False):
     """video_preproc with ColorJitterVideo: jitter_ops int32 (Bout, 4) in application order (0 brightness, 1 contrast, 2 saturation, 3 hue,
     -1 none), jitter_factors fp32 (Bout, 4) (hue: the 8-bit shift).  The resized clips go through an 8-bit scratch buffer.
     max_hw = (max new_h, max new_w) over the clips and slot_mask (bit s: slot s used by some clip, bit 4 + s: by a contrast operation)
@@ -584,9 +589,9 @@ def video_preproc_jitter(src_u8, params, jitter_ops, jitter_factors, out_hw, sca
         slot_mask = sum(((1 << s) if bool((host_ops[:, s] >= 0).any()) else 0) | ((16 << s) if bool((host_ops[:, s] == 1).any()) else 0) for s in range(4))
     scratch = torch.empty(_lib.load().avt_video_jitter_scratch_bytes(B, T, max_h, max_w), device=src_u8.device, dtype=torch.uint8)
     sums = torch.zeros(B, device=src_u8.device, dtype=torch.int64)
-    out = torch.empty((B, T, 3, 1, OH, OW), device=src_u8.device, dtype=torch.float32)
+    out = _patch_rows(B, T, OH, OW, src_u8.device) if patches else torch.empty((B, T, 3, 1, OH, OW), device=src_u8.device, dtype=torch.float32)
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
-    _lib.call('avt_video_preproc_jitter_u8', _p(src_u8), _p(out), _p(params), _p(jitter_ops.contiguous()), _p(jitter_factors.contiguous()), B, T, H, W,
+    _lib.call('avt_video_preproc_jitter_u8', _p(src_u8), None if patches else _p(out), _p(out) if patches else None, _p(params), _p(jitter_ops.contiguous()), _p(jitter_factors.contiguous()), B, T, H, W,
               OH, OW, max_h, max_w, float(scale_pix), ctypes.cast(m3, ctypes.c_void_p), ctypes.cast(s3, ctypes.c_void_p), int(reverse_channels),
               int(slot_mask), _p(scratch), scratch.numel(), _p(sums), _stream())
     return out

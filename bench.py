@@ -102,7 +102,7 @@ def build(args, device, world):
     opt = FusedSGD(model.parameters(), lr=1e-4 * world, momentum=0.9, nesterov=True, weight_decay=1e-6, arena=model.arena)
     op = Basic(model, device, None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
     trainer = Trainer(model, op, opt, None, {'cls_action': 1.0, 'past_cls_action': 1.0, 'feat': 1.0}, distributed=world > 1,
-                      bucket_bytes=args.bucket_mb << 20, reduce_mode=args.reduce_mode,
+                      bucket_bytes=args.bucket_mb << 20, reduce_mode=args.reduce_mode, reduce_transport=args.reduce_transport,
                       wire_dtype=torch.bfloat16 if args.wire_dtype == 'bf16' else torch.float32,
                       tail_bytes=None if args.tail_mb < 0 else args.tail_mb << 20)
     rank = int(os.environ.get('RANK', 0))
@@ -191,6 +191,7 @@ def main(argv=None):
     ap.add_argument('--frames', type=int, default=10)
     ap.add_argument('--model', default='vit_base_patch16_224', choices=list(VIT))
     ap.add_argument('--bucket-mb', type=int, default=64)
+    ap.add_argument('--reduce-transport', default='torch', choices=['torch', 'abi'], help="who issues the collectives: torch.distributed (backend nccl = RCCL), or the library's own RCCL entry points (avt_allreduce_bucket ..., include/avt_hip.h; needs --backend nccl's one device per rank)")
     ap.add_argument('--reduce-mode', default='all_reduce', choices=['all_reduce', 'rs_ag'], help='gradient exchange per bucket: RCCL all-reduce, or reduce-scatter + all-gather')
     ap.add_argument('--wire-dtype', default='fp32', choices=['fp32', 'bf16'], help='dtype of the gradient buckets on the wire (bf16 halves the xGMI bytes; the sum then keeps 8 mantissa bits)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help="'gloo' lets several ranks share one GPU (a functional check of the N > 1 path on a 1-GPU box; never a measurement)")

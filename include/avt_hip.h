@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 7
+#define AVT_ABI_VERSION 8
 
 const char* avt_last_error(void);
 int avt_abi_version(void);
@@ -238,8 +238,12 @@ int avt_relu_bf16(const void* x, void* y, void* mask, long n, void* stream);
  * evaluation MultiCropVideo, common/transforms.py:254-296, is several output clips reading one source clip). mean3 / std3: host.
  * quantize_u8 != 0: the resized pixels are cut to 8 bits (floor(v * 255) / 255) before scaling -- what the training chain's
  * ColorJitterVideo (common/transforms.py:399-421, strengths 0 in every AVT experiment) does through its float -> PIL -> float
- * round trip (torchvision 0.8.2 to_pil_image: pic.mul(255).byte(); to_tensor: / 255). */
-int avt_video_preproc_u8(const void* src, float* dst, const int* params, int B, int T, int H, int W, int OH, int OW,
+ * round trip (torchvision 0.8.2 to_pil_image: pic.mul(255).byte(); to_tensor: / 255).
+ * patches (ABI 8; may be NULL): the SAME pixels written as the patch-embedding GEMM's bf16 rows [B T (P + 1)][768] -- row n (P + 1) the zero CLS
+ * slot, row n (P + 1) + 1 + p patch p flattened as k = c 256 + ky 16 + kx, i.e. exactly avt_im2col_patch16 of the fp32 frames (timm PatchEmbed via
+ * models/video_classification.py:213-227) -- so that the 0.95 MB of fp32 per frame and the im2col pass leave the step; OH, OW multiples of 16 then.
+ * dst may be NULL when patches is given (either or both outputs). */
+int avt_video_preproc_u8(const void* src, float* dst, void* patches, const int* params, int B, int T, int H, int W, int OH, int OW,
                          float scale_pix, const float* mean3, const float* std3, int reverse_channels, int quantize_u8,
                          void* stream);
 
@@ -253,7 +257,7 @@ int avt_video_preproc_u8(const void* src, float* dst, const int* params, int B, 
  * are skipped), bit 4 + s = some clip's operation in slot s is contrast (only then is the clip's mean luma computed); 0xff = unknown.
  * Bit-exact against Pillow (tests/golden/g11_color_jitter.npz, generated through the reference's own wrapper; the HSV round trip
  * exhaustively over all 2^24 colours, tests/test_ops_gpu.py). */
-int avt_video_preproc_jitter_u8(const void* src, float* dst, const int* params, const int* jitter_ops, const float* jitter_factors,
+int avt_video_preproc_jitter_u8(const void* src, float* dst, void* patches, const int* params, const int* jitter_ops, const float* jitter_factors,
                                 int B, int T, int H, int W, int OH, int OW, int max_h, int max_w, float scale_pix,
                                 const float* mean3, const float* std3, int reverse_channels, int slot_mask,
                                 void* scratch, size_t scratch_bytes, unsigned long long* luma_sums, void* stream);
@@ -299,6 +303,28 @@ int avt_linear_softmax_xent_bwd(const float* logits, int ldl, const long* target
  * Also writes the bf16 shadow (may be NULL) and re-zeroes grad when zero_grad != 0. */
 int avt_sgd_step(float* param, float* grad, float* momentum_buf, void* shadow_bf16, long n, float lr, float momentum,
                  float weight_decay, float grad_scale, int nesterov, int first_step, int zero_grad, void* stream);
+
+/* ---- gradient exchange over RCCL (ABI 8) ------------------------------------------------------------------------------
+ * What the reference gets from torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu]) (func/train.py:771-778) after
+ * torch.distributed.init_process_group(backend='nccl') (common/utils.py:145-148): the SUM of a bucket of the flat gradient buffer over the
+ * ranks of one node (xGMI), in place, enqueued on `stream` (use a side stream and order it after the producing kernels with an event: the
+ * exchange then overlaps the rest of backward -- avt_amd/ddp.py::GradReducer does exactly that, with either torch.distributed or these
+ * entry points underneath).  One process per GPU.  Rank 0 draws a 128-byte id (avt_comm_unique_id) and the host ships it to the other
+ * ranks by any side channel; every rank then calls avt_comm_init_rank(nranks, rank, device, id) -- collective, blocks until all ranks arrive.
+ * dtype: 0 = fp32, 1 = bf16.  avt_reduce_scatter_bucket + avt_allgather_bucket are the same sum as two collectives (every rank
+ * reduces 1 / nranks of the bucket, then the shards are exchanged): shard r = elements [r n / nranks, (r + 1) n / nranks) of `buf`, in place;
+ * n must split into 16-byte aligned shards.  avt_broadcast_bucket: DDP's constructor broadcast of rank `root`'s parameters.
+ * The 1 / nranks average is NOT applied here: avt_sgd_step's grad_scale carries it.  RCCL is loaded at first use (dlopen of librccl.so.1),
+ * so a process that never calls these does not need it; errors carry RCCL's own message in avt_last_error(). */
+#define AVT_COMM_ID_BYTES 128
+int avt_comm_unique_id(void* id128);
+int avt_comm_init_rank(void** comm, int nranks, int rank, int device, const void* id128);
+int avt_comm_destroy(void* comm);
+int avt_comm_size(void* comm, int* nranks, int* rank);
+int avt_allreduce_bucket(void* comm, void* buf, size_t n, int dtype, void* stream);
+int avt_reduce_scatter_bucket(void* comm, void* buf, size_t n, int dtype, void* stream);
+int avt_allgather_bucket(void* comm, void* buf, size_t n, int dtype, void* stream);
+int avt_broadcast_bucket(void* comm, void* buf, size_t n, int dtype, int root, void* stream);
 
 #ifdef __cplusplus
 }

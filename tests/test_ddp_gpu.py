@@ -21,11 +21,11 @@ from avt_amd.func.train_eval_ops import Basic
 from avt_amd.optim import FusedSGD
 rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 backend = os.environ.get('AVT_TEST_BACKEND', 'gloo')
-if backend == 'nccl':                      # RCCL: one device per rank
+if backend == 'nccl' or os.environ.get('AVT_TEST_TRANSPORT') == 'abi':                      # RCCL: one device per rank
     assert torch.cuda.device_count() >= world
     torch.cuda.set_device(rank)
 if world > 1:
-    dist.init_process_group(backend, init_method='env://', rank=rank, world_size=world)
+    dist.init_process_group(backend, init_method='env://', rank=rank, world_size=world)      # (transport 'abi': only the side channel for the 128-byte id)
     assert dist.get_backend() == backend
 torch.manual_seed(0)                       # identical init on every rank (broadcast must be a no-op then)
 model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32), device=torch.device('cuda', torch.cuda.current_device()))
@@ -36,7 +36,8 @@ if rank == 1:                              # perturb: broadcast from rank 0 must
     with torch.no_grad(): model.classifiers.action.bias.add_(1.0)
 opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-4, arena=model.arena)
 op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
-tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=world > 1, bucket_bytes=64 << 10, reduce_mode=os.environ.get('AVT_TEST_REDUCE_MODE', 'all_reduce'))
+tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=world > 1, bucket_bytes=64 << 10, reduce_mode=os.environ.get('AVT_TEST_REDUCE_MODE', 'all_reduce'),
+             reduce_transport=os.environ.get('AVT_TEST_TRANSPORT', 'torch'))
 g = torch.Generator().manual_seed(9)
 B = int(os.environ.get('AVT_TEST_CLIPS', 4))
 video = torch.rand((B, 4, 3, 1, 32, 32), generator=g) * 2 - 1
@@ -158,6 +159,52 @@ def test_rccl_training_on_one_device_per_rank_matches_single_process(tmp_path, m
         assert e < 2e-2, (k, e, world, mode)
 
 
+@pytest.mark.parametrize('mode', ['all_reduce', 'rs_ag'])
+def test_abi_rccl_training_on_one_device_per_rank_matches_single_process(tmp_path, mode):
+    """The same as above with the collectives issued through the C ABI (GradReducer(transport='abi'): avt_comm_init_rank on every rank from
+    the id rank 0 drew, avt_broadcast_bucket, avt_allreduce_bucket | avt_reduce_scatter_bucket + avt_allgather_bucket); torch.distributed (gloo)
+    only carries the 128-byte id.  Skipped on a one-GPU box; RCCL parity evidence for the ABI on any node with two or more devices."""
+    n = _devices()
+    if n < 2:
+        pytest.skip(f'RCCL needs one device per rank: {n} device(s) here')
+    clips = str(2 * n)
+    _run(1, tmp_path / 'single.pt', tmp_path, 29591, AVT_TEST_CLIPS=clips)
+    _run(n, tmp_path / 'abi.pt', tmp_path, 29592 + (mode == 'rs_ag'), AVT_TEST_TRANSPORT='abi', AVT_TEST_REDUCE_MODE=mode, AVT_TEST_CLIPS=clips)
+    a, b = torch.load(tmp_path / 'single.pt'), torch.load(tmp_path / 'abi.pt')
+    for k in a:
+        e = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-12))
+        assert e < 2e-2, (k, e, n, mode)
+
+
+def test_rccl_collectives_through_the_c_abi_on_one_gpu():
+    """The communicator and every collective of include/avt_hip.h's "gradient exchange over RCCL" section at world size 1 (a sum over one rank is the
+    identity): fp32 and bf16, reduce-scatter + all-gather, broadcast, the size query, the host-side argument checks."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from avt_amd.comm import RcclComm
+    from avt_amd.lib import AvtHipError
+    c = RcclComm(1, 0, 0, RcclComm.unique_id())
+    assert c.size() == (1, 0)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(4096, device='cuda', generator=g).to(dt)
+        y = x.clone()
+        c.all_reduce(y); c.reduce_scatter(y); c.all_gather(y); c.broadcast(y, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):                                   # explicit stream: the call lands on the caller's current stream
+        z = torch.ones(1024, device='cuda')
+        c.all_reduce(z)
+    s.synchronize()
+    assert float(z.sum()) == 1024.0
+    with pytest.raises(AvtHipError, match='fp32 / bf16'):
+        c.all_reduce(torch.ones(8, device='cuda', dtype=torch.float16))
+    with pytest.raises(AvtHipError, match='bad rank'):
+        RcclComm(1, 3, 0, RcclComm.unique_id())
+    c.destroy()
+
+
 def test_bench_multi_gpu_line_over_rccl():
     """`python bench.py --gpus N` over RCCL on every device of the node (N >= 2): one JSON line, n_gpus = N, RCCL saw N ranks on N distinct
     devices, per-rank rates and the exchange accounting present.  Skipped on a one-GPU box."""
@@ -191,8 +238,10 @@ model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
 opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, arena=model.arena)
 op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
 tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=True, bucket_bytes=64 << 10, force_reducer=True, reduce_mode=os.environ.get('AVT_TEST_REDUCE_MODE', 'all_reduce'),
-             wire_dtype=torch.bfloat16 if os.environ.get('AVT_TEST_WIRE') == 'bf16' else torch.float32)
-assert tr.reducer is not None
+             wire_dtype=torch.bfloat16 if os.environ.get('AVT_TEST_WIRE') == 'bf16' else torch.float32, reduce_transport=os.environ.get('AVT_TEST_TRANSPORT', 'torch'))
+assert tr.reducer is not None and tr.reducer.transport == os.environ.get('AVT_TEST_TRANSPORT', 'torch')
+if tr.reducer.transport == 'abi':
+    assert tr.reducer.comm.size() == (1, 0)                  # asked of RCCL itself (ncclCommCount / ncclCommUserRank)
 g = torch.Generator().manual_seed(9)
 data = {'video': (torch.rand((2, 4, 3, 1, 32, 32), generator=g) * 2 - 1).cuda(), 'target': {'action': torch.randint(0, 17, (2,), generator=g).cuda()},
         'target_subclips': {'action': torch.randint(-1, 17, (2, 4, 1), generator=g).cuda()}}
@@ -210,16 +259,19 @@ print('OK nccl', tr.reducer.launched)
 '''
 
 
+@pytest.mark.parametrize('transport', ['torch', 'abi'])
 @pytest.mark.parametrize('mode,wire', [('all_reduce', 'fp32'), ('rs_ag', 'fp32'), ('all_reduce', 'bf16'), ('rs_ag', 'bf16')])
-def test_rccl_executes_the_bucketed_allreduce_on_one_gpu(tmp_path, mode, wire):
+def test_rccl_executes_the_bucketed_allreduce_on_one_gpu(tmp_path, mode, wire, transport):
     """backend='nccl' (= RCCL) with world_size 1: init_process_group, rank-0 broadcast, the bucketed all_reduce launched from
-    the backward segment hooks on the side stream, finish() -- the same code path the 8-GPU run takes, on the box we have."""
+    the backward segment hooks on the side stream, finish() -- the same code path the 8-GPU run takes, on the box we have.
+    transport 'abi': the same exchange through the library's own RCCL entry points (avt_comm_init_rank, avt_broadcast_bucket, avt_allreduce_bucket /
+    avt_reduce_scatter_bucket + avt_allgather_bucket; include/avt_hip.h ABI 8) instead of torch.distributed's."""
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     script = tmp_path / 'nccl_worker.py'
     script.write_text(NCCL_WORKER)
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29561', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0',
-               HSA_ENABLE_IPC_MODE_LEGACY='0', AVT_TEST_REDUCE_MODE=mode, AVT_TEST_WIRE=wire)
+               HSA_ENABLE_IPC_MODE_LEGACY='0', AVT_TEST_REDUCE_MODE=mode, AVT_TEST_WIRE=wire, AVT_TEST_TRANSPORT=transport)
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and 'OK nccl' in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
 

@@ -623,10 +623,17 @@ def test_g6b_rollout_full_size_head_vs_reference_golden(golden_dir):
     assert rel(out['future'], g['out/future']) < TOL_OUT and rel(out['past'], g['out/past']) < TOL_OUT
     assert rel(out['past_logits/action'][:, :, ::16], g['out/past_logits/action_sub']) < TOL_OUT
     assert rel(aux['feat'][:, :, ::8], g['loss/feat_sub']) < TOL_OUT
-    model.train()                                    # roll-out with gradients is not implemented: must fail loudly
-    model.future_predictor.output_len = 2
-    with pytest.raises(NotImplementedError):
-        model(video[:, :, 0], target_shape=(2,))
+    # the roll-out WITH gradients (round 6: cache-free, one differentiable head node per step) computes the same thing as the cached eval roll-out:
+    # same logits up to the bf16 rounding of a different kernel route for the single-token steps (golden G12 pins it to the reference with gradients)
+    model.future_predictor.output_len_eval = -1
+    model.future_predictor.output_len = 4
+    with torch.enable_grad():
+        out_g, _ = model(video[:, :, 0], target_shape=(2,))
+    with torch.no_grad():
+        out_c, _ = model(video[:, :, 0], target_shape=(2,))
+    torch.cuda.synchronize()
+    assert out_g['logits/action'].requires_grad and not out_c['logits/action'].requires_grad
+    assert rel(out_g['logits/action'], out_c['logits/action']) < 1e-2 and rel(out_g['future'], out_c['future']) < 1e-2
 
 
 # ---- round 2: structure checks -------------------------------------------------------------------------------------------------
@@ -874,6 +881,38 @@ def test_train_net_entry_runs_the_composed_experiment(tmp_path):
                         '--steps', '2', '--batch', '2', 'synthetic.uint8_source=[256,456]'], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     assert len([l for l in r.stdout.splitlines() if l.startswith('iter ')]) == 2, r.stdout[-2000:]
+    # ... by default as patch rows straight from the input kernel: no fp32 frames, no im2col pass (round 6); synthetic.emit_patches=false keeps the tensor
+    assert 'abi calls: avt_im2col_patch16 0 ' in r.stdout and 'avt_video_preproc_u8 2' in r.stdout, r.stdout[-2000:]
+
+
+def test_model_on_patch_rows_equals_model_on_the_fp32_clip():
+    """The input pipeline's PatchVideo (bf16 patch rows straight from avt_video_preproc_u8) through BaseModel + Basic gives the outputs, losses and
+    gradients of the same step on the fp32 clip tensor, bit for bit, and makes no avt_im2col_patch16 call (timm PatchEmbed via
+    models/video_classification.py:213-227)."""
+    from avt_amd import lib
+    from avt_amd.common.gpu_transforms import GpuClipTransform
+    torch.manual_seed(3)
+    model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32))
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.ndim >= 2:
+                p.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(8)
+    B, T = 3, 4
+    u8 = torch.randint(0, 256, (B, T, 40, 56, 3), generator=g, dtype=torch.uint8).cuda()
+    target, sub = torch.randint(0, 17, (B,), generator=g).cuda(), torch.randint(-1, 17, (B, T, 1), generator=g).cuda()
+    params = [(40, 56, 0, 3, 11), (44, 61, 1, 9, 20), (36, 50, 1, 0, 5)]
+    video = GpuClipTransform(40, -1, 32, train=True)(u8, params=params)
+    pv = GpuClipTransform(40, -1, 32, train=True, emit_patches=True)(u8, params=params)
+    out_a, losses_a, _, tot_a = hip_step(model, video, target, sub)
+    grads_a = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    before = lib.CALLS_BY_NAME.get('avt_im2col_patch16', 0)
+    out_b, losses_b, _, tot_b = hip_step(model, pv, target, sub)
+    assert lib.CALLS_BY_NAME.get('avt_im2col_patch16', 0) == before
+    assert torch.equal(out_a['logits/action'], out_b['logits/action']) and torch.equal(out_a['past_logits/action'], out_b['past_logits/action'])
+    assert float(tot_a) == float(tot_b)
+    for n, p in model.named_parameters():
+        assert torch.equal(p.grad, grads_a[n]), n
 
 
 def test_checkpoint_round_trip_with_the_reference_format(tmp_path):

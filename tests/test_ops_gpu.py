@@ -1151,6 +1151,51 @@ def test_video_preproc_with_color_jitter_vs_reference_golden(golden_dir):
 
 
 @pytest.mark.gpu
+def test_input_pipeline_patch_rows_equal_im2col_of_its_fp32_frames(golden_dir):
+    """Round 6 (timm PatchEmbed via models/video_classification.py:213-227 + common/transforms.py:124-170): the input kernels' ``patches`` output -- the
+    patch-embedding GEMM's bf16 rows [frames x 197, 768] written directly -- is avt_im2col_patch16 of the SAME call's fp32 frames, bit for bit: the
+    training chain with its 8-bit round trip, the evaluation chain, the three-stage colour-jitter chain (G11's clips and draws), flips, ragged resizes."""
+    import os
+    import numpy as np
+    from avt_amd import ops
+    from avt_amd.common.gpu_transforms import GpuClipTransform
+    from avt_amd.common.patch_video import PatchVideo
+    g = torch.Generator().manual_seed(5)
+    B, T, H, W = 3, 4, 256, 456
+    u8 = torch.randint(0, 256, (B, T, H, W, 3), generator=g, dtype=torch.uint8).cuda()
+    params = [(248, 441, 0, 0, 0), (280, 498, 1, 56, 274), (263, 468, 1, 17, 100)]
+    for train in (True, False):
+        frames = GpuClipTransform('248-280', -1, 224, train=train)(u8, params=params)
+        pv = GpuClipTransform('248-280', -1, 224, train=train, emit_patches=True)(u8, params=params)
+        assert isinstance(pv, PatchVideo) and pv.shape == frames.shape and pv.ndim == 6 and pv.to('cuda') is pv
+        assert pv.patches.shape == (B * T * 197, 768)
+        want = ops.im2col_patch16(frames.view(B * T, 3, 224, 224))
+        torch.cuda.synchronize()
+        assert torch.equal(pv.patches.view(torch.int16), want.view(torch.int16))
+        assert float(pv.patches.view(B * T, 197, 768)[:, 0].float().abs().max()) == 0.0          # the CLS slots
+        assert pv.reshape((B * T, 3, 1, 224, 224)).patches is pv.patches
+    # the colour-jitter chain (three stages through the 8-bit scratch clip)
+    z = np.load(os.path.join(golden_dir, 'g11_color_jitter.npz'))
+    clips = torch.from_numpy(z['clips']).cuda()
+    names = ('brightness', 'contrast', 'saturation', 'hue')
+    prm = [tuple(int(v) for v in row) for row in z['params']]
+    jit = [[(names[int(i)], float(f)) for i, f in zip(ids, fs) if i >= 0] for ids, fs in zip(z['op_ids'], z['op_factors'])]
+    kw = dict(mean=tuple(z['mean']), std=tuple(z['std']), train=True)
+    frames = GpuClipTransform(56, -1, 48, **kw)(clips, params=prm, jitter=jit)
+    pv = GpuClipTransform(56, -1, 48, emit_patches=True, **kw)(clips, params=prm, jitter=jit)
+    n = frames.size(0) * frames.size(1)
+    want = ops.im2col_patch16(frames.view(n, 3, 48, 48))
+    torch.cuda.synchronize()
+    assert isinstance(pv, PatchVideo) and torch.equal(pv.patches.view(torch.int16), want.view(torch.int16))
+    # multi-crop evaluation keeps the 7-D tensor; a crop that is no multiple of 16 cannot be cut into patches
+    ev = GpuClipTransform(int(z['mc_target']) if 'mc_target' in z else 56, -1, 48, train=False, eval_num_crops=3, emit_patches=True)
+    assert torch.is_tensor(ev(clips[:1]))
+    from avt_amd.lib import AvtHipError
+    with pytest.raises(AvtHipError, match='multiple of 16'):
+        GpuClipTransform(56, -1, 40, train=True, emit_patches=True)(clips, params=[(56, 99, 0, 0, 0)] * clips.size(0))
+
+
+@pytest.mark.gpu
 def test_color_jitter_operations_exact_vs_oracle_random_chains(ops):
     """The four Pillow operations on the device against the oracle's restatement (itself pinned to Pillow on the CPU), identity geometry (so
     the 8-bit input is the clip itself), random orders / factors incl. the clipping branch of Image.blend, negative hue shifts, grey pixels
