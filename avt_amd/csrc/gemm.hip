@@ -353,9 +353,10 @@ int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk,
   p.splitk = splitk;
   if (epi == 2) {                    // deterministic accumulate: only the weight-gradient layout (both operands reduction-major)
     if (a_kmajor || b_kmajor) { avt_set_error("avt_gemm_accum_bf16: operands must both be stored reduction-index-major"); return -1; }
-    if ((size_t)p.tiles_m * p.tiles_n * splitk * BM * BN * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * BM * BN * 4); return -2; }
+    // (splitk == 1: the kernel adds its tile into C itself -- no slab, no reduce; gemm_tile.hpp::gemm_epilogue)
+    if (splitk > 1 && (size_t)p.tiles_m * p.tiles_n * splitk * BM * BN * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * BM * BN * 4); return -2; }
     int rc = launch<BM, BN, WGM, WGN, BK, NSTAGE, false, false, 2, SPREAD, PR, MINW, NWL>(p, s);
-    return rc ? rc : launch_reduce<BM / WGM / 32, BN / WGN / 32, WGM, WGN>(p, s);
+    return (rc || splitk == 1) ? rc : launch_reduce<BM / WGM / 32, BN / WGN / 32, WGM, WGN>(p, s);
   }
   return epi ? dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 1, SPREAD, PR, MINW, NWL>(p, a_kmajor, b_kmajor, s)
              : dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 0, SPREAD, PR, MINW, NWL>(p, a_kmajor, b_kmajor, s);
@@ -698,9 +699,9 @@ int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
 #endif
   if (epi == 2) {
     if (a_kmajor || b_kmajor) { avt_set_error("avt_gemm_accum_bf16: operands must both be stored reduction-index-major"); return -1; }
-    if ((size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4); return -2; }
+    if (splitk > 1 && (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4); return -2; }
     int rc = launch_8p<false, false, 2>(p, s);
-    return rc ? rc : launch_reduce<4, 2, 2, 4>(p, s);
+    return (rc || p.splitk == 1) ? rc : launch_reduce<4, 2, 2, 4>(p, s);
   }
   if (!persist && (p.c2_frag || p.aux_frag)) { avt_set_error("avt_gemm_bf16: a fragment-major C2 / aux (ldc2 == 0 / ldaux == 0) needs the persistent kernel (tile 0 or 809)"); return -1; }
   if (persist) {
@@ -913,7 +914,7 @@ __device__ __forceinline__ void w4_frag_put(bf16x8_t (&af)[4], bf16x8_t (&bf)[4]
 #ifndef AVT_W4_LDB_AUX
 #define AVT_W4_LDB_AUX 0
 #endif
-template <int EPI>
+template <int EPI, bool DIRECT = false>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   static_assert(EPI == 2, "4-wave weight-gradient kernel: split-K slab epilogue only");
   constexpr int BM = 256, BN = 256, BK = 32, NST = 5, WM = 128, WN = 128, TM = 4, TN = 4;
@@ -1087,7 +1088,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
 #undef W4_STEP
 #undef W4_RDF
 #undef W4_PIN
-  gemm_epilogue<TM, TN, WM, WN, EPI>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
+  gemm_epilogue<TM, TN, WM, WN, EPI, 0, false, false, DIRECT ? 1 : 0>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
 }
 
 int dispatch_w4(GemmParams& p, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
@@ -1097,14 +1098,19 @@ int dispatch_w4(GemmParams& p, int a_kmajor, int b_kmajor, int splitk, hipStream
   if (splitk <= 0) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk64, 1, 8);      // same choice as the 8-phase kernel: the workspace query mirrors it
   if (splitk > nk64) splitk = nk64;
   p.splitk = splitk;
-  if ((size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4); return -2; }
+  if (splitk > 1 && (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4); return -2; }
   constexpr int smem = 5 * 2 * 32 * 512;               // 160 KB
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
-  hipLaunchKernelGGL((gemm_w4_kernel<2>), dim3(p.tiles_m * p.tiles_n * splitk), dim3(256), smem, s, p);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  if (splitk == 1) hipLaunchKernelGGL((gemm_w4_kernel<2, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), smem, s, p);      // adds its tiles into C itself
+  else hipLaunchKernelGGL((gemm_w4_kernel<2, false>), dim3(p.tiles_m * p.tiles_n * splitk), dim3(256), smem, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
-  return launch_reduce<4, 4, 2, 2>(p, s);
+  return splitk == 1 ? 0 : launch_reduce<4, 4, 2, 2>(p, s);            // (splitk == 1: the kernel added its tiles into C itself)
 }
 
 int dispatch_4w(GemmParams& p, int epi, int a_kmajor, int b_kmajor, hipStream_t s) {

@@ -841,12 +841,38 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
 #define AVT_SLAB_ST(ptr, val) (*(f32x4_t*)(ptr) = (val))
 #endif
 // LN: compile the LayerNorm-fold variants of the epilogue (only the kernels with both operands k-major are ever asked for them)
-template <int TM, int TN, int WM, int WN, int EPI, int PR = 0, bool TAB = false, bool LN = false>
+// DIRECT (EPI 2): 1 = the workgroup holds the whole reduction (splitk == 1) and adds its tile into C itself, 0 = slabs, -1 = decided at run time
+// (the register-limited 4-wave kernel compiles the two as separate instantiations: with both in one body it spilled 16 registers)
+template <int TM, int TN, int WM, int WN, int EPI, int PR = 0, bool TAB = false, bool LN = false, int DIRECT = -1>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[TM][TN], char* lds, int wave, int lane,
                                               int row0, int col0, const char* tab = nullptr) {
   // row0/col0: global coordinates of this wave's tile origin
   static_assert(WM == TM * 32 && WN == TN * 32 && TM <= 4, "wave tile geometry");
   if (EPI == 2) {
+    if (DIRECT == 1 || (DIRECT < 0 && p.splitk == 1)) {
+      // (round 6) the whole reduction sits in this workgroup: C += acc right here -- every C element has exactly one owner, plain read-modify-write,
+      // the same sum bit for bit as a one-slab reduce -- instead of a slab round trip (tile written, re-read, C read and written) and a second launch.
+      // Each store instruction covers two rows x 32 consecutive columns: two full 128-byte lines.  (The head's 2048 x 8192 weights at <= 2560 rows.)
+      float* C = (float*)p.C;
+      const int nl = lane & 31, hq = 4 * (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = col0 + j * 32 + nl;
+          if (n < p.N) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int m0 = row0 + i * 32 + 8 * q + hq;
+              float* c = C + (size_t)m0 * (size_t)p.ldc + n;
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                if (m0 + k < p.M) c[(size_t)k * p.ldc] += acc[i][j][4 * q + k];
+            }
+          }
+        }
+      return;
+    }
     // deterministic weight-gradient epilogue: this block's partial tile goes to its own slab of the caller's workspace in
     // accumulator order (full 1-KB wave stores); splitk_reduce_kernel adds the slabs in split order into C
     const int NWV = (int)(blockDim.x >> 6);
