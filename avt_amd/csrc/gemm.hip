@@ -53,10 +53,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   const int kt_begin = p.splitk == 1 ? 0 : (int)((unsigned)nk_total * (unsigned)split / (unsigned)p.splitk);
   const int kt_end = p.splitk == 1 ? nk_total : (int)((unsigned)nk_total * (unsigned)(split + 1) / (unsigned)p.splitk);
   const int nk = kt_end - kt_begin;
-#ifdef AVT_LAB
-  if (MINW >= 2) stagger_slot(p.stagger, bid, 512); else
-#endif
-  stagger_start(AVT_STAGGER(p), bid);
 
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
@@ -79,8 +75,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
     else stage_kstrided<BN, NW, BK>(rb, base + A_TILE, tn0, k0, p.ldb, p.N, wave, lane);
   };
 
-  long long t_start = 0, t_loop = 0;
-  if (AVT_DBG(p)) t_start = __builtin_readcyclecounter();
   // NSTAGE-deep LDS ring, one barrier per K tile: iteration `it` waits (counted vmcnt) until its own tile has
   // landed while up to NSTAGE-2 younger tiles stay in flight across the barrier, then refills the slot that was
   // consumed in iteration it-1 with tile it+NSTAGE-1, then computes.
@@ -231,21 +225,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
     if (++slot == NSTAGE) slot = 0;
   }
   asm volatile("s_barrier" ::: "memory");   // every wave is done reading the ring before the epilogue reuses it
-  if (AVT_DBG(p)) t_loop = __builtin_readcyclecounter();
 
   gemm_epilogue<TM, TN, WM, WN, EPI, 0, false, A_KMAJOR && B_KMAJOR>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
-#ifdef AVT_LAB
-  if (p.dbg && tid == 0) {
-    const long long t_math = __builtin_readcyclecounter();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const long long t_end = __builtin_readcyclecounter();
-    uint32_t hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    long long* d_ = p.dbg + (size_t)bid * 16;            // same record stride as the 8-phase kernel (two groups x 8)
-    d_[0] = t_start; d_[1] = t_loop; d_[2] = t_math; d_[3] = t_end; d_[4] = hw; d_[5] = xcc; d_[6] = nk; d_[7] = bid;
-  }
-#endif
 }
 
 // Second pass of the deterministic split-K accumulate: one wave per 1-KB chunk (producing wave w, block (i, j), register
@@ -353,18 +334,14 @@ int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk,
   p.splitk = splitk;
   if (epi == 2) {                    // deterministic accumulate: only the weight-gradient layout (both operands reduction-major)
     if (a_kmajor || b_kmajor) { avt_set_error("avt_gemm_accum_bf16: operands must both be stored reduction-index-major"); return -1; }
-    // (splitk == 1: the kernel adds its tile into C itself -- no slab, no reduce; gemm_tile.hpp::gemm_epilogue)
-    if (splitk > 1 && (size_t)p.tiles_m * p.tiles_n * splitk * BM * BN * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * BM * BN * 4); return -2; }
+    if ((size_t)p.tiles_m * p.tiles_n * splitk * BM * BN * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * BM * BN * 4); return -2; }
     int rc = launch<BM, BN, WGM, WGN, BK, NSTAGE, false, false, 2, SPREAD, PR, MINW, NWL>(p, s);
-    return (rc || splitk == 1) ? rc : launch_reduce<BM / WGM / 32, BN / WGN / 32, WGM, WGN>(p, s);
+    return rc ? rc : launch_reduce<BM / WGM / 32, BN / WGN / 32, WGM, WGN>(p, s);
   }
   return epi ? dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 1, SPREAD, PR, MINW, NWL>(p, a_kmajor, b_kmajor, s)
              : dispatch_layout<BM, BN, WGM, WGN, BK, NSTAGE, 0, SPREAD, PR, MINW, NWL>(p, a_kmajor, b_kmajor, s);
 }
 
-#ifdef AVT_LAB   // lab-only kernel variants (negative results kept for A/B in tools/): not part of libavt_hip.so
-#include "../../tools/lab/gemm_lab_variants.inc"
-#endif
 
 // ---- 8-phase kernel: 256x256x64 tile, two wave groups half a phase apart, half-tile ring 1.5 K tiles deep ---------
 // The K tile is consumed in four phases, one 64x32 quadrant of the 128x64 wave tile each; every phase is
@@ -429,10 +406,6 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
   const int kt_begin = p.splitk == 1 ? 0 : (int)((unsigned)nk_total * (unsigned)split / (unsigned)p.splitk);
   const int kt_end = p.splitk == 1 ? nk_total : (int)((unsigned)nk_total * (unsigned)(split + 1) / (unsigned)p.splitk);
   const int nk = kt_end - kt_begin;
-#ifdef AVT_LAB
-  long long t8_start = 0, t8_loop = 0;
-  if (p.dbg) t8_start = __builtin_readcyclecounter();
-#endif
 
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
@@ -488,7 +461,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
     const uint32_t adv = (uint32_t)tile * kstepA;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offA[h][j] + adv, 0, 0, AVT_LDA_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offA[h][j] + adv, 0, 0, 0);
   };
   auto stage_b = [&](int h, int tile) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t r = (tile < nk) ? rb : rb_null;
@@ -496,7 +469,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
     const uint32_t adv = (uint32_t)tile * kstepB;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offB[h][j] + adv, 0, 0, AVT_LDB_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(d + j * JSTEP), 16, offB[h][j] + adv, 0, 0, 0);
   };
 
   bf16x8_t fa[2][4], fb0[4], fb1[4];
@@ -633,22 +606,7 @@ __global__ __launch_bounds__(512) void gemm_8p_kernel(GemmParams p) {
   P8_BARRIER();                                          // every LDS-DMA has landed and every fragment read retired: LDS is free
   int lane_e = lane, m0_e = tm0 + grp * WM, n0_e = tn0 + wn * WN;
   asm volatile("" : "+v"(lane_e), "+s"(m0_e), "+s"(n0_e));   // keep the epilogue's address arithmetic out of the K loop's register budget
-#ifdef AVT_LAB
-  if (p.dbg) t8_loop = __builtin_readcyclecounter();
-#endif
   gemm_epilogue<TM, TN, WM, WN, EPI, 0, GTAB, A_KMAJOR && B_KMAJOR>(p, acc, lds, wave, lane_e, m0_e, n0_e, smem8);
-#ifdef AVT_LAB
-  if (p.dbg && (tid == 0 || tid == 256)) {            // first wave of each group: start, end of K loop, arithmetic done, stores drained, placement
-    const long long t_math = __builtin_readcyclecounter();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const long long t_end = __builtin_readcyclecounter();
-    uint32_t hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    long long* d_ = p.dbg + ((size_t)bid * 2 + grp) * 8;
-    d_[0] = t8_start; d_[1] = t8_loop; d_[2] = t_math; d_[3] = t_end; d_[4] = hw; d_[5] = xcc; d_[6] = nk; d_[7] = bid;
-  }
-#endif
 #undef P8_PIN
 #undef P8_MFMA
 #undef P8_BARRIER
@@ -694,22 +652,16 @@ int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
       if (w >= 3 && w < p.tiles_n) p.strip_w = w;
     }
   }
-#ifdef AVT_LAB
-  { static const char* e = getenv("AVT_GEMM_STRIP"); if (e) p.strip_w = (epi == 0 && atoi(e) < p.tiles_n) ? atoi(e) : 0; }
-#endif
   if (epi == 2) {
     if (a_kmajor || b_kmajor) { avt_set_error("avt_gemm_accum_bf16: operands must both be stored reduction-index-major"); return -1; }
-    if (splitk > 1 && (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4); return -2; }
+    if ((size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4); return -2; }
     int rc = launch_8p<false, false, 2>(p, s);
-    return (rc || p.splitk == 1) ? rc : launch_reduce<4, 2, 2, 4>(p, s);
+    return rc ? rc : launch_reduce<4, 2, 2, 4>(p, s);
   }
   if (!persist && (p.c2_frag || p.aux_frag)) { avt_set_error("avt_gemm_bf16: a fragment-major C2 / aux (ldc2 == 0 / ldaux == 0) needs the persistent kernel (tile 0 or 809)"); return -1; }
   if (persist) {
     // the persistent form (gemm_persist.hip) where it covers the shape and the epilogue: 0 = not covered
     int mask = 0xF;
-#ifdef AVT_LAB
-    { const char* e = getenv("AVT_GEMM_PERSIST"); if (e) mask = atoi(e); }
-#endif
     const int rc = (epi == 0 && a_kmajor && b_kmajor && splitk == 1) ? avt_gemm_persist(p, mask, persist == 2, s) : 0;
     if (rc != 0) return rc < 0 ? rc : 0;
     if (p.c2_frag || p.aux_frag) { avt_set_error("avt_gemm_bf16: a fragment-major C2 / aux (ldc2 == 0 / ldaux == 0) needs the persistent kernel: ask avt_gemm_frag_ok(M, N, K) first"); return -1; }
@@ -731,161 +683,9 @@ int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, 
   return launch_8p<false, true, 1>(p, s);
 }
 
-// ---- 4-wave kernel: 256x128x32 tile, TWO workgroups per CU, so that one's epilogue runs under the other's K loop ------------
-// Measured on gfx950 (tools/lab/coissue_lab.hip, coissue2_lab.hip, valu_rate_lab.hip; profiles/r03_issue_rules.txt):
-//   * a wave's vector-ALU instructions never overlap its OWN MFMAs (8 MFMA + k packed FMAs = 8 x 32 + 4.7 k cycles), but the
-//     vector ALU of ANOTHER wave on the same SIMD does run under them (the MFMA wave keeps 32.1 cycles per MFMA; the other
-//     wave's packed FMAs slow from one per 9.5 to one per 17.5 cycles);
-//   * a wave's own ds_read_b128 and LDS-DMA issue DO overlap its MFMAs (8 MFMA + 6 reads = 257 cycles, + 2 LDS-DMA = 281).
-// In the 8-phase kernel all eight waves of the CU reach the epilogue together: for a GELU (+ GELU') tile that is 22 k cycles of
-// vector-ALU work next to a 32 k-cycle K loop with the matrix pipe idle (tools/gemm_timeline.py).  Here a workgroup is four
-// waves (one per SIMD, wave tile 128x64 as in the 8-phase kernel, so the epilogue code is shared) on a 256x128 tile with a
-// 72-KB ring (3 stages of 32 k), and two workgroups share the CU: while one converts and stores its tile, the other owns the
-// matrix pipe.  The K loop therefore has to keep the pipe busy from ONE wave per SIMD: it contains no vector-ALU instruction at
-// all (per-lane offsets are computed once, the K advance goes through the scalar offset of the buffer instruction, stages past
-// the end read through a zero-length descriptor), fragments of the next k-step are requested before the MFMAs of the current
-// one, and the six LDS-DMA instructions of a stage are spread between the MFMAs.
-//   stage s (slot s % 3):  wait own DMA of stage s (vmcnt 6), lgkmcnt(0), s_barrier
-//                          read fragments (s, k-step 0) | 8 MFMA of (s-1, k-step 1) with 3 DMA of stage s+2 between them
-//                          read fragments (s, k-step 1) | 8 MFMA of (s,   k-step 0) with 3 DMA of stage s+2 between them
-// The barrier of stage s also tells that every wave has its (s-1, k-step 1) fragments in registers, so slot (s+2) % 3 = (s-1) % 3 is free.
-template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(256, 2) void gemm_4w_kernel(GemmParams p) {
-  static_assert(A_KMAJOR && B_KMAJOR, "4-wave kernel: k-major operands only");
-  constexpr int BM = 256, BN = 128, BK = 32, WM = 128, WN = 64, TM = 4, TN = 2;
-  constexpr int A_ST = BM * BK * 2, STAGE = (BM + BN) * BK * 2;      // 16 KB + 8 KB
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int ntile = p.tiles_m * p.tiles_n;
-  const int t_ = xcd_remap(blockIdx.x, ntile);
-  const int tm0 = (t_ / p.tiles_n) * BM;
-  const int tn0 = (t_ % p.tiles_n) * BN;
-  const int nk = p.K / BK;                                           // host-checked: K % 32 == 0
-#ifdef AVT_LAB
-  long long t4_start = 0, t4_loop = 0;
-  if (p.dbg) t4_start = __builtin_readcyclecounter();
-#endif
-
-  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t ra_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0, 0x00020000);
-  __amdgpu_buffer_rsrc_t rb_null = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0, 0x00020000);
-
-  // LDS-DMA: one instruction = 16 rows x 64 B; wave w stages rows j*64 + w*16 .. +15 of A (j = 0..3) and of B (j = 0, 1).
-  // Rows past the matrix edge lie past the descriptor's range and arrive as zeros.
-  uint32_t voffA[4], voffB[2];
-  {
-    const int rl = wave * 16 + (lane >> 2);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = j * 64 + rl;
-      const int c = (lane & 3) ^ kmajor_swz<BK>(r);
-      voffA[j] = (uint32_t)(((size_t)(tm0 + r) * (size_t)p.lda + (size_t)c * 8) * 2);
-      if (j < 2) voffB[j] = (uint32_t)(((size_t)(tn0 + r) * (size_t)p.ldb + (size_t)c * 8) * 2);
-    }
-  }
-  char* const dst = lds + wave * 16 * (BK * 2);                       // wave-uniform part of the destination
-  auto dma = [&](int q, int st) __attribute__((always_inline)) {      // q = 0..3: A rows, 4..5: B rows; st = stage to fetch
-    const uint32_t kadv = (uint32_t)st * (BK * 2);                    // scalar: k advance in bytes
-    char* d = dst + (st % 3) * STAGE;
-    if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(st < nk ? ra : ra_null, AVT_LDS_PTR(d + q * 64 * (BK * 2)), 16, voffA[q], kadv, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(st < nk ? rb : rb_null, AVT_LDS_PTR(d + A_ST + (q - 4) * 64 * (BK * 2)), 16, voffB[q - 4], kadv, 0, 0);
-  };
-  // fragment addresses: lane (i = l & 31, h = l >> 5) reads row (block*32 + i), 16-B chunk (ks*2 + h) ^ ((i >> 2) & 3); the
-  // row-block, the k-step (chunk ^ 2) and the slot are immediates of the ds_read
-  const int ch0 = (lane >> 5) ^ (((lane & 31) >> 2) & 3);
-  const char* const fa0 = lds + (wm * 128 + (lane & 31)) * (BK * 2) + ch0 * 16;
-  const char* const fa1 = lds + (wm * 128 + (lane & 31)) * (BK * 2) + (ch0 ^ 2) * 16;
-  const char* const fb0 = lds + A_ST + (wn * 64 + (lane & 31)) * (BK * 2) + ch0 * 16;
-  const char* const fb1 = lds + A_ST + (wn * 64 + (lane & 31)) * (BK * 2) + (ch0 ^ 2) * 16;
-  bf16x8_t af[2][TM], bfr[2][TN];
-  auto rdf = [&](int ks, int slot) __attribute__((always_inline)) {
-    const char* a = (ks ? fa1 : fa0) + slot * STAGE;
-    const char* b = (ks ? fb1 : fb0) + slot * STAGE;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) af[ks][i] = *(const bf16x8_t*)(a + i * 32 * (BK * 2));
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bfr[ks][j] = *(const bf16x8_t*)(b + j * 32 * (BK * 2));
-  };
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
-  // 8 MFMAs of k-step KS with the DMA instructions Q0 .. Q0+2 of stage ST after the 1st, 3rd and 5th of them
-#define W4_MFMA(KS, Q0, ST)                                                                              \
-  do {                                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                       \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                   \
-        acc[i][j] = mma<0>(af[KS][i], bfr[KS][j], acc[i][j]);                                            \
-        if (j == 0 && i < 3) { W4_PIN(); dma((Q0) + i, (ST)); W4_PIN(); }                               \
-      }                                                                                                  \
-  } while (0)
-  // one stage: S = stage index (runtime), SLOT = S % 3 (compile time)
-#define W4_STAGE(S, SLOT, FIRST)                                                                         \
-  do {                                                                                                   \
-    wait_vmcnt<6>();                                                                                     \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
-    W4_PIN(); asm volatile("s_barrier" ::: "memory"); W4_PIN();                                          \
-    rdf(0, SLOT); W4_PIN();                                                                              \
-    if (!(FIRST)) { W4_MFMA(1, 0, (S) + 2); } else { dma(0, (S) + 2); dma(1, (S) + 2); dma(2, (S) + 2); } \
-    W4_PIN(); rdf(1, SLOT); W4_PIN();                                                                    \
-    asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");       /* the six k-step-0 fragments are older than the six just requested */ \
-    W4_PIN(); W4_MFMA(0, 3, (S) + 2); W4_PIN();                                                          \
-  } while (0)
-
-  // prologue: stages 0 and 1
-#pragma unroll
-  for (int q = 0; q < 6; ++q) dma(q, 0);
-#pragma unroll
-  for (int q = 0; q < 6; ++q) dma(q, 1);
-  W4_STAGE(0, 0, true);
-  int s = 1;
-  for (; s + 2 < nk; s += 3) {            // slots 1, 2, 0
-    W4_STAGE(s, 1, false);
-    W4_STAGE(s + 1, 2, false);
-    W4_STAGE(s + 2, 0, false);
-  }
-  if (s < nk) { W4_STAGE(s, 1, false); ++s; }
-  if (s < nk) { W4_STAGE(s, 2, false); ++s; }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  W4_PIN();
-#pragma unroll
-  for (int i = 0; i < TM; ++i)            // k-step 1 of the last stage
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = mma<0>(af[1][i], bfr[1][j], acc[i][j]);
-  wait_vmcnt<0>();                        // the zero-length fetches past the end
-  W4_PIN(); asm volatile("s_barrier" ::: "memory"); W4_PIN();       // every wave is done with the ring: the epilogue reuses it
-#undef W4_STAGE
-#undef W4_MFMA
-#undef W4_PIN
-  int lane_e = lane, m0_e = tm0 + wm * WM, n0_e = tn0 + wn * WN;
-  asm volatile("" : "+v"(lane_e), "+s"(m0_e), "+s"(n0_e));
-#ifdef AVT_LAB
-  if (p.dbg) t4_loop = __builtin_readcyclecounter();
-#endif
-  gemm_epilogue<TM, TN, WM, WN, 0>(p, acc, lds, wave, lane_e, m0_e, n0_e);
-#ifdef AVT_LAB
-  if (p.dbg && tid == 0) {
-    const long long t_math = __builtin_readcyclecounter();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const long long t_end = __builtin_readcyclecounter();
-    uint32_t hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    long long* d_ = p.dbg + (size_t)blockIdx.x * 16;
-    d_[0] = t4_start; d_[1] = t4_loop; d_[2] = t_math; d_[3] = t_end; d_[4] = hw; d_[5] = xcc; d_[6] = nk; d_[7] = blockIdx.x;
-  }
-#endif
-}
+// (Round 3, measured and removed: a 4-wave 256x128x32 kernel, TWO workgroups per CU, so that one's epilogue runs under the other's K loop -- bit-identical
+// results, 65-86 % of every epilogue under the partner's K loop, and slower: fc1 forward 3648 vs 3274 us; profiles/r03_tile_timeline.txt, DESIGN.md section 4.
+// The source is part of tools/lab/avt_lab_hooks.diff.)
 
 // ---- 4-wave weight-gradient kernel: 256x256x32 tile, wave tile 128x128, accumulators in the AGPR half of the file ----------
 // C[m, n] += sum_k A[k, m] B[k, n], both operands stored reduction-index-major (dy^T x), split-K slabs (EPI 2).
@@ -907,13 +707,7 @@ template <int F>
 __device__ __forceinline__ void w4_frag_put(bf16x8_t (&af)[4], bf16x8_t (&bf)[4], bf16x8_t v) {
   if constexpr (F == 0) af[0] = v; else if constexpr (F <= 4) bf[F - 1] = v; else af[F - 4] = v;
 }
-// cache policy of the two operand streams (aux of buffer_load ... lds: 0 = default, 2 = nt, 16 = sc1); A/B switches, see profiles/r05e_w4_cache_policy.txt
-#ifndef AVT_W4_LDA_AUX
-#define AVT_W4_LDA_AUX 0
-#endif
-#ifndef AVT_W4_LDB_AUX
-#define AVT_W4_LDB_AUX 0
-#endif
+// (cache policy of the two operand streams: default on both -- nt on the dY stream / the x stream / both measured 0 / -0.7 / -0.9 % on the step, profiles/r05e_w4_cache_policy.txt)
 template <int EPI, bool DIRECT = false>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   static_assert(EPI == 2, "4-wave weight-gradient kernel: split-K slab epilogue only");
@@ -976,8 +770,8 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   };
   auto dma = [&](int q, int slot) __attribute__((always_inline)) {    // q = 0..3: A, 4..7: B, of the stage next_stage() prepared
     char* d = dst + slot * STAGE;
-    if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_t, AVT_LDS_PTR(d + q * 8 * ROWB), 16, voffA[q], 0, 0, AVT_W4_LDA_AUX);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_t, AVT_LDS_PTR(d + OP_T + (q - 4) * 8 * ROWB), 16, voffB[q - 4], 0, 0, AVT_W4_LDB_AUX);
+    if (q < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_t, AVT_LDS_PTR(d + q * 8 * ROWB), 16, voffA[q], 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_t, AVT_LDS_PTR(d + OP_T + (q - 4) * 8 * ROWB), 16, voffB[q - 4], 0, 0, 0);
   };
   // transposing fragment reads (frag_kstrided<256>): lane (g = l >> 4, i = l & 15) reads k rows ks*16 + (g>>1)*8 + (i>>2) + 4h
   // (h = 0, 1), columns tile*32 + (g&1)*16 + (i&3)*4 .. +3; the 16-B chunk index is swizzled with (row & 3) << 2 = (i>>2) << 2,
@@ -1113,20 +907,6 @@ int dispatch_w4(GemmParams& p, int a_kmajor, int b_kmajor, int splitk, hipStream
   return splitk == 1 ? 0 : launch_reduce<4, 4, 2, 2>(p, s);            // (splitk == 1: the kernel added its tiles into C itself)
 }
 
-int dispatch_4w(GemmParams& p, int epi, int a_kmajor, int b_kmajor, hipStream_t s) {
-  if (epi != 0 || !a_kmajor || !b_kmajor || p.K % 32 != 0) { avt_set_error("avt_gemm_bf16: tile 2564 (4-wave, two workgroups per CU) needs the activation epilogue, k-major operands and K %% 32 == 0"); return -1; }
-  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 127) / 128; p.splitk = 1;
-  constexpr int ring = 3 * (256 + 128) * 32 * 2, patch = 4 * epi_wave_lds<64>();
-  constexpr int smem = ring > patch ? ring : patch;
-  static_assert(2 * smem <= 160 * 1024, "two workgroups must fit one CU's LDS");
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)gemm_4w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
-  hipLaunchKernelGGL((gemm_4w_kernel<true, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), smem, s, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
-  return 0;
-}
-
 }  // namespace
 
 static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kmajor, int splitk, int K, hipStream_t s);
@@ -1144,6 +924,7 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
   AVT_CHECK(K % 8 == 0 || (!a_kmajor && !b_kmajor), "avt_gemm_bf16: K must be a multiple of 8 for k-major operands (K=%d)", K);
   AVT_CHECK(out_mode >= 0 && out_mode <= 3, "avt_gemm_bf16: out_mode must be 0 (bf16), 1 (fp32) or 2 (fp32 atomic accumulate)");
   AVT_CHECK(out_mode != 3 || (ws && aligned16(ws)), "avt_gemm_accum_bf16: needs a 16-byte aligned workspace");
+  AVT_CHECK(out_mode != 3 || (size_t)M * (size_t)ldc * 4 < 0xFFFFFFF0ull, "avt_gemm_accum_bf16: C larger than 4 GiB");      // (the one-split epilogue addresses C through a buffer descriptor)
   AVT_CHECK(act >= 0 && act <= 3, "avt_gemm_bf16: bad act %d", act);
   AVT_CHECK(act < 3 || aux, "avt_gemm_bf16: act %d needs aux", act);
   AVT_CHECK(drop_p >= 0.f && drop_p < 1.f, "avt_gemm_bf16: bad dropout p");
@@ -1172,10 +953,6 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
               "avt_gemm_ln_bf16: row statistics (stat_part) go with a bf16 bias (+ residual) epilogue, N %% 32 == 0 and 16-byte row strides");
     AVT_CHECK((!ln_stat || (((uintptr_t)ln_stat) & 7) == 0) && (!ln_c || aligned16(ln_c)) && (!stat_part || aligned16(stat_part)), "avt_gemm_ln_bf16: misaligned statistics");
   }
-#ifdef AVT_LAB
-  { static const char* e2 = getenv("AVT_GEMM_STAGGER"); p.stagger = e2 ? atoi(e2) : 0; }
-  { static const char* e = getenv("AVT_GEMM_DBG_PTR"); p.dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
-#endif
   size_t a_rows = a_kmajor ? (size_t)M : (size_t)K, b_rows = b_kmajor ? (size_t)N : (size_t)K;
   size_t ab = a_rows * (size_t)lda * 2, bb = b_rows * (size_t)ldb * 2;
   AVT_CHECK(ab < 0xFFFFFFF0ull && bb < 0xFFFFFFF0ull, "avt_gemm_bf16: operand larger than 4 GiB");
@@ -1204,13 +981,9 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
       // rounds waste most of a second round (72 / 282 / 1116 tiles: 23.4 / 27.2 / 17.7 us at K = 768).  Longer reductions and the other layouts keep
       // the 128 x 128 tiles there (head, 2560 x 2048 x 8192: 115 us against 125 on the 8-phase kernel and 191 on 64 x 64).
       const bool kk = a_kmajor && b_kmajor;
-#if defined(AVT_OLD_SMALL_TILE_RULE)      // A/B build: the rule of rounds 1-5
-      bm = (t256 >= 200) ? 256 : (t128 >= 192 ? 128 : 64); (void)kk;
-#else
       if (t256 >= 200 || (kk && K % 64 == 0 && t256 >= 96)) bm = 256;
       else if (t128 >= 192 && !(kk && K <= 3072)) bm = 128;
       else bm = 64;
-#endif
     }
     else {
       long sk = ((K + 63) / 64) / 4; if (sk < 1) sk = 1; if (sk > 64) sk = 64;
@@ -1256,7 +1029,6 @@ static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kma
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_epi<256, 256, 2, 4, 64, 2, true, 0, 1, 4>(p, epi, a_kmajor, b_kmajor, splitk, s);
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 2568: return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);       // all 8 waves issue LDS-DMA
-    case 2564: return dispatch_4w(p, epi, a_kmajor, b_kmajor, s);
     case 2565:                                                                                    // 4-wave weight-gradient kernel (128x128 wave tiles, AGPR accumulators)
       if (epi != 2) { avt_set_error("avt_gemm: tile 2565 is the deterministic weight-gradient kernel (avt_gemm_accum_bf16 only)"); return -1; }
       return dispatch_w4(p, a_kmajor, b_kmajor, splitk, s);                                  // 4 waves, 256x128x32, two workgroups per CU
@@ -1264,15 +1036,6 @@ static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kma
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_8p(p, epi, a_kmajor, b_kmajor, splitk, s, bm == 808 ? 0 : (bm == 809 ? 2 : 1));
       if (bm == 809) { avt_set_error("avt_gemm_bf16: tile 809 needs K %% 64 == 0"); return -1; }
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
-#ifdef AVT_LAB
-    // two independent 4-wave workgroups per CU (<= 80 KB LDS, <= 256 registers each), optionally started half a tile apart
-    // (AVT_GEMM_STAGGER cycles): while one is in its epilogue the other owns the matrix pipe
-    case 2563: return dispatch_epi<256, 128, 2, 2, 32, 3, true, 0, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
-    case 2562: return dispatch_epi<256, 128, 2, 2, 32, 3, false, 0, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
-    case 1283: return dispatch_epi<128, 256, 1, 4, 32, 3, true, 0, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
-    case 258: return dispatch_deepa(p, epi, a_kmajor, b_kmajor, splitk, s);                          // A ring 3 deep, B ring 2 deep
-    case 512: return dispatch_pp(p, epi, a_kmajor, b_kmajor, splitk, s);                            // ping-pong 256x256
-#endif
     default: break;
   }
   avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 64, 128, 643, 256 / 2568 (one barrier per K tile), 808 (8-phase) or 809 (8-phase, persistent) (got %d)", bm);

@@ -36,13 +36,10 @@
 
 namespace {
 
-// PK_FULLPF = 1: the epilogues without a second operand (bias, GELU) run in two slots + the space behind the ring, and the next tile's
-// K tile 1 halves A0h / B0h are fetched before the epilogue as well (six stages resident when a tile starts instead of four).  Built and
-// measured (256 clips, one box, whole step): 906.9 clips/s against 911.5 with the four-slot layout (off: 900.6) -- a tile's first K-loop
-// iteration stays 1.4x as long as the others either way (6.7 k against 4.9 k cycles), so that time is not the wait for those two stages.
-#ifndef PK_FULLPF
-#define PK_FULLPF 0
-#endif
+// (Measured and removed, round 4: running the epilogues without a second operand in two slots + the space behind the ring, so that the next tile's
+// K tile 1 halves A0h / B0h are fetched before the epilogue as well -- six stages resident when a tile starts instead of four: 906.9 clips/s against
+// 911.5 with the four-slot layout; a tile's first K-loop iteration stays 1.4x as long as the others either way, 6.7 k against 4.9 k cycles, so that time
+// is not the wait for those two stages.  profiles/r04_persistent_gemm.txt; the switch is part of tools/lab/avt_lab_hooks.diff.)
 // Fragment-major second output / second operand (late round 5; EPK 8 / 9 write it, EPK 10 / 11 read it; chosen by ldc2 == 0 / ldaux == 0 in the C ABI):
 // the saved GELU' of fc1 forward (C2) is only ever read back by the fc2 data gradient (aux), a launch with the same M, N and the same 128 x 64 wave
 // tiles -- a private tensor between two such kernels needs no row-major form.  Layout: per (128-row strip, 64-column group) 4 blocks x 4 KB, block i =
@@ -55,9 +52,6 @@ constexpr bool epk_aux(int e) { return e == 3 || e == 7 || e == 10 || e == 11; }
 constexpr bool epk_scale(int e) { return e == 7 || e == 11; }
 constexpr bool epk_fragw(int e) { return e == 8 || e == 9; }
 constexpr bool epk_fragr(int e) { return e == 10 || e == 11; }
-#ifndef AVT_PK_ABL      // timing-only ablations of the epilogues (lab builds: 1 = no GELU table gathers, 2 = the output stores stay in L2, 4 = no LDS patch round trip)
-#define AVT_PK_ABL 0
-#endif
 constexpr int PK_HALF = 128 * 64 * 2;                      // one half-tile slot of the ring: 16 KB
 // Longer reductions stay with gemm_8p_kernel unless the caller forces tile 809: what the persistent form removes is per-TILE time (fill,
 // store drain, workgroup turn-over: 12-20 % of a K = 768 tile, 2-4 % of a K = 3072 tile), and the step runs at the board's power limit --
@@ -65,10 +59,7 @@ constexpr int PK_HALF = 128 * 64 * 2;                      // one half-tile slot
 // 907.4 clips/s without, 920.1 with every shape persistent, 924.1 with K <= 1024 only; profiles/r04_persistent_gemm.txt).
 // Round 5, after the epilogue stores lost their waterfall loops: every shape persistent 963.5 / 962.5 against 960.2 / 958.6 clips/s with K <= 1024 only
 // (same box, profiles/r05j_persistent_all_k.txt): the limit now covers every reduction of ViT-B / ViT-L (K <= 4096).
-#ifndef AVT_PK_KMAX
-#define AVT_PK_KMAX 4096
-#endif
-constexpr int PK_KMAX = AVT_PK_KMAX;
+constexpr int PK_KMAX = 4096;
 
 // swizzled wave-private patch [32 rows][128 B]: the 8-byte position q8 (0..15) of row r lives at position q8 ^ (r & 15).
 // Writes (accumulator layout: lane = row, 8 B per (j, q)): the 32 lanes of a half-wave hit 16 positions x 2 rows each = every
@@ -125,9 +116,6 @@ struct PkStore {
     voff = (uint32_t)(lane >> 3) * ld2 + (uint32_t)(lane & 7) * 16u;
   }
   __device__ __forceinline__ void st(int row8, u32x4_t v) const {      // row8 = first row of the 8-row group (wave-uniform)
-#if AVT_PK_ABL & 2      // timing-only ablation: every output store lands in the tile's first 8 rows (no HBM write stream: the lines stay in L2)
-    row8 = 0;
-#endif
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff + (uint32_t)row8 * ld2, 0, AVT_ST_AUX);
   }
 };
@@ -139,11 +127,7 @@ __device__ __forceinline__ void pk_store_block(const char* patch_c, const char* 
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int row = it * 8 + rl;
-#if AVT_PK_ABL & 4
-    const u32x2_t lo = {(uint32_t)row, (uint32_t)pc}, hi = {(uint32_t)lane, (uint32_t)i32};
-#else
     const u32x2_t lo = *(const u32x2_t*)(patch_c + patch_rd(row, pc, 0)), hi = *(const u32x2_t*)(patch_c + patch_rd(row, pc, 1));
-#endif
     u32x2_t lo2 = lo, hi2 = hi;
     if (TWO) { lo2 = *(const u32x2_t*)(patch_d + patch_rd(row, pc, 0)); hi2 = *(const u32x2_t*)(patch_d + patch_rd(row, pc, 1)); }
     sc.st(i32 + it * 8, (u32x4_t){lo[0], lo[1], hi[0], hi[1]});
@@ -238,12 +222,8 @@ __device__ __forceinline__ void pk_epi_gelu_block(const GemmParams& p, const Epi
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-#if AVT_PK_ABL & 1      // timing-only ablation: no table gathers (wrong values)
-      e[2 * k] = off[k]; e[2 * k + 1] = off[k] ^ 0x55u;
-#else
       e[2 * k] = *(const uint32_t*)(tab + (off[k] & 0xffffu));
       e[2 * k + 1] = *(const uint32_t*)(tab + (off[k] >> 16));
-#endif
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -318,7 +298,7 @@ struct PkOperand {
       if (mrem <= 0) off = 0xFFFFFFF0u;                        // a strip wholly past M: zeros
 #pragma unroll
       for (int itr = 0; itr < 4; ++itr)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(buf + itr * 1024), 16, off == 0xFFFFFFF0u ? off : off + (uint32_t)(itr * 1024), 0, 0, AVT_LDP_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(buf + itr * 1024), 16, off == 0xFFFFFFF0u ? off : off + (uint32_t)(itr * 1024), 0, 0, 0);
       return;
     }
     const int rl = lane >> 3, pc = lane & 7;
@@ -329,7 +309,7 @@ struct PkOperand {
       const int n = col0 + ((pc ^ ((r_ >> 1) & 7)) * 8);
       uint32_t off = (uint32_t)(((size_t)m * (size_t)ld + (size_t)n) * 2);
       if (i * 32 + r_ >= mrem) off = 0xFFFFFFF0u;            // a row past M: out of the descriptor's range (zeros)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(buf + itr * 1024), 16, off, 0, 0, AVT_LDP_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, AVT_LDS_PTR(buf + itr * 1024), 16, off, 0, 0, 0);
     }
   }
 };
@@ -489,7 +469,6 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
   constexpr bool GELU = epk_gelu(EPK), FOLD = epk_fold(EPK), AUX = epk_aux(EPK);
   constexpr int TABB = GELU ? GELU_TAB_BYTES : 0;
   constexpr bool HAS_OP = (EPK == 2 || EPK == 4 || AUX);
-  constexpr bool FULLPF = !HAS_OP && PK_FULLPF;
   extern __shared__ __attribute__((aligned(16))) char smem8[];
   char* const lds = smem8 + TABB;                       // the ring: 8 half-tile slots (kind x K-tile parity), as in gemm_8p_kernel
   char* const ext = lds + 8 * HALF;                     // behind the ring: 32 KB (8 KB next to the table), idle during the K loop
@@ -497,9 +476,6 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wn = wave & 3;
-#if AVT_PK_STAGGER > 0        // A/B switch: the workgroups start spread over this many cycles (stagger_start, gemm_tile.hpp), so that their tiles' store tails do not coincide
-  stagger_start(AVT_PK_STAGGER, (int)blockIdx.x);
-#endif
   if constexpr (GELU) {       // the table: once per workgroup
     __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)g_gelu_tab, 0, GELU_TAB_BYTES, 0x00020000);
 #pragma unroll
@@ -508,7 +484,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
                                                (uint32_t)((wave * (GELU_TAB_BYTES / 8192) + i) * 1024 + lane * 16), 0, 0, 0);
   }
   // the wave's epilogue space: 8 KB in a parity-1 slot (two waves per slot), and its share of the space behind the ring
-  char* const P1 = FULLPF ? lds + (wave < 4 ? 5 : 7) * HALF + (wave & 3) * 4096 : lds + (2 * wn + 1) * HALF + grp * 8192;
+  char* const P1 = lds + (2 * wn + 1) * HALF + grp * 8192;
   char* const P2 = ext + wave * (GELU ? 1024 : 4096);
 
   const int ntile = p.tiles_m * p.tiles_n;
@@ -609,7 +585,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
     char* d = dstw + ((h ? 3 : 0) * 2 + (kt & 1)) * HALF;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, AVT_LDS_PTR(d + j * JSTEP), 16, base_a + (adv + (uint32_t)(j * 128 + h * 64) * lda2), 0, 0, AVT_LDA_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, AVT_LDS_PTR(d + j * JSTEP), 16, base_a + (adv + (uint32_t)(j * 128 + h * 64) * lda2), 0, 0, 0);
   };
   auto stage_b = [&](int h, int kt) __attribute__((always_inline)) {
     const bool in = kt < nk;
@@ -617,7 +593,7 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
     char* d = dstw + ((h ? 2 : 1) * 2 + (kt & 1)) * HALF;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, AVT_LDS_PTR(d + j * JSTEP), 16, base_b + (adv + (uint32_t)(j * 128 + h * 32) * ldb2), 0, 0, AVT_LDB_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, AVT_LDS_PTR(d + j * JSTEP), 16, base_b + (adv + (uint32_t)(j * 128 + h * 32) * ldb2), 0, 0, 0);
   };
   bf16x8_t fa[2][4], fb0[4], fb1[4], fb0n[4];
   auto read_a = [&](bf16x8_t (&f)[2][4], int h, int par) __attribute__((always_inline)) {
@@ -670,21 +646,13 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
   // first tile: its K tile 0 (the later tiles find theirs in the ring when they start)
   if (has_cur) {
   stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
-  if (FULLPF) { stage_a(0, 1); stage_b(0, 1); }
   wait_vmcnt<0>();
   P8_BARRIER();
 
-#ifdef AVT_LAB
-  int tile_k = 0;
-#endif
   for (;;) {
-#ifdef AVT_LAB
-    long long ts_top = 0, ts_loop = 0, ts_epi = 0, ts_w2 = 0;
-    if (p.dbg) ts_top = __builtin_readcyclecounter();
-#endif
-    // here: the four parity-0 slots hold K tile 0 of `cur` (FULLPF: slots 1 and 3 its K tile 1 halves A0h, B0h), every other slot is free,
+    // here: the four parity-0 slots hold K tile 0 of `cur`, every other slot is free,
     // nothing but stores is in flight
-    if (!FULLPF) { stage_a(0, 1); stage_b(0, 1); }
+    stage_a(0, 1); stage_b(0, 1);
     if (grp == 1) P8_BARRIER();
     f32x16_t acc[4][2];                                     // (first written by the zero-operand MFMAs of iteration 0)
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -696,25 +664,15 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
 #pragma nounroll
     for (int t = 0; t < nk; t += 2) {
       const bool last = t + 2 >= nk;
-#ifdef AVT_LAB
-      if (p.dbg && (tid == 0) && tile_k == 3 && t < 16) p.dbg[(size_t)256 * 128 * 2 * 8 + (size_t)blockIdx.x * 16 + (t >> 1)] = __builtin_readcyclecounter();
-#endif
       // ---- even K tile t (slot parity 0).  t == 0: B1h / A1h of K tile 0 landed before the epilogue's barrier -- no counted wait
       //      (a vmcnt(8) there would wait for the previous tile's stores) ----
       read_a(fa, 0, 0); P8_PIN(); stage_b(1, t + 1); if (t) wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA0(fa, fb0, 0, 0); P8_BARRIER();
       read_b(fb1, 1, 0); P8_PIN(); stage_a(1, t + 1); if (t) wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA0(fa, fb1, 0, 1); P8_BARRIER();
-#ifdef AVT_LAB
-      long long tw0 = 0;
-      if (p.dbg && t == 0) tw0 = __builtin_readcyclecounter();
-#endif
-      read_a(fa, 1, 0); P8_PIN(); stage_a(0, t + 2); if (t || !FULLPF) wait_vmcnt<6>(); P8_BARRIER();
-#ifdef AVT_LAB
-      if (p.dbg && t == 0) ts_w2 = __builtin_readcyclecounter() - tw0;
-#endif
+      read_a(fa, 1, 0); P8_PIN(); stage_a(0, t + 2); wait_vmcnt<6>(); P8_BARRIER();
       P8_MFMA0(fa, fb1, 2, 1); P8_BARRIER();
-      read_b(fb0n, 0, 1); P8_PIN(); stage_b(0, t + 2); if (t || !FULLPF) wait_vmcnt<8>(); P8_BARRIER();
+      read_b(fb0n, 0, 1); P8_PIN(); stage_b(0, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA0(fa, fb0, 2, 0); P8_BARRIER();
       // ---- odd K tile t+1 (slot parity 1).  In the last iteration the stages of "K tile nk" fetch the next output tile's K tile 0;
       //      those of K tile nk + 1 are left out (their slots become the epilogue's) ----
@@ -740,24 +698,19 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
       read_b(fb1, 1, 1); P8_PIN(); stage_a(1, t + 2); wait_vmcnt<8>(); P8_BARRIER();
       P8_MFMA(fa, fb1, 0, 1); P8_BARRIER();
       read_a(fa, 1, 1); P8_PIN();
-      if (!last || FULLPF) { stage_a(0, t + 3); wait_vmcnt<6>(); }
+      if (!last) { stage_a(0, t + 3); wait_vmcnt<6>(); }
       else {
         if (HAS_OP) op.template dma_block<epk_fragr(EPK)>(P2, pk_lane_id(), m0_e, n0_e, 0, mrem);          // the epilogue's second operand, block 0 -> behind the ring
       }
       P8_BARRIER();
       P8_MFMA(fa, fb1, 2, 1); P8_BARRIER();
       if (!last) { read_b(fb0, 0, 0); P8_PIN(); stage_b(0, t + 3); wait_vmcnt<8>(); }
-      else if (FULLPF) { stage_b(0, t + 3); wait_vmcnt<8>(); }
       P8_BARRIER();
       P8_MFMA(fa, fb0n, 2, 0); P8_BARRIER();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (grp == 0) P8_BARRIER();
     P8_BARRIER();                                          // every fragment read retired: the parity-1 slots are free
-#ifdef AVT_LAB
-    if (p.dbg) ts_loop = __builtin_readcyclecounter();
-    if (p.dbg && (tid == 0) && tile_k == 3) p.dbg[(size_t)256 * 128 * 2 * 8 + (size_t)blockIdx.x * 16 + 8] = ts_loop, p.dbg[(size_t)256 * 128 * 2 * 8 + (size_t)blockIdx.x * 16 + 9] = ts_top;
-#endif
     int tk;
     {
       // the epilogue's pointers and strides are re-read from the kernel-argument segment for every tile (scalar loads through a
@@ -788,9 +741,6 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
         tk = pk_epi_ext<EPK>(pe, acc, P1, P2, P1 + 4096, op, bias_v, lane_e, m0_e, n0_e, tkt, mrem);
       }
     }
-#ifdef AVT_LAB
-    if (p.dbg) ts_epi = __builtin_readcyclecounter();
-#endif
     if (GELU && two_outputs) wait_vmcnt<32>();        // (GELU + GELU': 32 stores per wave and tile)
     else if (EPK == 4) wait_vmcnt<20>();                   // (16 output stores + 4 of the row statistics)
     else wait_vmcnt<16>();                                 // everything older than the tile's last 16 stores: the next tile's K tile 0, the ticket
@@ -809,13 +759,6 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     P8_BARRIER();                                          // ... for every wave's share of it; and every patch has been read back
-#ifdef AVT_LAB
-    if (p.dbg && (tid == 0 || tid == 256) && tile_k < 128) {   // tile start, end of K loop, epilogue issued, next tile may start, phase-2 wait of iteration 0
-      long long* d_ = p.dbg + (((size_t)blockIdx.x * 128 + tile_k) * 2 + grp) * 8;
-      d_[0] = ts_top; d_[1] = ts_loop; d_[2] = ts_epi; d_[3] = __builtin_readcyclecounter(); d_[4] = ts_w2; d_[5] = xcc; d_[6] = nk; d_[7] = tile_k;
-    }
-    ++tile_k;
-#endif
     if (!has_next) break;
     vic = __builtin_amdgcn_readfirstlane(mailbox[1]);
     tkn = __builtin_amdgcn_readfirstlane(mailbox[0]);      // the position of the tile after the one that starts now: turned into a tile under
@@ -905,9 +848,6 @@ int avt_gemm_persist(GemmParams& p, int kinds, bool force, hipStream_t s) {
   if (p.splitk != 1 || p.out_f32 || !p.wide_ok || p.drop_thresh || p.res_period) return 0;
   if (p.N % 256 || p.K % 128 || p.K < 256) return 0;
   int kmax = PK_KMAX;
-#ifdef AVT_LAB
-  { const char* e = getenv("AVT_GEMM_PERSIST_KMAX"); if (e) kmax = atoi(e); }
-#endif
   if (p.K > kmax && !force) return 0;
   const int ntile = p.tiles_m * p.tiles_n;
   if (ntile < 512 || ntile >= 65536) return 0;              // fewer than two tiles per CU: nothing to overlap (measured at 288 tiles: 122-133 us against 64-104 us for the one-tile kernel's GELU epilogues -- table load and set-up per workgroup for one tile each); (the walk's reciprocals: n, d < 2^16)

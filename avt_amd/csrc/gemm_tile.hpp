@@ -23,9 +23,6 @@ struct GemmParams {
   float* ws;                     // EPI 2: split-K partial slabs, [splitk * tiles][BM * BN] fp32 in accumulator order
   uint32_t a_bytes, b_bytes;     // buffer-descriptor bounds
   uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
-#ifdef AVT_LAB
-  int stagger;                   // lab only: cycles over which the first wave of workgroups spreads its start (0 = off)
-#endif
   int wide_ok;                   // all epilogue leading dims are multiples of 8 -> 16-byte accesses allowed
   // LayerNorm folded into the GEMMs around it (avt_gemm_ln_bf16, include/avt_hip.h):
   //   ln_c != NULL ("fold"): A holds the UN-normalised rows x, B = gamma o W, and v = rstd[m] * acc + (bias[n] - mean[m] * rstd[m] * ln_c[n]) with
@@ -36,9 +33,6 @@ struct GemmParams {
   const float* ln_stat; const float* ln_c; float* stat_part;
   // fragment-major second output / second operand (ldc2 == 0 / ldaux == 0 in the C ABI; gemm_persist.hip: the persistent kernel only)
   int c2_frag, aux_frag;
-#ifdef AVT_LAB
-  long long* dbg;                // lab only: per-block phase timestamps (s_memtime)
-#endif
 };
 // gemm_persist.hip: the persistent form of the 8-phase kernel (one workgroup per CU walks a queue of output tiles and keeps the
 // next tile's first operand half-tiles in flight while it converts and stores the current one).  Returns 1 = launched,
@@ -51,25 +45,10 @@ namespace {
 
 // Instrumentation and experiment switches exist only in the lab build (make lab -> libavt_hip_lab.so, used by tools/):
 // the product library reads no environment variable and takes no pointer from anywhere but its arguments.
-#ifdef AVT_LAB
-#define AVT_DBG(p) ((p).dbg)
-#define AVT_STAGGER(p) ((p).stagger)
-#else
-#define AVT_DBG(p) ((long long*)nullptr)
-#define AVT_STAGGER(p) 0
-#endif
 
 constexpr int BK64 = 64;
-// cache policy of the 8-phase kernel's operand streams (aux of buffer_load ... lds: 0 = default, 2 = nt)
-#ifndef AVT_LDA_AUX
-#define AVT_LDA_AUX 0
-#endif
-#ifndef AVT_LDB_AUX
-#define AVT_LDB_AUX 0
-#endif
-#ifndef AVT_LDP_AUX          // the epilogue's second operand (saved derivative / residual), read exactly once
-#define AVT_LDP_AUX 0
-#endif
+// (cache policy of the operand streams and of the epilogue's second operand: default -- nt on the A stream costs 0.3-0.6 %, on the second operand it is
+// neutral; profiles/r04_cache_policy.txt)
 
 // XCD-aware bijective remap of the linear block id: XCD x (= id % 8 by dispatch order) owns a contiguous
 // range of logical blocks, ordered (split, tile row, tile column), so tiles sharing an A row-panel sit behind the same L2
@@ -283,29 +262,6 @@ __device__ __forceinline__ void frag4_tr_na(bf16x8_t (&f)[4], uint32_t addr) {
     f[ks] = tr_join(lo, hi);
   }
 }
-// De-synchronise the chip: all CUs start together and would otherwise hit their output-store tails together (a burst at
-// the HBM write rate while the MFMA pipes idle).  The workgroups of the FIRST dispatch wave start spread over
-// `cycles`; every CU keeps its offset afterwards because it picks up its next tile when it finishes the previous one.
-__device__ __forceinline__ void stagger_start(int cycles, int bid) {
-  if (cycles <= 0 || bid >= 256) return;
-  const long long target = (long long)cycles * ((bid >> 3) & 31) / 32;
-  const long long t0 = __builtin_readcyclecounter();
-  while (__builtin_readcyclecounter() - t0 < target) __builtin_amdgcn_s_sleep(16);
-}
-
-#ifdef AVT_LAB
-// lab: two workgroups share a CU; the one in the odd threadgroup slot of the FIRST dispatch wave starts `cycles` late, so that
-// afterwards one workgroup's epilogue (vector ALU, stores) runs under the other's K loop (matrix pipe) instead of both doing
-// the same thing at the same time.  HW_REG_HW_ID (id 4): TG_ID = bits 19:16.
-__device__ __forceinline__ void stagger_slot(int cycles, int bid, int nfirst) {
-  if (cycles <= 0 || bid >= nfirst) return;
-  uint32_t hw;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-  if (((hw >> 16) & 1u) == 0) return;
-  const long long t0 = __builtin_readcyclecounter();
-  while (__builtin_readcyclecounter() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
-}
-#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -494,18 +450,15 @@ __device__ __forceinline__ void epi_write_block_i(float* patch, const f32x16_t (
 // dropped from L2 -- MI355X_MICROARCH.md, price list "stores of each flavour").  Measured on the whole step (256 clips, same box,
 // profiles/r04_cache_policy.txt): plain 878.7 / 880.3 clips/s, sc1 883.6 / 882.7, nt 889.2 / 887.4 (+1.0 %; fc1 forward 3094 ->
 // 2990 us with sc1) -> nt is the product's policy.  Rows are addressed relative to the wave tile's origin through a buffer descriptor.
-#ifndef AVT_ST_AUX
-#define AVT_ST_AUX 2
-#endif
+constexpr int AVT_ST_AUX = 2;
 struct TileStore {
   __amdgpu_buffer_rsrc_t r; bf16_t* base; int ld;
   __device__ __forceinline__ void init(bf16_t* origin, int ld_) {
     base = origin; ld = ld_;
-    if (AVT_ST_AUX != 0) r = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, 0xFFFFFFF0u, 0x00020000);
+    r = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, 0xFFFFFFF0u, 0x00020000);
   }
   __device__ __forceinline__ void st(int drow, int dcol, u32x4_t v) const {
-    if (AVT_ST_AUX == 0) *(u32x4_t*)(base + (size_t)drow * ld + dcol) = v;
-    else __builtin_amdgcn_raw_buffer_store_b128(v, r, (uint32_t)((drow * ld + dcol) * 2), 0, AVT_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (uint32_t)((drow * ld + dcol) * 2), 0, AVT_ST_AUX);
   }
 };
 
@@ -698,7 +651,7 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
       const int mr = prim_period ? (m % prim_period) : m;
       uint32_t off = (uint32_t)(((size_t)mr * (size_t)prim_ld + (size_t)n) * 2);
       if (m >= p.M || n >= p.N) off = 0xFFFFFFF0u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, AVT_LDS_PTR(opbuf + (i & 1) * OPB + itr * 1024), 16, off, 0, 0, AVT_LDP_AUX);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, AVT_LDS_PTR(opbuf + (i & 1) * OPB + itr * 1024), 16, off, 0, 0, 0);
     }
   };
   if (has_prim) { dma_block(0); if (TM > 1) dma_block(1); }
@@ -831,46 +784,53 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
   }
 }
 
-// split-K slab stores (written once, read once by splitk_reduce_kernel): 0 = plain, 1 = nontemporal
-#ifndef AVT_SLAB_NT
-#define AVT_SLAB_NT 0
-#endif
-#if AVT_SLAB_NT
-#define AVT_SLAB_ST(ptr, val) __builtin_nontemporal_store((val), (f32x4_t*)(ptr))
-#else
+// split-K slab stores (written once, read once by splitk_reduce_kernel): plain -- nontemporal measured +0.15 % (noise), profiles/r05e_w4_cache_policy.txt
 #define AVT_SLAB_ST(ptr, val) (*(f32x4_t*)(ptr) = (val))
-#endif
 // LN: compile the LayerNorm-fold variants of the epilogue (only the kernels with both operands k-major are ever asked for them)
-// DIRECT (EPI 2): 1 = the workgroup holds the whole reduction (splitk == 1) and adds its tile into C itself, 0 = slabs, -1 = decided at run time
-// (the register-limited 4-wave kernel compiles the two as separate instantiations: with both in one body it spilled 16 registers)
-template <int TM, int TN, int WM, int WN, int EPI, int PR = 0, bool TAB = false, bool LN = false, int DIRECT = -1>
+// DIRECT (EPI 2): 1 = the workgroup holds the whole reduction (splitk == 1) and adds its tile into C itself, 0 = slabs.  Only the 4-wave weight-gradient
+// kernel has the direct form, as a separate instantiation (both in one body spilled 16 of its registers; in the generic 128 x 128 kernel the 64 values in
+// flight would cost the second workgroup per CU): the head's 2048 x 8192 weights are what it is for.
+template <int TM, int TN, int WM, int WN, int EPI, int PR = 0, bool TAB = false, bool LN = false, int DIRECT = 0>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&acc)[TM][TN], char* lds, int wave, int lane,
                                               int row0, int col0, const char* tab = nullptr) {
   // row0/col0: global coordinates of this wave's tile origin
   static_assert(WM == TM * 32 && WN == TN * 32 && TM <= 4, "wave tile geometry");
   if (EPI == 2) {
-    if (DIRECT == 1 || (DIRECT < 0 && p.splitk == 1)) {
+    if constexpr (DIRECT == 1) {
       // (round 6) the whole reduction sits in this workgroup: C += acc right here -- every C element has exactly one owner, plain read-modify-write,
       // the same sum bit for bit as a one-slab reduce -- instead of a slab round trip (tile written, re-read, C read and written) and a second launch.
       // Each store instruction covers two rows x 32 consecutive columns: two full 128-byte lines.  (The head's 2048 x 8192 weights at <= 2560 rows.)
-      float* C = (float*)p.C;
+      // Branch-free, batched: all the loads of a 32-row block row (TN x 16 per lane) are issued before the first add, and elements past M / N are
+      // kept out by the buffer descriptor's bounds check (an out-of-range offset: loads return 0, stores are dropped) instead of a predicate.  The
+      // first version -- a plain `if (in range) C[..] += acc` loop -- compiled to s_waitcnt vmcnt(0) in front of every one of the 256 stores per wave
+      // (hipcc waits for everything outstanding at a branch that hides the count) and cost +95 us per launch (profiles/r06e_direct_accumulate_ab.txt).
+      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.C, 0, (uint32_t)((size_t)p.M * (size_t)p.ldc * 4), 0x00020000);   // (host-checked: < 4 GiB)
       const int nl = lane & 31, hq = 4 * (lane >> 5);
+      const uint32_t ld4 = (uint32_t)p.ldc * 4u;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) {
+        float old[TN][16];
+        uint32_t off[TN][4];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int n = col0 + j * 32 + nl;
-          if (n < p.N) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int m0 = row0 + i * 32 + 8 * q + hq;
-              float* c = C + (size_t)m0 * (size_t)p.ldc + n;
+          for (int q = 0; q < 4; ++q) {
+            const int m0 = row0 + i * 32 + 8 * q + hq;
+            off[j][q] = n < p.N ? (uint32_t)m0 * ld4 + (uint32_t)n * 4u : 0xFFFFFFF0u;      // (rows past M end up past the descriptor's range by themselves)
 #pragma unroll
-              for (int k = 0; k < 4; ++k)
-                if (m0 + k < p.M) c[(size_t)k * p.ldc] += acc[i][j][4 * q + k];
-            }
+            for (int k = 0; k < 4; ++k) old[j][4 * q + k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, off[j][q] == 0xFFFFFFF0u ? off[j][q] : off[j][q] + (uint32_t)k * ld4, 0, 0));
           }
         }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, old[j][4 * q + k] + acc[i][j][4 * q + k]), rc,
+                                                    off[j][q] == 0xFFFFFFF0u ? off[j][q] : off[j][q] + (uint32_t)k * ld4, 0, 0);
+      }
       return;
     }
     // deterministic weight-gradient epilogue: this block's partial tile goes to its own slab of the caller's workspace in
@@ -951,7 +911,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
         const int mr = prim_period ? (m % prim_period) : m;
         uint32_t off = (uint32_t)(((size_t)mr * (size_t)prim_ld + (size_t)e.n) * 2);
         if (m >= p.M || !e.ncol_ok) off = 0xFFFFFFF0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, AVT_LDS_PTR(opbuf + (i & 1) * OPB + itr * 1024), 16, off, 0, 0, AVT_LDP_AUX);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, AVT_LDS_PTR(opbuf + (i & 1) * OPB + itr * 1024), 16, off, 0, 0, 0);
       }
     };
     if (staged) { dma_block(0); if (TM > 1) dma_block(1); }

@@ -12,39 +12,15 @@
 #include <cstdlib>
 #include <type_traits>
 #include "common.hpp"
-// L2 policy of the attention kernels' streams (A/B switches).  Measured (profiles/r04_cache_policy.txt): nt on the K / V / Q / dO tile
-// loads costs 15 % (forward 708 -> 820 us at 2560 frames: the twelve heads of a frame read adjacent 128-byte pieces of the same qkv rows),
-// so the loads keep the default policy.
-#ifndef AVT_ATTN_LD_AUX
-#define AVT_ATTN_LD_AUX 0
-#endif
-// ... and so do the output stores (nt on the 8-byte stores of round 4: forward 727 -> 945 us, backward 2276 -> 2576 us).
-// Round 5: the outputs leave in 16-byte pieces (AVT_ATTN_WIDE_ST, see the forward kernel's last lines); 0 = the 8-byte stores, for A/B.
+// Settled by A/B runs (records in profiles/; the switches themselves live on in tools/lab/avt_lab_hooks.diff):
+//  * L2 policy: nt on the K / V / Q / dO tile loads costs 15 % (forward 708 -> 820 us at 2560 frames: the twelve heads of a frame read adjacent
+//    128-byte pieces of the same qkv rows) and nt on the output stores more (forward 727 -> 945 us): default policy everywhere (profiles/r04_cache_policy.txt).
+//  * The outputs leave in 16-byte pieces (round 5, see the forward kernel's last lines; profiles/r05d_attention_stores.txt).
+//  * A start stagger of the persistent workgroups gains nothing (1845-1881 vs 1834-1845 us: the CUs are not in a harmful lockstep).
+//  * The dK / dV of an item leave in chunk 0 of the NEXT item (packed, 16 registers that are free there: the new accumulators are not live before the
+//    chunk's first dV product) instead of in the item's tail, next to the strip requests (-2.6 % per launch); barrier S2 inside chunk 0 and the tail in
+//    front of the last chunk's dQ products measured no better (profiles/r05n_attention_boundary.txt).
 #define AVT_ATTN_STG(p, v) (*(p) = (v))
-#ifndef AVT_ATTN_WIDE_ST
-#define AVT_ATTN_WIDE_ST 1
-#endif
-#ifndef AVT_ATTN_ABL               // timing-only ablations of the single-pass backward (WRONG results; tools/lab/job_r05p.sh): bit 0 no dK / dV stores,
-#define AVT_ATTN_ABL 0             // 1 no wait for the K tile in chunk 0, 2 no barrier S2, 3 no dQ products, 4 no K / V strip requests, 5 no row requests of the last chunk, 6 no scalar requests
-#endif
-// Start stagger: the persistent workgroups all start together and every item takes the same time, so all 256 CUs reach their items' ends -- the
-// dK / dV / dQ (forward: O) stores and the next strips' requests -- at the same moment; workgroup b sleeps ((b / 8) mod 32) x AVT_ATTN_STAGGER_* x 64 cycles first
-// (b mod 8 is the XCD: 32 phases inside every XCD).
-#ifndef AVT_ATTN_STAGGER_BWD
-#define AVT_ATTN_STAGGER_BWD 0
-#endif
-#ifndef AVT_ATTN_STAGGER_FWD
-#define AVT_ATTN_STAGGER_FWD 0
-#endif
-#ifndef AVT_ATTN_LATE_ST           // A/B switch: the dK / dV of an item leave in chunk 0 of the NEXT item (packed, 16 registers that are free there: the new
-#define AVT_ATTN_LATE_ST 1         // accumulators are not live before the chunk's first dV product) instead of in the item's tail, next to the strip requests
-#endif
-#ifndef AVT_ATTN_S2_LATE
-#define AVT_ATTN_S2_LATE 0       // 1: measured no better (1872 / 1868 vs 1852 / 1862 us per launch)
-#endif
-#ifndef AVT_ATTN_TAIL_FIRST
-#define AVT_ATTN_TAIL_FIRST 0      // 1: measured no better (backward 1849 vs 1842 us per launch, step 955.9 / 953.8 vs 957.0 / 954.6 clips/s; profiles/r05o_attention_boundary.txt)
-#endif
 #include "../../include/avt_hip.h"
 
 namespace {
@@ -102,7 +78,7 @@ __device__ __forceinline__ void stage_head_dma(const bf16_t* src, int ld, int S,
     uint32_t off = (uint32_t)(((size_t)r * (size_t)ld + (size_t)c * 8) * 2);
     if (r >= S) off = 0xFFFFFFF0u;
     char* dst = rm + __builtin_amdgcn_readfirstlane(j) * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(dst), 16, off, 0, 0, AVT_ATTN_LD_AUX);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(dst), 16, off, 0, 0, 0);
   }
 }
 
@@ -281,9 +257,6 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
   };
   uint32_t troff[4];
   tr_lane_offsets(lane, troff);
-  if (AVT_ATTN_STAGGER_FWD > 0) {
-    for (int i = (int)((blockIdx.x >> 3) & 31u); i > 0; --i) __builtin_amdgcn_s_sleep(AVT_ATTN_STAGGER_FWD);
-  }
   if (item < items) {
     const bf16_t* base = qkv + (size_t)(item / H) * S * ld + (item % H) * HD;
     stage_head_dma(base + D, ld, S, smem, KP, wv, NKT, lane);
@@ -304,7 +277,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
     // (late round 5: the Q strip, requested right behind the tiles, is waited for here too -- all but the previous item's 3 / 5 stores -- and the
     // barrier is a bare s_barrier: __syncthreads() brought a full `s_waitcnt vmcnt(0)` with it, i.e. the completion of those stores)
 #define AVT_Q_LANDED(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bq[0]), "+v"(bq[1]) :: "memory")
-    if (ALL_LIVE) { if (AVT_ATTN_WIDE_ST) AVT_Q_LANDED(3); else AVT_Q_LANDED(5); }
+    if (ALL_LIVE) AVT_Q_LANDED(3);
     else AVT_Q_LANDED(0);
 #undef AVT_Q_LANDED
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // also: everyone is done with the other buffer (item n-1)
@@ -386,7 +359,6 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
     }
     const int q = q0 + (lane & 15);
     const float inv = 1.0f / sum;
-#if AVT_ATTN_WIDE_ST
     {
       // 16-byte stores: v_permlane16_swap exchanges the odd 16-lane rows of block dt with the even rows of block dt + 1, after which lane (i, g)
       // holds 8 consecutive columns of block dt + (g & 1): 64 contiguous bytes per output row and instruction instead of 32 (round 5: backward
@@ -409,327 +381,12 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_fwd_kernel(const bf16_t* __
         *(u32x4_t*)(orow + (2 + (g & 1)) * 16) = st2[1];
       }
     }
-#else
-    if (q < S) {
-      bf16_t* orow = out + ((size_t)frame * S + q) * D + head * HD;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        u32x2_t w; w[0] = pack2bf(o[dt][0] * inv, o[dt][1] * inv); w[1] = pack2bf(o[dt][2] * inv, o[dt][3] * inv);
-        AVT_ATTN_STG((u32x2_t*)(orow + dt * 16 + 4 * g), w);
-      }
-    }
-#endif
     if (q < S && g == 0) lse[((size_t)frame * H + head) * S + q] = mx * scale + __logf(sum);
   }
 }
 
-// Backward: persistent workgroups (one per CU -- the four operand tiles of a head take 112 KB of LDS), each walking over
-// (frame, head) items.  Per item:
-//     barrier 1 (everyone is done with the previous item; K/V of this item -- requested during the previous item's phase B --
-//                have landed)  ->  request Q, dO (LDS-DMA) and fetch this wave's own Q / dO / O strips from global
-//     phase A: dQ of this wave's 16 queries (needs the K, V tiles + own strips)
-//     barrier 2 (Q, dO landed; nobody reads K/V tiles any more)  ->  request K, V of the NEXT item
-//     phase B: dK, dV of this wave's 16 keys (needs the Q, dO tiles + own K / V strips, taken before barrier 2)
-// so the global -> LDS latency of every tile hides behind the other phase.  Column sums of dq|dk|dv (the qkv bias gradient)
-// are kept in LDS per head for the whole kernel and flushed once.  Every wave stores the sums of its strip into its own row of
-// a staging array; after the next barrier the rows are added in wave order by the column's owner thread, so the per-workgroup
-// sums do not depend on which wave arrived first.  The flush stores one partial vector per workgroup when the caller gave a
-// partials workspace (merged in fixed order by avt_reduce_partials: bit-identical from run to run), else fp32 atomics.
-template <int NKT, bool ALL_LIVE>
-__global__ __launch_bounds__(64 * NKT) void vit_attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
-                                                                const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                                bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
-                                                                float* __restrict__ part, int S, int H, int items, float scale, long long* dbg) {
-  long long tcs = 0, tca = 0, tcb = 0, tw1 = 0, tw2 = 0, tc0 = dbg ? __builtin_readcyclecounter() : 0;      // lab stamps (dbg is null in the product library)
-  constexpr int NP = (NKT + 1) / 2;
-  constexpr int KP = NP * 32;                // rows of every LDS tile (zero padded)
-  constexpr int RM = KP * 128;               // bytes of a row-major [KP][64] bf16 tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // Q, K, V, dO of one (frame, head), all swizzled row-major; operands that a product needs "transposed" are gathered
-  // with ds_read_b64_tr_b16 (frag_tr_rm), so no transposed copy is built.  Zero padding of rows >= S makes every
-  // padded key / query contribute exactly zero to dQ, dK, dV (no masks in the inner loops).
-  char* Qs = smem;
-  char* Ks = smem + RM;
-  char* Vs = smem + 2 * RM;
-  char* dOs = smem + 3 * RM;
-  float* lse_s = (float*)(smem + 4 * RM);    // lse * log2(e)
-  float* dq_s = lse_s + KP;                  // D[q] * scale,  D[q] = sum_d dO[q,d] O[q,d]
-  float* bias_s = dq_s + KP;                 // [H][3*64] column sums of dq | dk | dv
-  float* stage_s = bias_s + H * 192;         // [NKT][3*64] this item's sums per wave
-  int prev_head = -1;
-  const int D = H * HD, ld = 3 * D;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = 64 * NKT;
-  const int g = lane >> 4;
-  const int wv = __builtin_amdgcn_readfirstlane(wave);
-  const float sl = scale * LOG2E;
-
-  if (dbias) for (int i = tid; i < H * 192; i += nthr) bias_s[i] = 0.f;
-  int item = blockIdx.x;
-  const int q0 = wave * 16, q = q0 + (lane & 15);
-  uint32_t tr0[4], tr1[4];                     // LDS addresses of the lane's transposing reads: tiles below / above 64 KB
-  tr_lane_offsets(lane, tr0);
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) { tr0[dt] += lds_addr32(smem); tr1[dt] = tr0[dt] + 65536u; }
-  // this wave's own Q / dO / O strips and lse of the NEXT item are fetched (to registers) at the end of phase B of the current one
-  bf16x8_t nq[2], ndo[2], no[2];
-  float nlq = 0.f;
-  auto fetch_strips = [&](int it) __attribute__((always_inline)) {
-    const int fr = it / H, hd = it % H;
-    const size_t r0 = (size_t)fr * S;
-    load_strip(qkv + r0 * ld + hd * HD, ld, S, q0, lane, nq);
-    load_strip(dout + r0 * D + hd * HD, D, S, q0, lane, ndo);
-    load_strip(out + r0 * D + hd * HD, D, S, q0, lane, no);
-    nlq = (q < S) ? lse[((size_t)fr * H + hd) * S + q] * LOG2E : 0.f;
-  };
-  if (item < items) {
-    const bf16_t* base = qkv + (size_t)(item / H) * S * ld + (item % H) * HD;
-    stage_head_dma(base + D, ld, S, Ks, KP, wv, NKT, lane);
-    stage_head_dma(base + 2 * D, ld, S, Vs, KP, wv, NKT, lane);
-    fetch_strips(item);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  for (; item < items; item += gridDim.x) {
-    // per-lane offsets are cheap to recompute; hide the lane id from loop-invariant code motion so that they are not all
-    // kept in registers across the item loop (the kernel runs 13 waves = 128 VGPRs per lane)
-    int lane_i = lane;
-    asm volatile("" : "+v"(lane_i));
-#define lane lane_i
-    const int frame = item / H, head = item % H;
-    const size_t row0 = (size_t)frame * S;
-    const bf16_t* base = qkv + row0 * ld + head * HD;
-    const bf16_t* dobase = dout + row0 * D + head * HD;
-    bf16_t* dbase = dqkv + row0 * ld + head * HD;
-    const float* lse_g = lse + ((size_t)frame * H + head) * S;
-    float* bias_h = bias_s + head * 192;
-
-    // K, V of this item have landed once all but the youngest 15 vector-memory operations of this wave are done: after their
-    // LDS-DMA requests came the 7 strip loads and the 8 dK / dV stores of the previous item (nothing younger at the first item)
-    // (ALL_LIVE: every wave's strip has at least one row inside the sequence, so every guarded load / store is issued; else
-    // a wave may have skipped them and the count would be wrong -> wait for everything)
-    if (ALL_LIVE) asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    long long tb1 = dbg ? __builtin_readcyclecounter() : 0;
-    __syncthreads();                                       // barrier 1
-    if (dbg) tw1 += __builtin_readcyclecounter() - tb1;
-    if (dbias && prev_head >= 0) {                         // dv sums of the previous item, in wave order (the dk sums are zero)
-      for (int c = 128 + tid; c < 192; c += nthr) {
-        float t = bias_s[prev_head * 192 + c];
-#pragma unroll
-        for (int w = 0; w < NKT; ++w) t += stage_s[w * 192 + c];
-        bias_s[prev_head * 192 + c] = t;
-      }
-    }
-    prev_head = head;
-    stage_head_dma(base, ld, S, Qs, KP, wv, NKT, lane);
-    stage_head_dma(dobase, D, S, dOs, KP, wv, NKT, lane);
-    for (int i = tid; i < KP; i += nthr) lse_s[i] = (i < S) ? lse_g[i] * LOG2E : 0.f;
-    bf16x8_t bq[2], bdo[2];                  // B operands: lane (j = q, g) holds X[q][ks*32 + g*8 ..]
-    float dss, lq2;
-    {
-      bq[0] = nq[0]; bq[1] = nq[1]; bdo[0] = ndo[0]; bdo[1] = ndo[1];
-      lq2 = nlq;
-      float dsum = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dsum += (float)bdo[ks][e] * (float)no[ks][e];
-      dss = gsum(dsum) * scale;
-      if (g == 0) dq_s[q] = dss;             // q < NKT*16 <= KP
-    }
-    if (dbg) { long long t = __builtin_readcyclecounter(); tcs += t - tc0; tc0 = t; }
-
-    // ---------------- phase A: this wave's 16-query strip -> dQ ------------------------------------------------------
-    {
-      f32x4_t acc[4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < NP; ++t) {
-        f32x4_t dsv[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int kt = 2 * t + u;
-          dsv[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          if (kt < NKT) {
-            f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            s = mfma16(frag_rm(Ks, kt, 0, lane), bq[0], s);
-            s = mfma16(frag_rm(Ks, kt, 1, lane), bq[1], s);
-            dp = mfma16(frag_rm(Vs, kt, 0, lane), bdo[0], dp);
-            dp = mfma16(frag_rm(Vs, kt, 1, lane), bdo[1], dp);
-            // packed fp32 arithmetic (v_pk_fma / v_pk_mul): two elements per VALU instruction around the four exponentials
-            const f32x2_t s01 = (f32x2_t){s[0], s[1]} * sl - lq2, s23 = (f32x2_t){s[2], s[3]} * sl - lq2;
-            const f32x2_t e01 = (f32x2_t){dp[0], dp[1]} * scale - dss, e23 = (f32x2_t){dp[2], dp[3]} * scale - dss;
-            const f32x2_t p01 = (f32x2_t){__builtin_amdgcn_exp2f(s01[0]), __builtin_amdgcn_exp2f(s01[1])};
-            const f32x2_t p23 = (f32x2_t){__builtin_amdgcn_exp2f(s23[0]), __builtin_amdgcn_exp2f(s23[1])};
-            const f32x2_t d01 = p01 * e01, d23 = p23 * e23;
-            dsv[u] = (f32x4_t){d01[0], d01[1], d23[0], d23[1]};
-          }
-        }
-        bf16x8_t b = pack_pair(dsv[0], dsv[1]);
-        bf16x8_t kf[4];
-        frag4_tr_na<RM, NP>(kf, tr0, t);                                  // K tile
-        lgkm_wait4(kf[0], kf[1], kf[2], kf[3]);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(kf[dt], b, acc[dt]);
-      }
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        if (q < S) {
-          u32x2_t w; w[0] = pack2bf(acc[dt][0], acc[dt][1]); w[1] = pack2bf(acc[dt][2], acc[dt][3]);
-          AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)q * ld + dt * 16 + 4 * g), w);
-        }
-      }
-      if (dbias) {
-        // q part of the qkv-bias gradient: sums over the strip's 16 queries = the 16 lanes of a DPP row (queries past the end of the
-        // sequence have all-zero Q / dO / O strips, hence dS = 0 and dQ = 0 exactly: no mask); one 16-byte store per (dt, g)
-        // the accumulators come out of the matrix pipe (the assembly below is opaque to the hazard recogniser): the wait states are tied to
-        // the registers, so that no MFMA can be scheduled below them (round-3 advisor finding)
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) lsum16x4(acc[dt]);
-        if ((lane & 15) == 0) {
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) *(f32x4_t*)(stage_s + wave * 192 + dt * 16 + 4 * g) = acc[dt];
-        }
-      }
-    }
-    // own K / V strips for phase B, taken before the tiles are handed to the next item's prefetch
-    bf16x8_t bk[2], bv[2];
-    bk[0] = frag_rm(Ks, wave, 0, lane); bk[1] = frag_rm(Ks, wave, 1, lane);
-    bv[0] = frag_rm(Vs, wave, 0, lane); bv[1] = frag_rm(Vs, wave, 1, lane);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // Q, dO landed (this wave's share); strips are in registers
-    long long tb2 = dbg ? __builtin_readcyclecounter() : 0;
-    __syncthreads();                                                // barrier 2
-    if (dbg) tw2 += __builtin_readcyclecounter() - tb2;
-    if (dbias) {                                                    // dq sums of this item, in wave order
-      for (int c = tid; c < 64; c += nthr) {
-        float t = bias_h[c];
-#pragma unroll
-        for (int w = 0; w < NKT; ++w) t += stage_s[w * 192 + c];
-        bias_h[c] = t;
-      }
-    }
-    if (item + gridDim.x < items) {
-      const int nitem = item + gridDim.x;
-      const bf16_t* nbase = qkv + (size_t)(nitem / H) * S * ld + (nitem % H) * HD;
-      stage_head_dma(nbase + D, ld, S, Ks, KP, wv, NKT, lane);
-      stage_head_dma(nbase + 2 * D, ld, S, Vs, KP, wv, NKT, lane);
-    }
-    if (dbg) { long long t = __builtin_readcyclecounter(); tca += t - tc0; tc0 = t; }
-    // ---------------- phase B: this wave's 16-key strip -> dK, dV ----------------------------------------------------
-    {
-      const int key = wave * 16 + (lane & 15);
-      f32x4_t adk[4], adv[4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int t = 0; t < NP; ++t) {
-        f32x4_t pv2[2], ds2[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int qt = 2 * t + u;
-          pv2[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          ds2[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-          if (qt < NKT) {
-            f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            s = mfma16(frag_rm(Qs, qt, 0, lane), bk[0], s);
-            s = mfma16(frag_rm(Qs, qt, 1, lane), bk[1], s);
-            dp = mfma16(frag_rm(dOs, qt, 0, lane), bv[0], dp);
-            dp = mfma16(frag_rm(dOs, qt, 1, lane), bv[1], dp);
-            const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g);      // pre-scaled by log2(e)
-            const f32x4_t d4 = *(const f32x4_t*)(dq_s + qt * 16 + 4 * g);       // pre-scaled by `scale`
-            const f32x2_t s01 = (f32x2_t){s[0], s[1]} * sl - (f32x2_t){l4[0], l4[1]}, s23 = (f32x2_t){s[2], s[3]} * sl - (f32x2_t){l4[2], l4[3]};
-            const f32x2_t e01 = (f32x2_t){dp[0], dp[1]} * scale - (f32x2_t){d4[0], d4[1]}, e23 = (f32x2_t){dp[2], dp[3]} * scale - (f32x2_t){d4[2], d4[3]};
-            const f32x2_t p01 = (f32x2_t){__builtin_amdgcn_exp2f(s01[0]), __builtin_amdgcn_exp2f(s01[1])};
-            const f32x2_t p23 = (f32x2_t){__builtin_amdgcn_exp2f(s23[0]), __builtin_amdgcn_exp2f(s23[1])};
-            const f32x2_t d01 = p01 * e01, d23 = p23 * e23;
-            pv2[u] = (f32x4_t){p01[0], p01[1], p23[0], p23[1]};
-            ds2[u] = (f32x4_t){d01[0], d01[1], d23[0], d23[1]};
-          }
-        }
-        bf16x8_t bp = pack_pair(pv2[0], pv2[1]);
-        bf16x8_t bd = pack_pair(ds2[0], ds2[1]);
-        {
-          bf16x8_t tf[4];
-          constexpr bool HI = 3 * RM + (NP - 1) * 4096 + 2048 >= 65536;   // dO tile: past the 64-KB reach of the immediate at S > 128
-          frag4_tr_na<HI ? 3 * RM - 65536 : 3 * RM, NP>(tf, HI ? tr1 : tr0, t);
-          lgkm_wait4(tf[0], tf[1], tf[2], tf[3]);
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) adv[dt] = mfma16(tf[dt], bp, adv[dt]);
-          frag4_tr_na<0, NP>(tf, tr0, t);                                 // Q tile
-          lgkm_wait4(tf[0], tf[1], tf[2], tf[3]);
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) adk[dt] = mfma16(tf[dt], bd, adk[dt]);
-        }
-      }
-      // next item's strips: requested here, after the register-hungry loop, and hidden behind the stores and barrier 1
-      fetch_strips(item + gridDim.x < items ? item + gridDim.x : item);     // unconditional (re-fetches this item at the end): keeps the strips' live ranges short
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        if (key < S) {
-          u32x2_t w; w[0] = pack2bf(adk[dt][0], adk[dt][1]); w[1] = pack2bf(adk[dt][2], adk[dt][3]);
-          AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + D + dt * 16 + 4 * g), w);
-          u32x2_t x; x[0] = pack2bf(adv[dt][0], adv[dt][1]); x[1] = pack2bf(adv[dt][2], adv[dt][3]);
-          AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g), x);
-        }
-      }
-      // qkv-bias gradient, k and v parts, without the 2 x 64 cross-lane sums per wave the accumulators would need:
-      //   colsum(dK) = sum_q (sum_k dS[q,k]) Q[q] = 0 exactly (every row of dS sums to zero): nothing is added;
-      //   colsum(dV) = sum_k sum_q P[q,k] dO[q] = sum_q dO[q] (every row of P sums to one): wave t < NP takes the 32 queries of pair t
-      //   from the dO tile as one more product with an all-ones B operand (4 MFMAs per item instead of 64 DPP adds per wave).
-      if (dbias) {
-        f32x4_t cs[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) cs[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (wv < NP) {
-          constexpr bool HI = 3 * RM + (NP - 1) * 4096 + 2048 >= 65536;
-          bf16x8_t tf[4];
-          frag4_tr_na<HI ? 3 * RM - 65536 : 3 * RM, NP>(tf, HI ? tr1 : tr0, wv);
-          lgkm_wait4(tf[0], tf[1], tf[2], tf[3]);
-          union { bf16x8_t v; uint32_t w[4]; } ones;
-          ones.w[0] = ones.w[1] = ones.w[2] = ones.w[3] = 0x3F803F80u;
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) cs[dt] = mfma16(tf[dt], ones.v, cs[dt]);
-        }
-        // the sums go from the matrix pipe straight to LDS stores behind a branch: keep the 11 wait states an 8-pass MFMA result
-        // needs before a memory instruction reads it explicit (measured: without them the last block of 16 sums was occasionally garbage
-        // in the 4-wave instantiation, where the sums live in AGPRs)
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(cs[0]), "+v"(cs[1]), "+v"(cs[2]), "+v"(cs[3]));
-        if ((lane & 15) == 0) {
-#pragma unroll
-          for (int dt = 0; dt < 4; ++dt) *(f32x4_t*)(stage_s + wave * 192 + 128 + dt * 16 + 4 * g) = cs[dt];
-        }
-      }
-    }
-    if (dbg) { long long t = __builtin_readcyclecounter(); tcb += t - tc0; tc0 = t; }
-#undef lane
-  }
-  if (dbias) {
-    __syncthreads();
-    if (prev_head >= 0) {
-      for (int c = 128 + tid; c < 192; c += nthr) {
-        float t = bias_s[prev_head * 192 + c];
-#pragma unroll
-        for (int w = 0; w < NKT; ++w) t += stage_s[w * 192 + c];
-        bias_s[prev_head * 192 + c] = t;
-      }
-    }
-    __syncthreads();
-    for (int i = tid; i < H * 192; i += nthr) {
-      const int hh = i / 192, c = i % 192;
-      const float v = bias_s[i];
-      const int o = (c >> 6) * D + hh * HD + (c & 63);
-      if (part) part[(size_t)blockIdx.x * (3 * D) + o] = v;
-      else if (v != 0.f) unsafeAtomicAdd(&dbias[o], v);
-    }
-  }
-  if (dbg && lane == 0) {
-    long long* d = dbg + ((size_t)blockIdx.x * 16 + wave) * 8;
-    d[0] = tcs; d[1] = tca; d[2] = tcb; d[3] = (items - blockIdx.x + gridDim.x - 1) / gridDim.x; d[4] = tw1; d[5] = tw2;
-  }
-}
-
 // ---- single-pass backward (round 4) -------------------------------------------------------------------------------------------
-// The two-phase kernel above evaluates the scores and dP = dO V^T twice (once per query strip for dQ, once per key strip for
+// The two-phase kernel of rounds 2-3 (one pass per query strip for dQ, one per key strip for dK / dV; tools/lab/avt_lab_hooks.diff) evaluated the scores and dP = dO V^T twice (once per query strip for dQ, once per key strip for
 // dK / dV): 2 x 676 of its 2444 MFMAs per item and both softmax recomputations.  Here every (query tile, key tile) pair is evaluated
 // ONCE, by the wave that owns the key strip (wave w = keys 16w .. 16w+15, K / V strips held in registers straight from global):
 //     chunk c = queries 32c .. 32c+31:   S^T, dP^T (4 MFMAs per query tile)  ->  P, dS  ->  dV += P^T dO, dK += dS^T Q (8 MFMAs)
@@ -752,20 +409,9 @@ __device__ __forceinline__ void dma_rows8(__amdgpu_buffer_rsrc_t rsrc, int ld, i
   const int c = (lane & 7) ^ swz8(r);
   uint32_t off = (uint32_t)(((size_t)r * (size_t)ld + (size_t)c * 8) * 2);
   if (r >= S) off = 0xFFFFFFF0u;
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(rm + j * 1024), 16, off, 0, 0, AVT_ATTN_LD_AUX);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, AVT_LDS_PTR(rm + j * 1024), 16, off, 0, 0, 0);
 }
 
-#ifdef AVT_LAB
-// lab only (tools/lab/attn_timeline.py): cycle stamps of ONE item per workgroup at the points where the wave's LDS counter is zero anyway
-// (before / after every barrier, after a dQ product), parked in LDS (32 words per wave behind the kernel's own arrays) and written out at the end
-__device__ unsigned long long g_bwd1_stamps = 0;
-#ifndef AVT_BWD1_STAMP_MASK      // which of the 24 stamps are compiled in (each costs registers: all of them at once spill in the item's tail)
-#define AVT_BWD1_STAMP_MASK 0x3F0000Fu
-#endif
-#define AVT_BWD1_STAMP(i) do { if ((AVT_BWD1_STAMP_MASK >> (i)) & 1u) if (rec) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ((uint32_t*)((char*)(rs_s + KP) + OTB))[wv * 32 + (i)] = (uint32_t)t_; } } while (0)
-#else
-#define AVT_BWD1_STAMP(i) do { } while (0)
-#endif
 // OT ("O tile", late round 5; chosen by the launcher when the LDS has room: H <= 21 at NKT = 13): the head's O rows get a row-major tile of their own
 // (NKT * 16 rows, filled by LDS-DMA chunk by chunk like the Q / dO rows), and D[q] = sum_d dO[q,d] O[q,d] of a wave's strip is formed from the two LDS
 // tiles after the item's first barrier instead of from 16 registers of global strips requested in the previous item's tail: those requests could not be
@@ -828,14 +474,14 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
   // compiler -- possibly in front of the wait)
   bf16x8_t bk[2], bv[2], ndo[2], no[2];
   float nlq = 0.f, nrs = 1.f;
-  constexpr bool LS = AVT_ATTN_LATE_ST && AVT_ATTN_WIDE_ST && OT && NP > 1;      // late dK / dV stores (see AVT_ATTN_LATE_ST)
+  constexpr bool LS = OT && NP > 1;      // late dK / dV stores (file comment)
   u32x4_t hold[4];                           // LS: the previous item's packed dK | dV pieces
   bf16_t* hold_base = nullptr;               // LS: ... and where they go (null: nothing held)
   auto flush_hold = [&]() __attribute__((always_inline)) {
     int lane_h = lane;                       // (opaque: the addresses are formed here, not kept across the item)
     asm volatile("" : "+v"(lane_h));
     const int key_h = k0 + (lane_h & 15), g_h = lane_h >> 4;
-    if (key_h < S && !(AVT_ATTN_ABL & 1)) {
+    if (key_h < S) {
 #pragma unroll
       for (int which = 0; which < 2; ++which) {
         bf16_t* rp = hold_base + (which + 1) * D + (size_t)key_h * ld + (g_h >> 1) * 8;
@@ -870,17 +516,11 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     }
     // per-row scalars of rows past the sequence: the last row's (finite; they only ever meet zeros -- D[q] of such a row is 0 through the zero strips)
     const int kc = in ? key_f : S - 1;
-    if (!(AVT_ATTN_ABL & 64)) {
+    {
       nlq = dword_ld_na(lse + ((size_t)fr * H + hd) * S, (uint32_t)(kc * 4));              // raw: `* log2(e)` where it is stored to LDS
       if (SCALED) nrs = dword_ld_na(row_scale + 2 * r0, (uint32_t)(kc * 8));
     }
   };
-#ifdef AVT_LAB
-  if (lane < 32) ((uint32_t*)((char*)(rs_s + KP) + OTB))[wave * 32 + lane] = 0u;
-#endif
-  if (AVT_ATTN_STAGGER_BWD > 0) {
-    for (int i = (int)((blockIdx.x >> 3) & 31u); i > 0; --i) __builtin_amdgcn_s_sleep(AVT_ATTN_STAGGER_BWD);
-  }
   int item = blockIdx.x;
   if (item < items) {
     const size_t r0 = (size_t)(item / H) * S;
@@ -898,9 +538,6 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     const bool has_next = item + gridDim.x < items;
     const int nitem = has_next ? item + gridDim.x : item;
     const size_t nr0 = (size_t)(nitem / H) * S;
-#ifdef AVT_LAB
-    const bool rec = g_bwd1_stamps != 0 && item == (int)blockIdx.x + 3 * (int)gridDim.x;
-#endif
     __amdgpu_buffer_rsrc_t nrq = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + nr0 * ld + (nitem % H) * HD), 0, 0x7FFFFFF0u, 0x00020000);
     __amdgpu_buffer_rsrc_t nrdo = __builtin_amdgcn_make_buffer_rsrc((void*)(dout + nr0 * D + (nitem % H) * HD), 0, 0x7FFFFFF0u, 0x00020000);
     __amdgpu_buffer_rsrc_t nro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + nr0 * D + (nitem % H) * HD), 0, 0x7FFFFFF0u, 0x00020000);      // (OT)
@@ -910,7 +547,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
     // (wide stores: 4)
 #define AVT_STRIPS_LANDED(N) do { if constexpr (OT) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(nlq), "+v"(nrs) :: "memory"); \
     else asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(ndo[0]), "+v"(ndo[1]), "+v"(no[0]), "+v"(no[1]), "+v"(nlq), "+v"(nrs) :: "memory"); } while (0)
-    if (ALL_LIVE && !(AVT_ATTN_ABL & 1) && !LS) { if (AVT_ATTN_WIDE_ST) AVT_STRIPS_LANDED(4); else AVT_STRIPS_LANDED(8); }
+    if (ALL_LIVE && !LS) AVT_STRIPS_LANDED(4);
     else AVT_STRIPS_LANDED(0);               // (LS: the stores are not issued yet -- the strips' requests are the youngest operations)
 #undef AVT_STRIPS_LANDED
     auto publish_rows = [&](float dsum) __attribute__((always_inline)) {
@@ -928,12 +565,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
         for (int e = 0; e < 8; ++e) dsum += (float)ndo[ks][e] * (float)no[ks][e];
       publish_rows(dsum);
     }
-#ifdef AVT_LAB
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    AVT_BWD1_STAMP(0);
-#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // barrier S: (!OT: scalars visible;) every wave is done with the previous item, its share of this item's rows has landed
-    AVT_BWD1_STAMP(1);
     stage_head_dma(qkv + row0 * ld + D + head * HD, ld, S, Ks, KP, wv, NKT, lane);       // K tile: first read after barrier 0
     if constexpr (OT) {
       // D of the own strip from the dO and O tiles (B-operand layout = the layout of a row fragment)
@@ -947,13 +579,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
         for (int e = 0; e < 8; ++e) dsum += (float)a[e] * (float)b[e];
       }
       publish_rows(dsum);
-#ifdef AVT_LAB
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      AVT_BWD1_STAMP(24);
-#endif
-      // barrier S2 (scalars visible): AVT_ATTN_S2_LATE moves it into chunk 0, behind the first query tile's score products -- the first readers of the scalars
-      if (!(AVT_ATTN_ABL & 4) && !AVT_ATTN_S2_LATE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      AVT_BWD1_STAMP(25);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // barrier S2 (scalars visible)
     }
     if (dbias && prev_head >= 0) {            // the previous item's sums, folded in tile order by the column's owner thread
       float* bh = bias_s + prev_head * 128;
@@ -976,12 +602,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { adk[dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; adv[dt] = adk[dt]; }
 
-    // the item's tail: dK / dV of the wave's strip leave, the next item's per-row scalars (!OT: and dO / O strips) are requested.  AVT_ATTN_TAIL_FIRST (late
-    // round 5, A/B switch, off): executed right after the last chunk's barrier, BEFORE that chunk's dQ products -- the two waves that have one are the last
-    // to reach the next item's first barrier, and the idea was that the product then hides their requests' latency (and runs with the 32 accumulator
-    // registers already free).  Measured no better.  (The counted wait at the loop top stays vmcnt(4) either way: with the switch on the dQ store of those
-    // two waves is younger than the four dK / dV stores, so they also wait for the oldest of the four, issued a whole product earlier.)
-    constexpr bool TF = AVT_ATTN_TAIL_FIRST && OT;      // (without the O tile the early tail spills one or two registers: the old order stays)
+    // the item's tail: dK / dV of the wave's strip leave, the next item's per-row scalars (!OT: and dO / O strips) are requested.  (Executing it right after
+    // the last chunk's barrier, before that chunk's dQ products, measured no better: file comment.)
     auto item_tail = [&]() __attribute__((always_inline)) {
     // (scaled: this item's scale of the wave's own key rows, back from LDS -- kept in a register across the item it cost 14 spilled registers)
       int lane_t = lane;                          // (opaque: the addresses below are formed here, not kept -- spilled -- across the item)
@@ -993,7 +615,6 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       // Unconditional (re-fetches this item at the end): keeps the counted wait at the loop top exact.  Every earlier place was tried and spills: the top
       // of the last chunk 20-25 registers, behind the last barrier 9-12 (profiles/r05n_attention_boundary.txt)
       fetch_rows(nitem);
-#if AVT_ATTN_WIDE_ST
       // 16-byte stores (see the forward kernel): lane (i, g) ends up with 8 consecutive columns of block dp + (g & 1); one tensor after the other
       // (eight registers of packed output at a time: the kernel sits at its 128-register limit)
       static_for<0, 2>([&](auto w_) __attribute__((always_inline)) {
@@ -1011,7 +632,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
         if constexpr (LS) { hold[2 * which] = sp[0]; hold[2 * which + 1] = sp[1]; }
         else {
           bf16_t* tb = dbase + (which + 1) * D;
-          if (key_t < S && !(AVT_ATTN_ABL & 1)) {
+          if (key_t < S) {
             bf16_t* rp = tb + (size_t)key_t * ld + (g_t >> 1) * 8;
             *(u32x4_t*)(rp + (g_t & 1) * 16) = sp[0];
             *(u32x4_t*)(rp + (2 + (g_t & 1)) * 16) = sp[1];
@@ -1019,21 +640,10 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
         }
       });
       if constexpr (LS) hold_base = dbase;
-#else
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        if (key < S) {
-          u32x2_t w; w[0] = pack2bf(adk[dt][0] * crs, adk[dt][1] * crs); w[1] = pack2bf(adk[dt][2] * crs, adk[dt][3] * crs);
-          AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + D + dt * 16 + 4 * g), w);
-          u32x2_t x; x[0] = pack2bf(adv[dt][0] * crs, adv[dt][1] * crs); x[1] = pack2bf(adv[dt][2] * crs, adv[dt][3] * crs);
-          AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)key * ld + 2 * D + dt * 16 + 4 * g), x);
-        }
-      }
-#endif
     };
     auto dma_next_rows = [&](int c) __attribute__((always_inline)) {
       // the NEXT item's Q / dO (OT: / O) rows of this chunk (4 + 4 (+ 4) LDS-DMA instructions of 8 rows), spread over the waves
-      if (has_next && !((AVT_ATTN_ABL & 32) && c == NP - 1)) {
+      if (has_next) {
         int lane_r = lane;                      // (opaque: the rows' per-lane offsets are formed here, not kept -- spilled -- across the item)
         asm volatile("" : "+v"(lane_r));
         for (int j = wv; j < (OT ? 12 : 8); j += NKT) {
@@ -1061,7 +671,6 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
           s = mfma16(frag_rm(Qs, qt, 1, lane), bk[1], s);
           dp = mfma16(frag_rm(dOs, qt, 0, lane), bv[0], dp);
           dp = mfma16(frag_rm(dOs, qt, 1, lane), bv[1], dp);
-          if constexpr (OT && AVT_ATTN_S2_LATE && c == 0) { if (u == 0 && !(AVT_ATTN_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // barrier S2
           int g_s = g;                           // (opaque: the scalars' LDS address is formed per chunk, not kept -- spilled -- across the item)
           asm volatile("" : "+v"(g_s));
           const f32x4_t l4 = *(const f32x4_t*)(lse_s + qt * 16 + 4 * g_s);    // pre-scaled by log2(e)
@@ -1076,7 +685,7 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
         }
       }
       // (the last chunk's score products were the last readers of this item's K / V strips)
-      if constexpr (c == NP - 1 && !(AVT_ATTN_ABL & 16)) fetch_kv(nitem);
+      if constexpr (c == NP - 1) fetch_kv(nitem);
       const bf16x8_t bp = pack_pair(pv2[0], pv2[1]);
       union { bf16x8_t v; uint32_t w[4]; } bd;
       bd.v = pack_pair(ds2[0], ds2[1]);
@@ -1109,22 +718,18 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
       lgkm_wait4(tfq[0], tfq[1], tfq[2], tfq[3]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) adk[dt] = mfma16(tfq[dt], bd.v, adk[dt]);
-      if (c == 0 && !(AVT_ATTN_ABL & 2)) {                                   // this wave's share of the K tile has landed
+      if (c == 0) {                                   // this wave's share of the K tile has landed
         if (LS && ALL_LIVE && held) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");           // (all but the four dK / dV stores just issued)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-#ifdef AVT_LAB
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      AVT_BWD1_STAMP(2 + 3 * c);
-#endif
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // barrier c: dS chunk complete; the chunk's Q / dO rows are free
-      AVT_BWD1_STAMP(3 + 3 * c);
-      if constexpr (TF && c == NP - 1) { dma_next_rows(c); item_tail(); }
+      (void)item_tail;      // (keeps `item_tail` captured by this lambda as it was while the tail could also run here: without the capture hipcc 7.2 lays the
+                            //  closure out differently and the kernel comes out with a spilled vector register -- compared on the ISA, round 6)
       // ---- dQ of the chunk's two query tiles: four (tile, half) products, one wave each ----
       static_for<0, 4>([&](auto hh_) __attribute__((always_inline)) {
         constexpr int h = 4 * c + decltype(hh_)::value;
         if constexpr (h < 2 * NKT) {
-          if (wv == h % NKT && !(AVT_ATTN_ABL & 8)) {
+          if (wv == h % NKT) {
             constexpr int qt = h >> 1, half = h & 1, u = qt & 1;
             f32x4_t acc[2];
             acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0];
@@ -1153,7 +758,6 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
             int lane_d = lane;                       // (opaque: the store addresses are recomputed here instead of being kept -- spilled -- across the item)
             asm volatile("" : "+v"(lane_d));
             const int q = qt * 16 + (lane_d & 15);
-#if AVT_ATTN_WIDE_ST
             {
               u32x2_t a, b;
               float rq = 1.f;
@@ -1167,16 +771,6 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
               const int gd = lane_d >> 4;
               if (q < S) *(u32x4_t*)(dbase + (size_t)q * ld + (2 * half + (gd & 1)) * 16 + (gd >> 1) * 8) = (u32x4_t){r0[0], r1[0], r0[1], r1[1]};
             }
-#else
-            if (q < S) {
-#pragma unroll
-              for (int j = 0; j < 2; ++j) {
-                const float rq = SCALED ? rs_s[qt * 16 + (lane_d & 15)] : 1.f;
-                u32x2_t w; w[0] = pack2bf(acc[j][0] * rq, acc[j][1] * rq); w[1] = pack2bf(acc[j][2] * rq, acc[j][3] * rq);
-                AVT_ATTN_STG((u32x2_t*)(dbase + (size_t)q * ld + (2 * half + j) * 16 + 4 * (lane_d >> 4)), w);
-              }
-            }
-#endif
             if (dbias) {
               // q part of the qkv-bias gradient: sums over the tile's 16 queries = the 16 lanes of a DPP row (rows past the sequence are
               // exactly zero).  The accumulators come straight out of the matrix pipe into hand-written DPP adds: the wait states are
@@ -1191,29 +785,15 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
           }
         }
       });
-#ifdef AVT_LAB
-      if (rec) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      AVT_BWD1_STAMP(4 + 3 * c);
-#endif
-      if constexpr (!(TF && c == NP - 1)) dma_next_rows(c);
+      dma_next_rows(c);
     });
 
-    if constexpr (!TF) item_tail();
-#ifdef AVT_LAB
-    if (rec) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    AVT_BWD1_STAMP(3 * NP + 2);
-#endif
+    item_tail();
   }
   // the last item re-requested its own strips (that keeps the counted waits exact): retire those requests before anything below reuses their registers --
   // the compiler considers them dead here, and a load landing in a register that meanwhile holds an address is a wild store (tools/isa_async_check.py found it)
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(bk[0]), "+v"(bk[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(ndo[0]), "+v"(ndo[1]), "+v"(no[0]), "+v"(no[1]), "+v"(nlq), "+v"(nrs) :: "memory");
   if constexpr (LS) { if (hold_base != nullptr) flush_hold(); }
-#ifdef AVT_LAB
-  if (g_bwd1_stamps != 0 && lane == 0) {
-    uint32_t* d = (uint32_t*)g_bwd1_stamps + ((size_t)blockIdx.x * 16 + wave) * 32;
-    for (int i = 0; i < 32; ++i) d[i] = ((uint32_t*)((char*)(rs_s + KP) + OTB))[wave * 32 + i];
-  }
-#endif
   if (dbias) {
     __syncthreads();
     if (prev_head >= 0) {
@@ -1244,13 +824,8 @@ __global__ __launch_bounds__(64 * NKT) void vit_attn_bwd1_kernel(const bf16_t* _
 int pick_nkt(int S) { int n = (S + 15) / 16; if (n <= 1) return 1; if (n <= 2) return 2; if (n <= 4) return 4; if (n <= 8) return 8; return 13; }
 
 template <int NKT> size_t fwd_smem() { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128; }     // K, V x 2 buffers
-template <int NKT> size_t bwd_smem(int H) { constexpr int NP = (NKT + 1) / 2; return (size_t)4 * NP * 32 * 128 + (size_t)(2 * NP * 32 + H * 192 + NKT * 192) * 4; }
 
-#ifdef AVT_LAB
-constexpr size_t BWD1_LAB_SMEM = 13 * 32 * 4;      // the stamps of AVT_BWD1_STAMP (32 words per wave; with the O tile 163 584 of the 163 840 bytes)
-#else
 constexpr size_t BWD1_LAB_SMEM = 0;
-#endif
 template <int NKT> size_t bwd1_smem(int H) { constexpr int NP = (NKT + 1) / 2, KP = NP * 32; return (size_t)3 * KP * 128 + (size_t)2 * KP * 72 + (size_t)(3 * KP + H * 128 + NKT * 64 + NP * 64) * 4 + BWD1_LAB_SMEM; }
 
 template <int NKT>
@@ -1270,9 +845,7 @@ int launch_fwd(const bf16_t* qkv, bf16_t* out, float* lse, int frames, int S, in
 template <int NKT>
 int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, float* dbias,
                float* part, size_t part_bytes, int frames, int S, int H, float scale, hipStream_t s, const float* row_scale = nullptr) {
-#ifndef AVT_ATTN_BWD_TWO_PHASE
   {
-    // single-pass kernel (default since round 4); the two-phase kernel stays selectable for A/B (-DAVT_ATTN_BWD_TWO_PHASE)
     size_t sm1 = bwd1_smem<NKT>(H);
     if (sm1 > 160 * 1024) { avt_set_error("avt_vit_attn_bwd: H = %d needs more LDS than a CU has", H); return -1; }
     // the O tile (kernel comment) where it fits: H <= 21 at NKT = 13
@@ -1280,14 +853,6 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
     if (ot) sm1 += (size_t)NKT * 16 * 128;
     const bool live = S > (NKT - 1) * 16;
     const int items1 = frames * H;
-#ifdef AVT_LAB
-    {
-      const char* e = getenv("AVT_BWD1_STAMPS_PTR");             // read on every launch: the tool sets and clears it
-      unsigned long long v = e ? strtoull(e, nullptr, 0) : 0ull;
-      static unsigned long long last = 0;
-      if (v != last) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bwd1_stamps), &v, sizeof(v)); last = v; }
-    }
-#endif
     const int pc = (int)((160 * 1024) / sm1) < 1 ? 1 : (int)((160 * 1024) / sm1);
     int grid1 = 256 * (pc > 8 ? 8 : pc);
     if (grid1 > items1) grid1 = items1;
@@ -1303,30 +868,6 @@ int launch_bwd(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const f
     if (part) { float* outs[1] = {dbias}; return avt_reduce_partials(part, grid1, 3L * H * HD, outs, 1, s); }
     return 0;
   }
-#endif
-  if (row_scale) { avt_set_error("avt_vit_attn_bwd_scaled: the two-phase kernel has no row scaling"); return -1; }
-  size_t sm = bwd_smem<NKT>(H);
-  if (sm > 160 * 1024) { avt_set_error("avt_vit_attn_bwd: H = %d needs more LDS than a CU has", H); return -1; }
-  (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  (void)hipFuncSetAttribute((const void*)vit_attn_bwd_kernel<NKT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  const bool all_live = S > (NKT - 1) * 16;
-#ifdef AVT_LAB            // per-phase cycle stamps for tools/: the product library takes no pointer from the environment
-  static const char* e = getenv("AVT_ATTN_DBG_PTR");
-  long long* dbg = e ? (long long*)strtoull(e, nullptr, 0) : nullptr;
-#else
-  long long* dbg = nullptr;
-#endif
-  const int items = frames * H;
-  // persistent: one workgroup per CU when the tiles of a head need most of the LDS, more for short sequences
-  const int per_cu = (int)((160 * 1024) / sm) < 1 ? 1 : (int)((160 * 1024) / sm);
-  int grid = 256 * (per_cu > 8 ? 8 : per_cu);
-  if (grid > items) grid = items;
-  if (!dbias) part = nullptr;
-  if (part && part_bytes < (size_t)grid * 3 * H * HD * 4) { avt_set_error("avt_vit_attn_bwd: partials workspace too small"); return -1; }
-  if (all_live) hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT, true>), dim3(grid), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, part, S, H, items, scale, dbg);
-  else hipLaunchKernelGGL((vit_attn_bwd_kernel<NKT, false>), dim3(grid), dim3(64 * NKT), sm, s, qkv, out, dout, lse, dqkv, dbias, part, S, H, items, scale, dbg);
-  if (part) { float* outs[1] = {dbias}; return avt_reduce_partials(part, grid, 3L * H * HD, outs, 1, s); }
-  return 0;
 }
 
 }  // namespace

@@ -26,8 +26,7 @@ PERSIST_KMAX = 4096      # mirrors PK_KMAX in csrc/gemm_persist.hip
 
 # Every kernel-template prefix the router below can return for an output tile of 128 rows or more: what bench.py's GEMM-family /
 # dominant-kernel numbers aggregate over (a CPU test checks that each name gemm_variant produces for such a tile is caught).
-LARGE_TILE_KERNELS = ('gemm_kernel<128', 'gemm_kernel<256', 'gemm_8pp_kernel', 'gemm_8p_kernel', 'gemm_w4_kernel', 'gemm_4w_kernel',
-                      'gemm_deepa_kernel', 'gemm_pp_kernel')
+LARGE_TILE_KERNELS = ('gemm_kernel<128', 'gemm_kernel<256', 'gemm_8pp_kernel', 'gemm_8p_kernel', 'gemm_w4_kernel')
 
 
 def persist_epilogue_kind(out_mode, act, has_bias, has_res, has_aux, has_c2, has_colsum, drop_p=0.0, res_period=0):
@@ -74,17 +73,11 @@ def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False)
                 bm = 809          # the persistent form (csrc/gemm_persist.hip: avt_gemm_persist)
         if bm == 64 and epi == 0 and a_kmajor and (b_kmajor or ((M + 63) // 64) * ((N + 63) // 64) <= 256):
             bm = 643
-    shape = {2564: '4w', 64: '64,64,2,2,64,2,0', 128: '128,128,2,2,64,2,0', 256: '256,256,2,4,64,2,1', 512: 'pp', 258: 'deepa', 2568: '256,256,2,4,64,2,1,l8', 808: '8p', 809: '8pp', 643: '64,64,2,2,64,3,0'}[bm]
-    if bm == 2564:
-        return f'gemm_4w_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))}>'
+    shape = {64: '64,64,2,2,64,2,0', 128: '128,128,2,2,64,2,0', 256: '256,256,2,4,64,2,1', 2568: '256,256,2,4,64,2,1,l8', 808: '8p', 809: '8pp', 643: '64,64,2,2,64,3,0'}[bm]
     if bm == 808:
         return f'gemm_8p_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
     if bm == 809:
         return 'gemm_8pp_kernel' if epk is None or epk < 0 else f'gemm_8pp_kernel<{epk}>'
-    if bm == 258:
-        return f'gemm_deepa_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
-    if bm == 512:
-        return f'gemm_pp_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
     return f'gemm_kernel<{shape},{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
 
 

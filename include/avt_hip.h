@@ -51,8 +51,7 @@ int avt_abi_version(void);
  * tile: 0 = choose; 64 | 128 | 256 | 808 (256x256 tile, 8-phase schedule, one tile per workgroup) | 809 (the same schedule as a persistent
  * kernel: one workgroup per CU draws tiles from a queue and fetches the next tile's first K tile under its epilogue; bit-identical to 808;
  * k-major operands, N % 256 == 0, K % 128 == 0, >= 512 tiles, bf16 output, bias | GELU | bias + residual | saved-derivative epilogue --
- * an error otherwise; the automatic choice takes it for K <= 4096) | 2564 (256x128 tile, 4 waves, two workgroups per CU: k-major
- * operands, K % 32 == 0; bit-identical to 808, measured slower -- kept for experiments) force a kernel.  The automatic choice walks the
+ * an error otherwise; the automatic choice takes it for K <= 4096) force a kernel.  The automatic choice walks the
  * tiles of an activation GEMM whose B operand exceeds an XCD's 4-MB L2 (N*K*2 > 4 MB, e.g. the fc1 weight) in column strips, so that
  * the strip of B stays L2-resident (results do not depend on the tile order).  Small outputs (fewer than 200 tiles of 256 x 256; the reference's own
  * 3 clips per GPU, expts/01_ek100_avt.txt:5): all-k-major contractions take the 8-phase kernel from 96 such tiles and 64 x 64 tiles with a 3-deep ring
