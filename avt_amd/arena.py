@@ -63,6 +63,8 @@ class ParamArena:
         self._folded = {}                # weight name -> FoldedLinear (LayerNorm folded into the Linear behind it, see folded_of)
         self._fold_jobs = None           # device job table of the G -> G^T transposes
         self._fold_scratch = {}          # (N, K) -> zeroed fp32 scratch of the raw weight gradient; N -> zeroed bias-gradient scratch
+        self._fold_dirty = False         # the masters changed since the folded forms were made (re-formed at their next use)
+        self.fold_scratch_busy = False   # a backward is between filling and consuming a shared scratch (fold_scratch_guard)
         self.refresh_shadow(force=True)
 
     # ---- views -------------------------------------------------------------------------------------------------
@@ -151,16 +153,31 @@ class ParamArena:
         return f
 
     def fold(self, weight, gamma, beta, bias):
+        if self._fold_dirty:
+            self._refresh_folded_now()
         return self.folded_of(self.name_of[id(weight)], self.name_of[id(gamma)], self.name_of[id(beta)], self.name_of[id(bias)])
 
     def refresh_folded(self):
-        if not self._folded:
-            return
+        """The masters changed: the folded forms are stale.  They are re-formed at their next USE (``fold``), not here -- a step below
+        ``HipViT.fold_min_rows`` token rows does not use them, and re-folding 22 weights per optimizer step for nothing cost 0.2 ms (round-5 advisor)."""
+        self._fold_dirty = bool(self._folded)
+
+    def _refresh_folded_now(self):
+        self._fold_dirty = False
         for f in self._folded.values():
             f.refresh()
         if self._fold_jobs is None:
             self._fold_jobs = ops.transpose_jobs([(f.G, f.Gt) for f in self._folded.values()])
         ops.transpose_batch(self._fold_jobs)
+
+    def fold_scratch_guard(self):
+        """The folded layers of one shape share their backward scratch (T, dbt), which every use leaves zeroed (ln_fold_wgrad).  A backward that died
+        between filling and consuming it (out of memory, an interrupt) leaves it dirty: the next backward would add that into another layer's gradient.
+        ``fold_scratch_busy`` is set while a scratch is in use; a backward that finds it set zeroes every scratch first (round-5 advisor)."""
+        if self.fold_scratch_busy:
+            for t in self._fold_scratch.values():
+                t.zero_()
+            self.fold_scratch_busy = False
 
     def master_of(self, name):
         o, shp = self.offsets[name], self.shapes[name]

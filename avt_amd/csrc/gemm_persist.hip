@@ -32,6 +32,8 @@
 // (Built with -mllvm -amdgpu-atomic-optimizer-strategy=None: the optimizer would turn the one-lane atomic into a wave reduction
 // followed by an immediate s_waitcnt vmcnt(0).)
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 #include "gemm_tile.hpp"
 
 namespace {
@@ -787,31 +789,30 @@ __global__ __launch_bounds__(512) void gemm_8pp_kernel(GemmParams p, PkWalk wk_a
 // ticket counters: one block (8 counters + the leave count, a 128-byte line each) per (device, stream), zeroed once; every launch leaves
 // its block zeroed.  Launches on one stream are ordered, so they can share a block whatever the depth of the launch queue; launches on
 // different streams (the forward thread and the autograd thread call in here concurrently) never share one.  The table is guarded by a
-// mutex; a 65th stream on a device gets no block and its GEMMs take the one-tile-per-workgroup kernel.  (The first call on a device
-// allocates: warm the library up before capturing a stream into a graph.)
+// mutex and grows in chunks of 64 blocks (round-5 advisor: it used to end at 64 streams per device, and a 65th stream's fragment-major
+// GEMMs -- which only this kernel can run -- failed); a stream gets no block only when the allocation itself fails, and its GEMMs then take
+// the one-tile-per-workgroup kernel.  (A new chunk allocates and clears device memory: warm the library up before capturing a stream into a graph.)
 constexpr int PK_SCHED_INTS = 9 * 32, PK_SCHED_BLOCKS = 64;
 int* sched_block(hipStream_t s) {
+  struct Dev { std::vector<int*> chunks; std::unordered_map<hipStream_t, int*> of; size_t used = 0; };
   static std::mutex mu;
-  static int* base[16] = {};
-  static hipStream_t owner[16][PK_SCHED_BLOCKS] = {};
-  static int nown[16] = {};
+  static Dev devs[16];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
-  if (!base[dev]) {
+  Dev& d = devs[dev];
+  auto it = d.of.find(s);
+  if (it != d.of.end()) return it->second;
+  if (d.used == d.chunks.size() * PK_SCHED_BLOCKS) {
     int* ptr = nullptr;
     if (hipMalloc(&ptr, (size_t)PK_SCHED_BLOCKS * PK_SCHED_INTS * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (hipMemset(ptr, 0, (size_t)PK_SCHED_BLOCKS * PK_SCHED_INTS * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ptr); return nullptr; }
-    base[dev] = ptr;
+    d.chunks.push_back(ptr);
   }
-  int idx = -1;
-  for (int i = 0; i < nown[dev]; ++i) if (owner[dev][i] == s) { idx = i; break; }
-  if (idx < 0) {
-    if (nown[dev] >= PK_SCHED_BLOCKS) return nullptr;
-    idx = nown[dev]++;
-    owner[dev][idx] = s;
-  }
-  return base[dev] + (size_t)idx * PK_SCHED_INTS;
+  int* blk = d.chunks.back() + (d.used % PK_SCHED_BLOCKS) * PK_SCHED_INTS;
+  ++d.used;
+  d.of.emplace(s, blk);
+  return blk;
 }
 
 template <int EPK>

@@ -230,6 +230,8 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
     x, meanf, rstdf = saved['final']
     last = m.blocks[-1]
     first_full = m.depth - 1
+    if saved['fold']:
+        arena.fold_scratch_guard()
     if saved['cls_last']:
         dx2 = ops.layernorm_bwd(dfeat, x, meanf, rstdf, m.norm.weight, gr(m.norm.weight), gr(m.norm.bias),
                                 colsum=gr(last.mlp.fc2.bias))
@@ -259,6 +261,7 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
             f1 = arena.fold(blk.attn.qkv.weight, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.bias)
             f2 = arena.fold(blk.mlp.fc1.weight, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.bias)
             ops.linear_wgrad(dx, act, gr(blk.mlp.fc2.weight))
+            arena.fold_scratch_busy = True                                   # (cleared when the block's last shared scratch has been consumed)
             dh = ops.linear_fwd(dx, sh_t(blk.mlp.fc2.weight), act=ops.ACT_MUL_AUX, aux=pre, colsum=f2.dbt, ln_stat=sb2)     # = rstd2 o dh; dbt = colsum(dh)
             del act, pre
             ops.linear_wgrad(dh, x1, f2.T)
@@ -273,6 +276,7 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
             del datt, att, qkv
             ops.linear_wgrad(dqkv, x, f1.T)
             f1.backward_weights()
+            arena.fold_scratch_busy = False
             dln1 = ops.linear_fwd(dqkv, f1.Gt)
             del dqkv
             dx = ops.layernorm_bwd_folded(dln1, x, sf1, dres=dx1, colsum=prev_bias)

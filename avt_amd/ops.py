@@ -151,7 +151,7 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
          ln_stat=None, ln_c=None, stat_part=None):
     """C[M,N] = epilogue(sum_k opA[m,k] opB[n,k]); see avt_gemm_bf16 in include/avt_hip.h.
     ln_stat / ln_c / stat_part: the LayerNorm-fold modes of avt_gemm_ln_bf16 (fold: ln_stat [M,2] + ln_c [N]; scale: ln_stat alone with
-    act=ACT_MUL_AUX; stat_part [N/32, M, 2]: row statistics of the output)."""
+    act=ACT_MUL_AUX; stat_part [ceil(N/64), M, 2, 2]: row statistics of the output)."""
     _chk(A, BF16, 'A'); _chk(B, BF16, 'B')
     if tile == 0 and FORCE_TILE:
         tile = FORCE_TILE

@@ -58,16 +58,21 @@ def flops_skipped_per_clip(D, T, S=197):
     return 3 * T * (full - done)
 
 
-def algorithmic_bytes_per_step(D, L, T, B, Dh=2048, Lh=6, S=197):
+def algorithmic_bytes_per_step(D, L, T, B, Dh=2048, Lh=6, S=197, folded=None):
     """HBM bytes per step per GPU of the implemented dataflow if every tensor crossed HBM exactly as often as the kernel
     sequence consumes / produces it (DESIGN.md section 4 lists the per-kernel terms).  Unit u = one [tokens, D] bf16 tensor.
     A full ViT block moves 26 u forward (qkv 4, attention 4, proj 3, fc1 9, fc2 6 -- since round 5 the two LayerNorms are folded into qkv /
     fc1 and write nothing: 30 u before) and 52 u backward (fc2 w/dgrad 14, fc1 w/dgrad 10, LN2 4, proj w/dgrad 4, attention 8, qkv w/dgrad 8,
     LN1 4); the CLS-only last block 20 u;
     patch embedding: fp32 frames once + 6 u; parameters: 38 B each (bf16 shadow read by forward and dgrad, fp32 gradient
-    read-modify-write, 26 B in the fused SGD); the temporal head's activations with u_h = [B*T, Dh] bf16."""
+    read-modify-write, 26 B in the fused SGD); the temporal head's activations with u_h = [B*T, Dh] bf16.
+    ``folded``: is the LayerNorm fold taken at this size (HipViT.fold_min_rows)?  None = ask the product's rule.  Without it a full block moves 30 u
+    forward (a normalised copy written and read per LayerNorm): 82 u in all (round-5 advisor: the 3-clip `also` run was priced with the folded 78 u)."""
     u = B * T * S * D * 2
-    vit = ((L - 1) * 78 + 20 + 6) * u + B * T * 3 * 224 * 224 * 4
+    if folded is None:
+        from avt_amd.models.vit import HipViT, use_fold
+        folded = use_fold(HipViT, B * T * S, D, L - 1)
+    vit = ((L - 1) * (78 if folded else 82) + 20 + 6) * u + B * T * 3 * 224 * 224 * 4
     n_vit = 768 * D + D + S * D + D + L * (12 * D * D + 13 * D) + 2 * D
     n_head = 2 * D * Dh + 1024 * Dh + Lh * (12 * Dh * Dh + 13 * Dh) + 2 * Dh
     n_cls = (D + 1) * NUM_CLASSES
@@ -364,6 +369,10 @@ def main(argv=None):
                 'executed_frac': rl['executed_frac'],
                 'traffic': None if pmc is None else pmc['hbm_bytes_per_step'],
                 'traffic_source': None if pmc is None else pmc.get('source'),
+                'traffic_note': 'traffic is NOT measured in this run: it is the fabric read + write bytes per step of a committed rocprofv3 --pmc pass (FETCH_SIZE / WRITE_SIZE, '
+                                'separate passes, gfx950 corrections) over the same workload -- traffic_source names the file; algorithmic_bytes_per_step is the per-kernel operand '
+                                'model of bench.py::algorithmic_bytes_per_step (every tensor crossing HBM as often as the kernel sequence consumes / produces it), not SURVEY 8d\'s '
+                                'secondary list of parameter / optimizer / input bytes (~13.5 GB, which it contains)',
                 'algorithmic_bytes_per_step': algorithmic_bytes_per_step(D, L, args.frames, args.batch),
                 'hbm_time_floor_ms_at_6p3TBs': round(algorithmic_bytes_per_step(D, L, args.frames, args.batch) / 6.3e12 * 1e3, 2),
                 'peak_note': 'peak = dense bf16 MFMA at the nominal clock (MI355X_MICROARCH.md); a bare MFMA loop on pseudo-random bf16 '

@@ -384,6 +384,28 @@ def test_persistent_gemm_complete_under_a_cu_mask(mask):
     assert r.returncode == 0 and 'CU_MASK_OK' in r.stdout, (mask, r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_persistent_gemm_on_more_than_64_streams(ops):
+    """Round-5 advisor finding: the persistent GEMM keeps one ticket block per (device, stream), the table ended at 64 streams, and the 65th stream's
+    launches fell back (or, with a fragment-major operand that only this kernel can run, failed).  The table grows now: 70 streams, the same GEMM with
+    the fragment-major GELU' output on each, every result equal to the first stream's, bit for bit."""
+    M, N, K = 512 * 64, 1024, 256                      # 128 x 4 = 512 tiles of 256 x 256: the persistent kernel's range
+    assert ops.gemm_frag_ok(M, N, K)
+    a, b, bias = rnd((M, K), 0.5, 51), rnd((N, K), 0.05, 52), rnd((N,), 1.0, 53, torch.float32)
+    ref_c = ref_d = None
+    torch.cuda.synchronize()
+    for i in range(70):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            d = ops.FragTensor(M, N, a.device)
+            c = ops.gemm(a, b, M, N, K, bias=bias, act=ops.ACT_GELU_ERF, c2=d, tile=809)
+        st.synchronize()
+        dm = ops.gemm_frag_unpack(d)
+        if ref_c is None:
+            ref_c, ref_d = c.clone(), dm.clone()
+        else:
+            assert torch.equal(c, ref_c) and torch.equal(dm, ref_d), i
+
+
 def test_column_sum_reductions_are_bit_reproducible(ops):
     """Every many-workgroups -> one fp32 vector reduction (GEMM colsum at each tile shape incl. ragged edges, LayerNorm backward,
     ViT attention dbias, colsum, patch-embed reduce) gives the same BITS on repeated calls with the partials workspace, and agrees
@@ -1073,15 +1095,15 @@ def test_linear_cross_entropy_fused_operator_vs_torch():
     weight, the bias and the input against torch.nn.functional.linear + cross_entropy in fp32 -- at the classifier's real shape
     ((B*T + B) rows x 768 -> 3806 classes, padded to 3840) and a ragged toy shape."""
     import torch.nn.functional as F
-    from avt_amd.loss_fn.fused_linear_xent import LinearCrossEntropy
+    from avt_amd.models.classifiers import HipLinear
     for (R, K, C) in [(2816, 768, 3806), (37, 64, 17)]:
         g = torch.Generator().manual_seed(R)
         x = (torch.randn((R, K), generator=g) * 0.5).cuda().requires_grad_()
         target = torch.randint(-1, C, (R,), generator=g).cuda()
-        m = LinearCrossEntropy(K, C).cuda()
+        m = HipLinear(K, C).cuda()          # the product's classifier; forward_with_loss = the fused node BaseModel runs in training
         with torch.no_grad():
             m.weight.normal_(0, 0.05, generator=torch.Generator(device='cuda').manual_seed(1)); m.bias.uniform_(-0.1, 0.1)
-        loss, rank, logits = m(x, target)
+        logits, loss, rank = m.forward_with_loss(x, target, -1)
         w = torch.rand(R, generator=g).cuda()
         (loss * w).sum().backward()
         xr = x.detach().clone().requires_grad_(); wr = m.weight.detach().clone().requires_grad_(); br = m.bias.detach().clone().requires_grad_()
@@ -1101,7 +1123,7 @@ def test_linear_cross_entropy_fused_operator_vs_torch():
         # they used to come back with the node as grad_fn and a silently ignored gradient)
         assert logits.requires_grad and not rank.requires_grad
         m.zero_grad(); x.grad = None
-        loss, rank, logits = m(x, target)
+        logits, loss, rank = m.forward_with_loss(x, target, -1)
         ((loss * w).sum() + 0.5 * (logits ** 2).mean() * R).backward()
         for t in (xr, wr, br):
             t.grad = None
@@ -1110,7 +1132,7 @@ def test_linear_cross_entropy_fused_operator_vs_torch():
         assert relerr(m.weight.grad, wr.grad) < 3e-2 and relerr(m.bias.grad, br.grad) < 3e-2 and relerr(x.grad, xr.grad) < 3e-2
         # only the logits used: the loss output receives no gradient at all
         m.zero_grad(); x.grad = None
-        loss, rank, logits = m(x, target)
+        logits, loss, rank = m.forward_with_loss(x, target, -1)
         logits.sum().backward()
         for t in (xr, wr, br):
             t.grad = None
