@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int ntile = p.tiles_m * p.tiles_n;
-  const int lb = xcd_remap(blockIdx.x, ntile * p.splitk);
+  const int lb = accum_slab(p);                               // split * tiles + row-major tile (walk order: gemm_tile.hpp)
   const int split = lb / ntile;
   const int t_ = lb - split * ntile;
   const int tm0 = (t_ / p.tiles_n) * BM;
@@ -892,6 +892,7 @@ int dispatch_w4(GemmParams& p, int a_kmajor, int b_kmajor, int splitk, hipStream
   if (splitk <= 0) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk64, 1, 8);      // same choice as the 8-phase kernel: the workspace query mirrors it
   if (splitk > nk64) splitk = nk64;
   p.splitk = splitk;
+  p.tile_cm = p.tiles_n > p.tiles_m;
   if (splitk > 1 && (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4 > p.ws_bytes) { avt_set_error("avt_gemm_accum_bf16: workspace too small (%zu bytes needed)", (size_t)p.tiles_m * p.tiles_n * splitk * 65536 * 4); return -2; }
   constexpr int smem = 5 * 2 * 32 * 512;               // 160 KB
   static bool attr_set = false;

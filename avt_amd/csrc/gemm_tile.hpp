@@ -33,6 +33,9 @@ struct GemmParams {
   const float* ln_stat; const float* ln_c; float* stat_part;
   // fragment-major second output / second operand (ldc2 == 0 / ldaux == 0 in the C ABI; gemm_persist.hip: the persistent kernel only)
   int c2_frag, aux_frag;
+  // weight-gradient slabs (EPI 2): walk a split's tiles column-major (the output has more column tiles than row tiles), so that the contiguous
+  // range of the walk an XCD owns covers few operand panels either way (accum_slab; profiles/r06h_wgrad_xcd.txt)
+  int tile_cm;
 };
 // gemm_persist.hip: the persistent form of the 8-phase kernel (one workgroup per CU walks a queue of output tiles and keeps the
 // next tile's first operand half-tiles in flight while it converts and stores the current one).  Returns 1 = launched,
@@ -59,6 +62,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   int xcd = bid & 7, idx = bid >> 3;
   int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return start + idx;
+}
+// Split-K slab of this workgroup = split * tiles + (row-major tile index): what splitk_reduce_kernel expects.  The WALK (which slab the workgroup at
+// position `xcd_remap(blockIdx.x)` takes) runs through a split's tiles along the SHORTER side of the tile grid first: an XCD owns a contiguous range of
+// ~32 positions, and its L2 serves every operand panel of that range once -- a 3 x 12 grid walked row-major makes such a range touch 3 + 12 panels of one
+// split and 1 + 4 .. 2 + 12 of the next, walked column-major 3 + 11 and 2 + 3 (fc2's weight gradient at 256 clips: 6.42 -> 4.8 GB of fabric reads per launch
+// for 3.87 GB of operands, profiles/r06h_wgrad_xcd.txt).
+__device__ __forceinline__ int accum_slab(const GemmParams& p) {
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int pos = xcd_remap(blockIdx.x, ntile * p.splitk);
+  if (!p.tile_cm) return pos;
+  const int split = pos / ntile, u = pos - split * ntile, tn = u / p.tiles_m;
+  return split * ntile + (u - tn * p.tiles_m) * p.tiles_n + tn;
 }
 
 // One MFMA step; the operand order decides whether a lane ends up holding a column or a row of the output block:
@@ -836,7 +851,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
     // deterministic weight-gradient epilogue: this block's partial tile goes to its own slab of the caller's workspace in
     // accumulator order (full 1-KB wave stores); splitk_reduce_kernel adds the slabs in split order into C
     const int NWV = (int)(blockDim.x >> 6);
-    const int slab = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splitk);      // = split * tiles + tile
+    const int slab = accum_slab(p);                                                 // = split * tiles + tile
     float* dst = p.ws + (size_t)slab * (size_t)(NWV * TM * TN * 1024) + (size_t)wave * (TM * TN * 1024) + lane * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i)

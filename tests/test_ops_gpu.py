@@ -916,11 +916,12 @@ def test_sgd_step(ops):
 
 
 @pytest.mark.parametrize('M,P,Q', [(64, 128, 128), (500, 768, 768), (3152, 2304, 768), (50000, 3072, 768), (176, 3840, 768), (77, 64, 32), (1280, 768, 768),
-                                   (640, 2048, 8192), (30, 2048, 8192), (640, 2000, 8200), (2560, 8192, 2048)])
+                                   (640, 2048, 8192), (30, 2048, 8192), (640, 2000, 8200), (2560, 8192, 2048), (50000, 768, 3072), (20000, 704, 1504)])
 def test_deterministic_wgrad_accumulate(ops, M, P, Q):
     """avt_gemm_accum_bf16 (split-K slabs + ordered reduce; since round 6 a launch whose workgroups hold the whole reduction -- the head's
     2048 x 8192 weights at <= 2560 rows, every tiny shape -- adds its tiles into C itself, no slab, no second launch): equals the fp32 reference,
-    accumulates on top of C, and is bit-identical from call to call -- unlike the atomic path, whose last bits depend on arrival order."""
+    accumulates on top of C, and is bit-identical from call to call -- unlike the atomic path, whose last bits depend on arrival order.
+    (50000, 768, 3072) / (20000, 704, 1504): more column tiles than row tiles with several splits -- the column-major walk of round 6, accum_slab.)"""
     dy, x = rnd((M, P), 1.0, 41), rnd((M, Q), 1.0, 42)
     ref = dy.float().t() @ x.float()
     base = rnd((P, Q), 1.0, 43, torch.float32)
