@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   const int lb = xcd_remap(bid, ntile * p.splitk);          // an XCD owns a contiguous range of (split, tile): see xcd_remap
   const int split = lb / ntile;
   const int t = lb - split * ntile;
-  const int tm0 = (t / p.tiles_n) * BM;
+  const int tm0 = (t / p.tiles_n + p.tile_m0) * BM;
   const int tn0 = (t % p.tiles_n) * BN;
 
   const int nk_total = (p.K + BK - 1) / BK;
@@ -229,6 +229,98 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   gemm_epilogue<TM, TN, WM, WN, EPI, 0, false, A_KMAJOR && B_KMAJOR>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
 }
 
+// ---- skinny kernel: at most 32 output rows (the head at the reference's own 3 clips per GPU: 30 rows; the CLS-only last ViT block) ----------------
+// C[M <= 32, N] = epilogue(A[M,K] . op(B)), A k-major.  Such a GEMM is a stream of the weight matrix (2048 x 8192 bf16 = 33.5 MB against 0.5 MB of
+// activations) and the 64 x 64 kernel runs it as 32 workgroups of N / 64 -- one eighth of the chip, each with two 16-KB stages in flight: 33 us = 1 TB/s
+// (profiles/r06h_kernel_trace_B3.txt).  Split-K would fill the chip but change the fp32 summation order, and every tile route of this library gives the
+// same bits for a shape (the batch-invariance tests).  So the reduction stays ONE ordered chain of v_mfma_f32_32x32x16_bf16 per 32 x 32 output tile, and
+// the parallelism comes from (a) 32-column tiles -- N / 32 workgroups -- and (b) memory-level parallelism inside a workgroup: four waves issue the LDS-DMA
+// of an 18-stage ring of [32 x 64] A + [32 x 64] B tiles (144 KB; 17 stages = 68 KB of weights in flight per workgroup, a wave's own counter sees 34
+// requests), wave 0 alone runs the chain (4 MFMAs per stage, the next stage's fragments requested before them).  Stages past the end of the reduction
+// are requested all the same (out of range -> zeros, no traffic): the counted wait stays one constant.
+template <bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
+  constexpr int BM = 32, BN = 32, BK = 64, NST = 18, NW = 4;
+  constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2, STAGE = A_TILE + B_TILE;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // neighbouring column tiles on the same XCD: with B stored [K][N] a k row of the tile is 64 bytes, half a cache line -- the other half belongs to the
+  // next tile, and one L2 then fetches the line once for both
+  const int tn0 = xcd_remap(blockIdx.x, p.tiles_n) * BN;
+  const int nk = (p.K + BK - 1) / BK;
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
+  auto stage = [&](int buf, int kt) __attribute__((always_inline)) {       // two requests per wave
+    char* base = lds + buf * STAGE;
+    const int k0 = kt * BK;
+    stage_kmajor<BM, NW, BK>(ra, base, 0, k0, p.lda, p.K, wave, lane);
+    if (B_KMAJOR) stage_kmajor<BN, NW, BK>(rb, base + A_TILE, tn0, k0, p.ldb, p.K, wave, lane);
+    else stage_kstrided<BN, NW, BK>(rb, base + A_TILE, tn0, k0 < p.K ? k0 : p.K, p.ldb, p.N, wave, lane);
+  };
+  f32x16_t acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  bf16x8_t af[2][4], bfr[2][4];
+  auto frags = [&](int slot, int b) __attribute__((always_inline)) {
+    const char* la = lds + slot * STAGE;
+    const char* lb = la + A_TILE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      af[b][ks] = frag_kmajor<BK>(la, 0, ks, lane);
+      bfr[b][ks] = B_KMAJOR ? frag_kmajor<BK>(lb, 0, ks, lane) : frag_kstrided_na<BN>(lb, 0, ks, lane);
+    }
+  };
+  auto chain = [&](int b) __attribute__((always_inline)) {
+    if (!B_KMAJOR) frag_wait<0>(af[b], bfr[b]);          // (inline-assembly reads: the compiler does not wait for them)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc[0][0] = mma<0>(af[b][ks], bfr[b][ks], acc[0][0]);
+  };
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) stage(s, s);
+  int slot = 0;
+#pragma nounroll
+  for (int it = 0; it < nk; it += 2) {
+    // even stage: its fragments go into set 0 while the chain of the previous (odd) stage runs on set 1
+    // (lgkmcnt(0): wave 0's fragment reads of the slot refilled below have retired -- they were issued a whole chain ago)
+    wait_vmcnt<2 * (NST - 2)>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    { int fill = slot + NST - 1; if (fill >= NST) fill -= NST; stage(fill, it + NST - 1); }
+    if (wave == 0) { frags(slot, 0); if (it) chain(1); }
+    if (++slot == NST) slot = 0;
+    // odd stage (past the end when nk is odd: fetched as zeros, never multiplied)
+    wait_vmcnt<2 * (NST - 2)>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    { int fill = slot + NST - 1; if (fill >= NST) fill -= NST; stage(fill, it + NST); }
+    if (wave == 0) { frags(slot, 1); chain(0); }
+    if (++slot == NST) slot = 0;
+  }
+  if (wave == 0 && !(nk & 1)) chain(1);
+  wait_vmcnt<0>();                                        // the zero stages past the end have landed: the ring is quiet
+  asm volatile("s_barrier" ::: "memory");
+  if (wave == 0) gemm_epilogue<1, 1, 32, 32, 0, 0, false, B_KMAJOR>(p, acc, lds, 0, lane, 0, tn0);
+}
+
+int dispatch_skinny(GemmParams& p, int a_kmajor, int b_kmajor, hipStream_t s) {
+  if (!a_kmajor || p.M > 32) { avt_set_error("avt_gemm_bf16: tile 32 is the skinny kernel: A k-major, M <= 32 (got M = %d)", p.M); return -1; }
+  // (a B stored [K][N] is addressed up to one stage past its last row: that offset must not wrap)
+  if (!b_kmajor && (uint64_t)p.b_bytes + 64ull * (uint64_t)p.ldb * 2ull >= (1ull << 32)) { avt_set_error("avt_gemm_bf16: tile 32: B too large"); return -1; }
+  p.tiles_m = 1; p.tiles_n = (p.N + 31) / 32; p.splitk = 1;
+  constexpr int smem = 18 * 8192;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  if (b_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<true>), dim3(p.tiles_n), dim3(256), smem, s, p);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<false>), dim3(p.tiles_n), dim3(256), smem, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
 // Second pass of the deterministic split-K accumulate: one wave per 1-KB chunk (producing wave w, block (i, j), register
 // quad q) mirrors the producer's register layout, sums the chunk over the splits IN ORDER and adds the result to C (every C
 // element has exactly one owner, so plain read-modify-write; C keeps the running sum of earlier GEMMs into the same gradient).
@@ -324,7 +416,7 @@ int dispatch_layout(const GemmParams& p, int a_kmajor, int b_kmajor, hipStream_t
 
 template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool SPREAD = false, int PR = 0, int MINW = 1, int NWL = 0>
 int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
-  p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+  p.tiles_m = ((p.m_cap ? p.m_cap : p.M - p.tile_m0 * BM) + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
   const int nk = (p.K + BK - 1) / BK;
   if (splitk <= 0) {                 // auto: about two blocks' worth of work per CU slot
     splitk = 1;
@@ -631,7 +723,7 @@ int launch_8p(const GemmParams& p, hipStream_t s) {
 
 // persist: 0 = never (tile 808: gemm_8p_kernel itself), 1 = where gemm_persist.hip covers the shape and measures faster (tile 0), 2 = forced (tile 809)
 int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s, int persist = 0) {
-  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
+  p.tiles_m = ((p.m_cap ? p.m_cap : p.M) + 255) / 256; p.tiles_n = (p.N + 255) / 256;      // (m_cap: the main launch of a GEMM whose tail round runs on small tiles)
   const int nk = (p.K + 63) / 64;
   if (splitk <= 0) {
     splitk = 1;
@@ -993,6 +1085,9 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
   }
   if (tile == 0 && bm == 256 && (K % 64 == 0 || (!a_kmajor && !b_kmajor))) bm = 8080;      // default big-tile kernel: the 8-phase schedule, persistent where that is faster
   if (tile == 0 && bm == 8080 && epi == 2) bm = 2565;                                          // weight gradients: 4 waves of 128x128 (+2-3 % over the 8-phase kernel)
+  // at most 32 output rows of k-major A rows (the head at the reference's 3 clips per GPU, the CLS-only last ViT block): the skinny kernel -- N / 32
+  // workgroups, one ordered MFMA chain each, an 18-stage ring: same bits, 2-3x the weight stream of the 64 x 64 tiles (profiles/r06j_skinny_gemm.txt)
+  if (tile == 0 && bm == 64 && epi == 0 && a_kmajor && M <= 32 && (b_kmajor || (uint64_t)bb + 64ull * (uint64_t)ldb * 2ull < (1ull << 32))) bm = 32;
   if (tile == 0 && bm == 64 && epi == 0 && a_kmajor && (b_kmajor || (long)((M + 63) / 64) * ((N + 63) / 64) <= 256)) bm = 643;                                // small outputs of k-major rows: 3-deep ring (+15-25 % on the head's data gradients; late round 5: also with B stored [K][N] while the tiles fit one round -- the head's forward at 30 .. 160 rows: 60 -> 46 us at K = 8192; at 2560 rows the 2-deep ring is the faster one there)
   AVT_CHECK(!(p.c2_frag || p.aux_frag) || bm == 8080 || bm == 809,
             "avt_gemm_bf16: a fragment-major C2 / aux (ldc2 == 0 / ldaux == 0) needs the persistent kernel, which does not take this shape: ask avt_gemm_frag_ok(M, N, K) first");
@@ -1000,9 +1095,26 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
   if (colsum && part) {
     // one partial row per wave row of the grid: every tile shape here has two wave rows per tile
     const int BM = (bm == 64 || bm == 643) ? 64 : (bm == 128 ? 128 : 256);
-    nslots = ((M + BM - 1) / BM) * 2;
+    nslots = bm == 32 ? 1 : ((M + BM - 1) / BM) * 2;             // (the skinny kernel: one wave row in all)
     AVT_CHECK(aligned16(part) && part_bytes >= (size_t)nslots * N * 4, "avt_gemm_bf16: partials workspace too small or misaligned (%zu bytes needed)", (size_t)nslots * N * 4);
     p.colsum_part = part;
+  }
+  // Tail round on small tiles (round 6).  The big-tile kernels run one workgroup per CU: t tiles take ceil(t / 256) rounds, and a last round that is at most
+  // half full costs a whole round (16 clips per GPU: 372 tiles of the N = 768 outputs = 1.45 rounds paid as 2; 256 clips: 23.09 as 24).  Such a GEMM is cut
+  // along M: the rows that fill whole rounds go to the big-tile kernel, the rest -- at most 128 big tiles' worth -- to 128 x 128 tiles, two workgroups per
+  // CU, in a second launch behind it (same bits: every tile route sums a row's products in the same order).  Not with column sums (their partials are
+  // laid out per kernel) or a fragment-major tensor (only the persistent kernel knows its order).
+  if (tile == 0 && bm == 8080 && epi == 0 && !colsum && !p.c2_frag && !p.aux_frag) {
+    const long tm = (M + 255) / 256, tn = (N + 255) / 256, t256 = tm * tn, full = t256 / 256, rem = t256 - full * 256;
+    const long r_main = full * 256 / tn;
+    if (full >= 1 && rem > 0 && rem <= 128 && r_main >= 1 && r_main < tm) {
+      GemmParams q = p;
+      p.m_cap = (int)r_main * 256;
+      int rc = gemm_dispatch(p, bm, epi, a_kmajor, b_kmajor, splitk, K, s);
+      if (rc) return rc;
+      q.tile_m0 = (int)r_main * 2;
+      return gemm_dispatch(q, 128, epi, a_kmajor, b_kmajor, splitk, K, s);
+    }
   }
   int rc = gemm_dispatch(p, bm, epi, a_kmajor, b_kmajor, splitk, K, s);
   if (rc == 0 && nslots) { float* outs[1] = {colsum}; rc = avt_reduce_partials(part, nslots, N, outs, 1, s); }
@@ -1025,6 +1137,9 @@ static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kma
     case 64:  return dispatch_epi<64, 64, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 128: return dispatch_epi<128, 128, 2, 2, 64, 2>(p, epi, a_kmajor, b_kmajor, splitk, s);
     case 643: return dispatch_epi<64, 64, 2, 2, 64, 3>(p, epi, a_kmajor, b_kmajor, splitk, s);     // 3-deep ring
+    case 32:
+      if (epi != 0 || splitk > 1) { avt_set_error("avt_gemm_bf16: tile 32 (skinny kernel) has the activation epilogue only"); return -1; }
+      return dispatch_skinny(p, a_kmajor, b_kmajor, s);
     // (4- and 6-deep rings measured no better than the 3-deep one on the head's 30 .. 160-row GEMMs: profiles/r05zc_tiny_m_gemm_sweep.txt)
     case 256:                                                                                     // one barrier per K tile, dribbled LDS-DMA issued by 4 loader waves
       if (K % 64 == 0 || (!a_kmajor && !b_kmajor)) return dispatch_epi<256, 256, 2, 4, 64, 2, true, 0, 1, 4>(p, epi, a_kmajor, b_kmajor, splitk, s);
@@ -1039,7 +1154,7 @@ static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kma
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
     default: break;
   }
-  avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 64, 128, 643, 256 / 2568 (one barrier per K tile), 808 (8-phase) or 809 (8-phase, persistent) (got %d)", bm);
+  avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 32 (M <= 32), 64, 128, 643, 256 / 2568 (one barrier per K tile), 808 (8-phase) or 809 (8-phase, persistent) (got %d)", bm);
   return -1;
 }
 

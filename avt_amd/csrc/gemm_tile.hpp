@@ -36,6 +36,9 @@ struct GemmParams {
   // weight-gradient slabs (EPI 2): walk a split's tiles column-major (the output has more column tiles than row tiles), so that the contiguous
   // range of the walk an XCD owns covers few operand panels either way (accum_slab; profiles/r06h_wgrad_xcd.txt)
   int tile_cm;
+  // a GEMM cut in two launches along M (gemm.hip: gemm_impl, "tail round on small tiles"): this launch covers `m_cap` rows (0 = up to M) from row tile
+  // `tile_m0` (in units of the kernel's own BM; only the generic kernel takes a non-zero one) -- M stays the whole matrix' row count (bounds, strides)
+  int tile_m0, m_cap;
 };
 // gemm_persist.hip: the persistent form of the 8-phase kernel (one workgroup per CU walks a queue of output tiles and keeps the
 // next tile's first operand half-tiles in flight while it converts and stores the current one).  Returns 1 = launched,
@@ -144,7 +147,7 @@ __device__ __forceinline__ void gelu_tab_both4(f32x2_t& x0, f32x2_t& x1, f32x2_t
 // c ^ ((r>>1)&7) for BK=64 (128-B rows) and c ^ ((r>>2)&3) for BK=32 (64-B rows): the 16 rows a ds_read_b128 lane
 // group touches then land on 16 distinct 16-B slots of the 256-B bank row.
 template <int BR>
-__device__ __forceinline__ int kstrided_swz_fwd(int r) { return BR >= 128 ? ((r & 3) << 2) : (((r >> 1) & 1) << 2); }
+__device__ __forceinline__ int kstrided_swz_fwd(int r) { return BR >= 128 ? ((r & 3) << 2) : (BR >= 64 ? (((r >> 1) & 1) << 2) : 0); }
 template <int BK>
 __device__ __forceinline__ int kmajor_swz(int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 template <int BR, int NW, int BK>
@@ -190,9 +193,10 @@ __device__ __forceinline__ void stage_kmajor(__amdgpu_buffer_rsrc_t rsrc, char* 
   }
 }
 // reduction-index-as-row operand: LDS tile [BK][BR] bf16; chunk swizzle keeps the 4 rows of a tr-read on
-// distinct 64-B bank segments (BR>=128: c ^ ((r&3)<<2); BR=64: c ^ (((r>>1)&1)<<2)).
+// distinct 64-B bank segments (BR>=128: c ^ ((r&3)<<2); BR=64: c ^ (((r>>1)&1)<<2); BR=32: 64-byte rows, the four rows of a read
+// already lie 64 B apart -- no swizzle).
 template <int BR>
-__device__ __forceinline__ int kstrided_swz(int r) { return BR >= 128 ? ((r & 3) << 2) : (((r >> 1) & 1) << 2); }
+__device__ __forceinline__ int kstrided_swz(int r) { return BR >= 128 ? ((r & 3) << 2) : (BR >= 64 ? (((r >> 1) & 1) << 2) : 0); }
 template <int BR, int NW, int BK>
 __device__ __forceinline__ void stage_kstrided(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int col0, int k0, int ld,
                                                int ncols, int wave, int lane) {

@@ -68,6 +68,11 @@ class GradReducer:
         self.launched = 0                   # buckets handed to the collective in the current step
         self.bytes_on_wire = 0              # payload bytes of those buckets (per rank, before the algorithm's own factor)
         self._timing = []                   # per step: (backward done on the compute stream, last collective done on the comm stream)
+        # on_final(lo, stream): everything in [lo, total) of the gradient buffer now holds its FINAL value for this step -- produced and, in a data-parallel
+        # job, exchanged.  `stream` = the stream that is current and on which that is true (the exchange's side stream), or None = the compute stream,
+        # right behind the producing kernels.  func/train.py::Trainer applies the fused optimizer to that suffix at once (round 6): the head's 78 % of the
+        # parameters are updated while the ViT's backward still runs, instead of in one weight-sized pass after it.
+        self.on_final = None
         self._hooked = [m for m in model.modules() if hasattr(m, 'grad_ready_hook')]
         self._seen = {}
         self._fwd_calls = {}
@@ -135,8 +140,10 @@ class GradReducer:
                 if lo < self._sent:
                     self._launch(lo, self._sent)
                     self._tail_sent = True
+        elif self.on_final is not None and self.world <= 1 and not self.always and not self.paused:
+            self.on_final(self._lo, None)       # a single process: final as produced
 
-    def _launch(self, s, e):
+    def _launch(self, s, e, notify=True):
         a = self.arena
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
@@ -144,8 +151,14 @@ class GradReducer:
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
                 h = self._reduce(a.grad[s:e])
+                if notify and self.on_final is not None:
+                    h.wait()                    # (nccl: orders the side stream behind the collective; gloo: blocks the host -- a functional path)
+                    self.on_final(s, self.comm_stream)
         else:
             h = self._reduce(a.grad[s:e])
+            if notify and self.on_final is not None:
+                h.wait()
+                self.on_final(s, None)
         self._handles.append(h)
         self.launched += 1
         self._sent = s
@@ -187,8 +200,9 @@ class GradReducer:
         if timed:
             bwd_done = torch.cuda.Event(enable_timing=True)
             bwd_done.record(torch.cuda.current_stream())
-        if self._sent > 0:
-            self._launch(0, self._sent)
+        tail = self._sent > 0
+        if tail:
+            self._launch(0, self._sent, notify=False)
         for h in self._handles:
             h.wait()
         if timed:
@@ -198,6 +212,8 @@ class GradReducer:
             self._timing.append((bwd_done, comm_done))
             del self._timing[:-64]
         self._handles = []
+        if tail and self.on_final is not None:
+            self.on_final(0, None)              # (the compute stream is ordered behind every collective here)
 
     def stats(self, last=None):
         """Per-rank exchange accounting for the bench line: buckets and payload bytes of the last step, and how long the

@@ -190,6 +190,34 @@ class Trainer:
             else:
                 GradReducer.broadcast_parameters(model)
         self.last_losses = {}
+        # Early optimizer step (round 6): as backward finishes a suffix of the flat gradient buffer (and, data-parallel, its exchange is enqueued), the
+        # fused SGD runs on that suffix at once -- single process: on a side stream, under the rest of backward; data-parallel: on the exchange's stream
+        # behind the bucket's collective -- so the weight-sized pass (26 B per parameter, 78 % of them the head's) no longer stands behind backward.
+        # Needs the step's gradient scale up front: not with gradient clipping (the norm of ALL gradients comes first).
+        self.early_step = bool(self.EARLY_STEP and self.fused and self.max_norm is None and model.arena.grad.is_cuda)
+        self._side_used = False
+        self._tracker = None
+        if self.early_step:
+            self._tracker = self.reducer if self.reducer is not None else GradReducer(model, bucket_bytes=bucket_bytes)    # (world of one: segment book-keeping only)
+            self._tracker.on_final = self._early_sgd
+
+    EARLY_STEP = False          # measured neutral to slightly negative on one GPU (profiles/r06k_early_step.txt): an option, off by default
+    EARLY_MIN_ELEMS = 32 << 20          # a suffix goes out once it holds this many new elements (the head at once, the ViT's blocks in two or three lots)
+
+    def _early_sgd(self, lo, stream):
+        opt = self.optimizer
+        if lo > 0 and opt._early_lo - lo < self.EARLY_MIN_ELEMS:
+            return                          # (deferred: a later call, or step(), covers it)
+        side = self._tracker.comm_stream
+        if stream is None and self.reducer is None and side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                opt.step_suffix(lo)
+            self._side_used = True
+        else:
+            opt.step_suffix(lo)             # on the exchange's stream (behind the bucket's collective), or on the compute stream after finish()
 
     def total_loss(self, losses):
         final = None
@@ -212,7 +240,11 @@ class Trainer:
         return float(torch.clamp(self.max_norm / (total + 1e-6), max=1.0))
 
     def step(self, data, sync_loss=False):
-        if self.reducer is not None:
+        if self._tracker is not None:
+            self._tracker.start_step()
+            if self.fused:
+                self.optimizer.grad_scale = 1.0 / self.world
+        elif self.reducer is not None:
             self.reducer.start_step()
         data, outputs, losses, accuracies = self.op(data, train_mode=True)
         loss = self.total_loss(losses)
@@ -227,6 +259,9 @@ class Trainer:
             self.optimizer.grad_scale = scale
         elif scale != 1.0:
             self.model.arena.grad.mul_(scale)
+        if self._side_used:                 # the early launches of this step ran on the side stream
+            torch.cuda.current_stream().wait_stream(self._tracker.comm_stream)
+            self._side_used = False
         self.optimizer.step()
         if self.lr_scheduler is not None:
             self.lr_scheduler.step()

@@ -44,7 +44,19 @@ def persist_epilogue_kind(out_mode, act, has_bias, has_res, has_aux, has_c2, has
     return None
 
 
-def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False):
+def gemm_tail_split(M, N, epi=0, ok=True):
+    """Mirror of gemm_impl's 'tail round on small tiles' (csrc/gemm.hip): (big tiles of the main launch, rows of the main launch | None when the GEMM is
+    one launch).  ``ok``: no column sums and no fragment-major tensor in the call."""
+    tm, tn = (M + 255) // 256, (N + 255) // 256
+    t256 = tm * tn
+    full, rem = divmod(t256, 256)
+    r_main = full * 256 // tn
+    if ok and epi == 0 and full >= 1 and 0 < rem <= 128 and 1 <= r_main < tm:
+        return r_main * tn, r_main * 256
+    return t256, None
+
+
+def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False, split_ok=True):
     """Mirror of the tile choice in avt_gemm_bf16 (csrc/gemm.hip): names the kernel template a call lands on.
     ``epilogue_ok``: False / None = the persistent kernel does not cover the epilogue; True or an int = it does (an int names the kind)."""
     epk = None if (epilogue_ok is False or epilogue_ok is None) else (epilogue_ok if type(epilogue_ok) is int else -1)
@@ -67,12 +79,16 @@ def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False)
             bm = 256 if (t256 * sk >= 256 and t256 < 4096) else 128
         if bm == 256 and (K % 64 == 0 or (not a_kmajor and not b_kmajor)):
             bm = 808
-            t256 = ((M + 255) // 256) * ((N + 255) // 256)
+            t256 = gemm_tail_split(M, N, epi, split_ok)[0]      # (the tiles of the main launch when the tail round goes to small tiles)
             if (epi == 0 and a_kmajor and b_kmajor and epilogue_ok and N % 256 == 0 and K % 128 == 0 and 256 <= K <= PERSIST_KMAX
                     and 512 <= t256 < 65536):
                 bm = 809          # the persistent form (csrc/gemm_persist.hip: avt_gemm_persist)
+        if bm == 64 and epi == 0 and a_kmajor and M <= 32:
+            bm = 32           # the skinny kernel (csrc/gemm.hip: gemm_skinny_kernel)
         if bm == 64 and epi == 0 and a_kmajor and (b_kmajor or ((M + 63) // 64) * ((N + 63) // 64) <= 256):
             bm = 643
+    if bm == 32:
+        return f'gemm_skinny_kernel<{int(bool(b_kmajor))}>'
     shape = {64: '64,64,2,2,64,2,0', 128: '128,128,2,2,64,2,0', 256: '256,256,2,4,64,2,1', 2568: '256,256,2,4,64,2,1,l8', 808: '8p', 809: '8pp', 643: '64,64,2,2,64,3,0'}[bm]
     if bm == 808:
         return f'gemm_8p_kernel<{int(bool(a_kmajor))},{int(bool(b_kmajor))},{epi}>'
@@ -188,7 +204,7 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
             ep_ok = {0: 5, 1: 6}.get(ep_ok) if ln_c is not None else ({3: 7}.get(ep_ok) if ln_stat is not None else ({2: 4}.get(ep_ok) if N % 64 == 0 else None))
         if c2_frag or aux_frag:               # the fragment-major forms: 8 / 9 = 1 / 6 writing it, 10 / 11 = 3 / 7 reading it
             ep_ok = {1: 8, 6: 9, 3: 10, 7: 11}.get(ep_ok)
-        trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, ep_ok), 2.0 * M * N * K, ev0, ev1, (M, N, K)))
+        trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, ep_ok, colsum is None and not c2_frag and not aux_frag), 2.0 * M * N * K, ev0, ev1, (M, N, K)))
     return out
 
 

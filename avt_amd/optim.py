@@ -36,6 +36,7 @@ class FusedSGD:
         self.grad_scale = 1.0            # set to 1/world_size by the gradient reducer (sum all-reduce)
         self._ranges = None
         self._uncovered = []
+        self._early_lo = arena.total     # this step's update has already been applied to [_early_lo, total) (step_suffix)
 
     def _build_ranges(self):
         """[(start, end, group_index)] covering each group's parameters as maximal contiguous arena ranges."""
@@ -57,8 +58,8 @@ class FusedSGD:
     def zero_grad(self, set_to_none: bool = False):
         """No-op by design: step() re-zeroes the gradient range it consumed."""
 
-    @torch.no_grad()
-    def step(self):
+    def _launch_ranges(self, lo, hi):
+        """The update on the part of every group range inside [lo, hi): one launch per maximal run of adjacent ranges whose hyper-parameters agree."""
         a = self.arena
         if self._ranges is None:
             self._ranges = self._build_ranges()
@@ -69,7 +70,6 @@ class FusedSGD:
                 pos = max(pos, e0)
             if pos < a.total:
                 self._uncovered.append((pos, a.total))
-        # launch per maximal run of adjacent ranges whose hyper-parameters agree
         i = 0
         R = self._ranges
         while i < len(R):
@@ -84,10 +84,28 @@ class FusedSGD:
                     j += 1
                 else:
                     break
-            ops.sgd_step(a.master[s:e], a.grad[s:e], self.momentum_buf[s:e], a.shadow[s:e], g['lr'], g['momentum'],
-                         g['weight_decay'], grad_scale=self.grad_scale, nesterov=bool(g['nesterov']),
-                         first_step=(self.steps == 0), zero_grad=True)
+            s, e = max(s, lo), min(e, hi)
+            if s < e:
+                ops.sgd_step(a.master[s:e], a.grad[s:e], self.momentum_buf[s:e], a.shadow[s:e], g['lr'], g['momentum'],
+                             g['weight_decay'], grad_scale=self.grad_scale, nesterov=bool(g['nesterov']),
+                             first_step=(self.steps == 0), zero_grad=True)
             i = j
+
+    @torch.no_grad()
+    def step_suffix(self, lo):
+        """Apply THIS step's update to [lo, the part already updated) now, on the current stream: the gradients there are final (backward fills the flat
+        buffer from its end; func/train.py::Trainer calls this as segments finish, round 6).  ``step()`` then only has [0, lo) left.  ``grad_scale`` and the
+        groups' learning rates must already be the step's.  Ranges must be 64-element aligned only in the sense that the arena's tensors are."""
+        lo = max(int(lo), 0)
+        if lo < self._early_lo:
+            self._launch_ranges(lo, self._early_lo)
+            self._early_lo = lo
+
+    @torch.no_grad()
+    def step(self):
+        a = self.arena
+        self._launch_ranges(0, self._early_lo)
+        self._early_lo = a.total
         for s0, e0 in self._uncovered:           # frozen parameters: nobody consumes their gradients, keep the range clean
             a.grad[s0:e0].zero_()
         self.steps += 1

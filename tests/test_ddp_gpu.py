@@ -36,8 +36,15 @@ if rank == 1:                              # perturb: broadcast from rank 0 must
     with torch.no_grad(): model.classifiers.action.bias.add_(1.0)
 opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-4, arena=model.arena)
 op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
+# early optimizer step (round 6): AVT_TEST_EARLY_MIN=1 lets every exchanged bucket of this small model be stepped behind its collective; '0' switches it off
+if os.environ.get('AVT_TEST_EARLY_MIN') == '0': Trainer.EARLY_STEP = False
+elif os.environ.get('AVT_TEST_EARLY_MIN'): Trainer.EARLY_MIN_ELEMS = int(os.environ['AVT_TEST_EARLY_MIN'])
 tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=world > 1, bucket_bytes=64 << 10, reduce_mode=os.environ.get('AVT_TEST_REDUCE_MODE', 'all_reduce'),
              reduce_transport=os.environ.get('AVT_TEST_TRANSPORT', 'torch'))
+early_calls = []
+if tr.early_step:
+    real_suffix = opt.step_suffix
+    opt.step_suffix = lambda lo: (early_calls.append(lo), real_suffix(lo))[1]
 g = torch.Generator().manual_seed(9)
 B = int(os.environ.get('AVT_TEST_CLIPS', 4))
 video = torch.rand((B, 4, 3, 1, 32, 32), generator=g) * 2 - 1
@@ -53,6 +60,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 if rank == 0:
     torch.save({k: v.cpu() for k, v in model.state_dict().items()}, sys.argv[2])
+if os.environ.get('AVT_TEST_EARLY_MIN', '0') not in ('0', ''):
+    assert tr.early_step and len(early_calls) > 3 * 2 and (world == 1 or min(early_calls) == 0), early_calls      # several suffixes per step; data-parallel: finish() hands over the rest
 if world > 1:
     assert tr.reducer is not None and tr.reducer.launched >= 1
     if os.environ.get('AVT_TEST_CHECK_COMM'):
@@ -97,6 +106,22 @@ def test_two_rank_training_matches_single_process(tmp_path):
         e = float((a[k] - b[k]).abs().max() / (a[k].abs().max() + 1e-12))
         worst = max(worst, e)
         assert e < 2e-2, (k, e)          # bf16 activations; batch split changes rounding, not the maths
+
+
+def test_early_optimizer_step_behind_each_bucket_matches_the_late_step(tmp_path):
+    """Round 6: the fused SGD runs on every suffix of the gradient buffer as soon as its exchange is enqueued (on the exchange's stream, behind the
+    collective) instead of in one pass after backward.  Two ranks, every 64-KiB bucket stepped on its own (AVT_TEST_EARLY_MIN=1), against the same job
+    with the feature off: identical parameters, bit for bit (the update of an element does not depend on when it is applied)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    _run(2, tmp_path / 'late.pt', tmp_path, 29561, AVT_TEST_EARLY_MIN='0')
+    _run(2, tmp_path / 'early.pt', tmp_path, 29562, AVT_TEST_EARLY_MIN='1')
+    _run(1, tmp_path / 'early1.pt', tmp_path, 29563, AVT_TEST_EARLY_MIN='1')          # single process: the side-stream form
+    _run(1, tmp_path / 'late1.pt', tmp_path, 29564, AVT_TEST_EARLY_MIN='0')
+    for x, y in (('late.pt', 'early.pt'), ('late1.pt', 'early1.pt')):
+        a, b = torch.load(tmp_path / x), torch.load(tmp_path / y)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (x, y, k)
 
 
 @pytest.mark.parametrize('mode', ['all_reduce', 'rs_ag'])
