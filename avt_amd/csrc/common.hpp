@@ -86,6 +86,13 @@ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
   return (uint32_t)(z >> 16);
 }
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) { return rng_u32(seed, idx) >= thresh; }
+// Indirect seeds (ABI 9, include/avt_hip.h "captured steps"): a seed argument with bit 63 set is not the seed but where to find it -- bits 0..47 = the
+// device address of a uint64 holding a base seed, bits 48..62 = an offset added to it -- so that a step captured into a hipGraph draws fresh masks at
+// every replay (the host rewrites the base seed between replays; the launches' arguments stay what they were).  Plain seeds have bit 63 clear.
+__device__ __forceinline__ uint64_t resolve_seed(uint64_t s) {
+  if (s >> 63) s = *(const uint64_t*)(uintptr_t)(s & 0x0000FFFFFFFFFFFFull) + ((s >> 48) & 0x7FFFull);
+  return s;
+}
 static inline uint32_t drop_threshold(float p) {
   double t = (double)p * 4294967296.0;
   if (t < 0) t = 0;

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void cast_back_kernel(const bf16_t* __restrict
 // y = keep(seed, idx) ? x / (1-p) : 0, bf16 -> bf16 (also its own backward on gradients, same seed)
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n,
                                                       uint32_t thresh, float scale, uint64_t seed) {
+  seed = resolve_seed(seed);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
     y[i] = drop_keep(seed, (uint64_t)i, thresh) ? f2bf(bf2f(x[i]) * scale) : (bf16_t)0;
 }
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__
 __global__ __launch_bounds__(256) void embed_pos_kernel(const bf16_t* __restrict__ enc, const float* __restrict__ wpe,
                                                         bf16_t* __restrict__ h, int B, int T, int E,
                                                         uint32_t thresh, float scale, uint64_t seed) {
+  seed = resolve_seed(seed);
   long n = (long)B * T * E;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     int e = (int)(i % E);
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(256) void embed_pos_kernel(const bf16_t* __restrict
 __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const bf16_t* __restrict__ dh, bf16_t* __restrict__ denc,
                                                             float* __restrict__ dwpe, int B, int T, int E,
                                                             uint32_t thresh, float scale, uint64_t seed) {
+  seed = resolve_seed(seed);
   long n = (long)T * E;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float acc = 0.f;

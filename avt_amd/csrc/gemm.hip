@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   const int lb = xcd_remap(bid, ntile * p.splitk);          // an XCD owns a contiguous range of (split, tile): see xcd_remap
   const int split = lb / ntile;
   const int t = lb - split * ntile;
-  const int tm0 = (t / p.tiles_n + p.tile_m0) * BM;
+  const int tm0 = (t / p.tiles_n) * BM;
   const int tn0 = (t % p.tiles_n) * BN;
 
   const int nk_total = (p.K + BK - 1) / BK;
@@ -416,7 +416,7 @@ int dispatch_layout(const GemmParams& p, int a_kmajor, int b_kmajor, hipStream_t
 
 template <int BM, int BN, int WGM, int WGN, int BK, int NSTAGE, bool SPREAD = false, int PR = 0, int MINW = 1, int NWL = 0>
 int dispatch_epi(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
-  p.tiles_m = ((p.m_cap ? p.m_cap : p.M - p.tile_m0 * BM) + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
+  p.tiles_m = (p.M + BM - 1) / BM; p.tiles_n = (p.N + BN - 1) / BN;
   const int nk = (p.K + BK - 1) / BK;
   if (splitk <= 0) {                 // auto: about two blocks' worth of work per CU slot
     splitk = 1;
@@ -723,7 +723,7 @@ int launch_8p(const GemmParams& p, hipStream_t s) {
 
 // persist: 0 = never (tile 808: gemm_8p_kernel itself), 1 = where gemm_persist.hip covers the shape and measures faster (tile 0), 2 = forced (tile 809)
 int dispatch_8p(GemmParams& p, int epi, int a_kmajor, int b_kmajor, int splitk, hipStream_t s, int persist = 0) {
-  p.tiles_m = ((p.m_cap ? p.m_cap : p.M) + 255) / 256; p.tiles_n = (p.N + 255) / 256;      // (m_cap: the main launch of a GEMM whose tail round runs on small tiles)
+  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
   const int nk = (p.K + 63) / 64;
   if (splitk <= 0) {
     splitk = 1;
@@ -1099,23 +1099,10 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
     AVT_CHECK(aligned16(part) && part_bytes >= (size_t)nslots * N * 4, "avt_gemm_bf16: partials workspace too small or misaligned (%zu bytes needed)", (size_t)nslots * N * 4);
     p.colsum_part = part;
   }
-  // Tail round on small tiles (round 6).  The big-tile kernels run one workgroup per CU: t tiles take ceil(t / 256) rounds, and a last round that is at most
-  // half full costs a whole round (16 clips per GPU: 372 tiles of the N = 768 outputs = 1.45 rounds paid as 2; 256 clips: 23.09 as 24).  Such a GEMM is cut
-  // along M: the rows that fill whole rounds go to the big-tile kernel, the rest -- at most 128 big tiles' worth -- to 128 x 128 tiles, two workgroups per
-  // CU, in a second launch behind it (same bits: every tile route sums a row's products in the same order).  Not with column sums (their partials are
-  // laid out per kernel) or a fragment-major tensor (only the persistent kernel knows its order).
-  if (tile == 0 && bm == 8080 && epi == 0 && !colsum && !p.c2_frag && !p.aux_frag) {
-    const long tm = (M + 255) / 256, tn = (N + 255) / 256, t256 = tm * tn, full = t256 / 256, rem = t256 - full * 256;
-    const long r_main = full * 256 / tn;
-    if (full >= 1 && rem > 0 && rem <= 128 && r_main >= 1 && r_main < tm) {
-      GemmParams q = p;
-      p.m_cap = (int)r_main * 256;
-      int rc = gemm_dispatch(p, bm, epi, a_kmajor, b_kmajor, splitk, K, s);
-      if (rc) return rc;
-      q.tile_m0 = (int)r_main * 2;
-      return gemm_dispatch(q, 128, epi, a_kmajor, b_kmajor, splitk, K, s);
-    }
-  }
+  // (Round 6, measured and removed: "tail round on small tiles" -- a big-tile GEMM whose last round of 256 workgroups is at most half full cut along M, the
+  // whole rounds on the 8-phase kernel, the remaining rows on 128 x 128 tiles in a second launch.  Same bits, and slower at every batch: 16 clips per GPU
+  // 25.3 -> 26.1 ms, 256 clips 261.2 -> 262.9 ms (profiles/r06m_tail_split.txt).  The dispatcher hands a finished CU its next tile by itself, a half-empty
+  // last round runs at a higher clock, and the small-tile kernel needs about a big-tile round for those rows anyway.)
   int rc = gemm_dispatch(p, bm, epi, a_kmajor, b_kmajor, splitk, K, s);
   if (rc == 0 && nslots) { float* outs[1] = {colsum}; rc = avt_reduce_partials(part, nslots, N, outs, 1, s); }
   return rc;

@@ -36,9 +36,6 @@ struct GemmParams {
   // weight-gradient slabs (EPI 2): walk a split's tiles column-major (the output has more column tiles than row tiles), so that the contiguous
   // range of the walk an XCD owns covers few operand panels either way (accum_slab; profiles/r06h_wgrad_xcd.txt)
   int tile_cm;
-  // a GEMM cut in two launches along M (gemm.hip: gemm_impl, "tail round on small tiles"): this launch covers `m_cap` rows (0 = up to M) from row tile
-  // `tile_m0` (in units of the kernel's own BM; only the generic kernel takes a non-zero one) -- M stays the whole matrix' row count (bounds, strides)
-  int tile_m0, m_cap;
 };
 // gemm_persist.hip: the persistent form of the 8-phase kernel (one workgroup per CU walks a queue of output tiles and keeps the
 // next tile's first operand half-tiles in flight while it converts and stores the current one).  Returns 1 = launched,
@@ -366,9 +363,10 @@ __device__ __forceinline__ void epi_cols(EpiLane& e, const GemmParams& p, const 
     store_bf(p.C2 + (size_t)m * p.ldc2 + nn, v);
   }
   if (p.drop_thresh) {
+    const uint64_t ds = resolve_seed(p.drop_seed);
 #pragma unroll
     for (int k = 0; k < W; ++k)
-      v[k] = drop_keep(p.drop_seed, (uint64_t)m * (uint64_t)p.N + (uint64_t)(nn + k), p.drop_thresh) ? v[k] * p.drop_scale : 0.f;
+      v[k] = drop_keep(ds, (uint64_t)m * (uint64_t)p.N + (uint64_t)(nn + k), p.drop_thresh) ? v[k] * p.drop_scale : 0.f;
   }
   if (p.res) {
 #pragma unroll
@@ -746,11 +744,11 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
           *(u32x2_t*)(patch_d + ml * LDB + nl * 2) = (u32x2_t){pack2bf(v0[0], v0[1]), pack2bf(v1[0], v1[1])};
         }
         if (p.drop_thresh) {
-          const uint64_t idx = (uint64_t)m * (uint64_t)p.N + (uint64_t)(col0 + nl);
-          v0[0] = drop_keep(p.drop_seed, idx, p.drop_thresh) ? v0[0] * p.drop_scale : 0.f;
-          v0[1] = drop_keep(p.drop_seed, idx + 1, p.drop_thresh) ? v0[1] * p.drop_scale : 0.f;
-          v1[0] = drop_keep(p.drop_seed, idx + 2, p.drop_thresh) ? v1[0] * p.drop_scale : 0.f;
-          v1[1] = drop_keep(p.drop_seed, idx + 3, p.drop_thresh) ? v1[1] * p.drop_scale : 0.f;
+          const uint64_t idx = (uint64_t)m * (uint64_t)p.N + (uint64_t)(col0 + nl), ds = resolve_seed(p.drop_seed);
+          v0[0] = drop_keep(ds, idx, p.drop_thresh) ? v0[0] * p.drop_scale : 0.f;
+          v0[1] = drop_keep(ds, idx + 1, p.drop_thresh) ? v0[1] * p.drop_scale : 0.f;
+          v1[0] = drop_keep(ds, idx + 2, p.drop_thresh) ? v1[0] * p.drop_scale : 0.f;
+          v1[1] = drop_keep(ds, idx + 3, p.drop_thresh) ? v1[1] * p.drop_scale : 0.f;
         }
         if (ACT != 3 && has_prim) { v0 += o0; v1 += o1; }
         if (stats) { s1 += v0; s1 += v1; s2 += v0 * v0; s2 += v1 * v1; }

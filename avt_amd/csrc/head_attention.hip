@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void causal_attn_fwd_kernel(const bf16_t* __re
                                                               float* __restrict__ probs, int T, int H, int hd, float scale,
                                                               uint32_t drop_thresh, float drop_scale, uint64_t seed, int causal) {
   __shared__ float P[TMAX][TMAX + 1];
+  seed = resolve_seed(seed);
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int E = H * hd, ld = 3 * E;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void causal_attn_bwd_kernel(const bf16_t* __re
   __shared__ float P[TMAX][TMAX + 1];    // pre-dropout probabilities
   __shared__ float Pd[TMAX][TMAX + 1];   // dropped probabilities (what multiplied v)
   __shared__ float dS[TMAX][TMAX + 1];
+  seed = resolve_seed(seed);
   const int b = blockIdx.x / H, h = blockIdx.x % H;
   const int E = H * hd, ld = 3 * E;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -10,7 +10,8 @@
 namespace {
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
                                                   bf16_t* __restrict__ shadow, long n, float lr, float mom, float wd,
-                                                  float grad_scale, int nesterov, int first, int zero_grad) {
+                                                  float grad_scale, int nesterov, int first, int zero_grad, const float* __restrict__ lr_dev) {
+  if (lr_dev) lr = *lr_dev;               // captured steps: the learning rate lives in device memory, rewritten between replays (avt_sgd_step_dev)
   long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * 256 * 4;
   for (; i + 4 <= n; i += stride) {
@@ -42,14 +43,25 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
 }
 }  // namespace
 
-extern "C" int avt_sgd_step(float* param, float* grad, float* momentum_buf, void* shadow_bf16, long n, float lr, float momentum,
-                            float weight_decay, float grad_scale, int nesterov, int first_step, int zero_grad, void* stream) {
+static int sgd_launch(float* param, float* grad, float* momentum_buf, void* shadow_bf16, long n, float lr, const float* lr_dev, float momentum,
+                      float weight_decay, float grad_scale, int nesterov, int first_step, int zero_grad, void* stream) {
   AVT_CHECK(param && grad && momentum_buf && n > 0, "avt_sgd_step: null argument");
   AVT_CHECK(aligned16(param) && aligned16(grad) && aligned16(momentum_buf) && (!shadow_bf16 || (((uintptr_t)shadow_bf16) & 7) == 0),
             "avt_sgd_step: buffers must be 16-byte aligned");
   long g = (n / 4 + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
   hipLaunchKernelGGL(sgd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, param, grad, momentum_buf, (bf16_t*)shadow_bf16, n, lr,
-                     momentum, weight_decay, grad_scale, nesterov, first_step, zero_grad);
+                     momentum, weight_decay, grad_scale, nesterov, first_step, zero_grad, lr_dev);
   AVT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int avt_sgd_step(float* param, float* grad, float* momentum_buf, void* shadow_bf16, long n, float lr, float momentum,
+                            float weight_decay, float grad_scale, int nesterov, int first_step, int zero_grad, void* stream) {
+  return sgd_launch(param, grad, momentum_buf, shadow_bf16, n, lr, nullptr, momentum, weight_decay, grad_scale, nesterov, first_step, zero_grad, stream);
+}
+
+extern "C" int avt_sgd_step_dev(float* param, float* grad, float* momentum_buf, void* shadow_bf16, long n, const float* lr_dev, float momentum,
+                                float weight_decay, float grad_scale, int nesterov, int first_step, int zero_grad, void* stream) {
+  AVT_CHECK(lr_dev && (((uintptr_t)lr_dev) & 3) == 0, "avt_sgd_step_dev: lr_dev must be a device pointer to one float");
+  return sgd_launch(param, grad, momentum_buf, shadow_bf16, n, 0.f, lr_dev, momentum, weight_decay, grad_scale, nesterov, first_step, zero_grad, stream);
 }

@@ -308,11 +308,23 @@ def main(cfg, steps=10, batch_size=None, log_every=1, ckpt=None):
     if ckpt and os.path.isfile(ckpt):
         start = load_checkpoint(ckpt, model, optimizer, lr_sched)
         logging.warning('Loaded model from %s (ep %f)', ckpt, start)
+    # train.captured_step=true: the step is recorded once into a hipGraph and replayed (func/graph.py; single process, fp32 synthetic clips) -- what a
+    # launch-bound batch wants: at the reference's 3 clips per GPU (expts/01_ek100_avt.txt:5) the host otherwise needs as long to issue a step as the device to run it
+    captured = None
+    if cfg.train.get('captured_step', False) and world == 1 and gpu_tf is None and steps > 2:
+        from .graph import CapturedStep
+        captured = CapturedStep(trainer, data, warmup=2)            # (its two warm-up steps are training steps: they count)
+        steps -= 2
     for it in range(steps):
         t0 = time.time()
         if gpu_tf is not None:
             data['video'] = gpu_tf(clips_u8)
-        loss, _, _, accs = trainer.step(data, sync_loss=True)
+        if captured is not None:
+            loss = float(captured.step(data)[0])
+            if not (loss == loss):
+                raise ValueError('Overall loss is NaN')
+        else:
+            loss, _, _, accs = trainer.step(data, sync_loss=True)
         dt = time.time() - t0
         if rank == 0 and it % log_every == 0:
             logging.info('iter %d loss %.4f clips/s %.1f lr %.3g', it, loss, B * world / dt, optimizer.param_groups[0]['lr'])

@@ -9,7 +9,7 @@ from ctypes import c_char_p, c_float, c_int, c_long, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AVT_HIP_LIB') or os.path.join(_HERE, 'libavt_hip.so')      # AVT_HIP_LIB: A/B a differently built library (lab use)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _P, _I, _F, _L, _U64, _SZ = c_void_p, c_int, c_float, c_long, c_uint64, ctypes.c_size_t
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     'avt_xent_bwd': [_P, _I, _P, _P, _P, _P, _I, _I, _I, _L, _P],
     'avt_gemm_frag_ok': [_I, _I, _I],              # (returns 1 / 0, not an error code: called through load(), not call())
     'avt_sgd_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _I, _I, _P],
+    'avt_sgd_step_dev': [_P, _P, _P, _P, _L, _P, _F, _F, _F, _I, _I, _I, _P],        # (ABI 9: the learning rate in device memory, for captured steps)
     'avt_linear_softmax_xent_fwd': [_P, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _L, _P],
     # gradient exchange over RCCL (ABI 8): comm handles are void*, sizes size_t
     'avt_comm_unique_id': [_P],

@@ -22,14 +22,20 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .. import seeds as _seeds
 from ..arena import get_arena
 
 _seed_counter = itertools.count(1)
 
 
-def fresh_seed():
-    """Seed of one dropout application: mixes the process's torch seed with a call counter (a seeded run repeats)."""
+def _draw_seed():
     return (next(_seed_counter) * 2000003 + 7919 * torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+
+
+def fresh_seed():
+    """Seed of one dropout application: mixes the process's torch seed with a call counter (a seeded run repeats).  Inside a captured step
+    (avt_amd/seeds.py) an indirect seed whose device slot is refilled from the same counter before every replay."""
+    return _seeds.fresh(_draw_seed)
 
 
 class _DropFn(torch.autograd.Function):

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from .. import seeds as _seeds
 from ..arena import get_arena
 from ..config import instantiate
 
@@ -86,6 +87,10 @@ class _GPT2(nn.Module):
 class AVTh(nn.Module):
     _seed_counter = itertools.count(1)
 
+    @staticmethod
+    def _draw_seed():
+        return (next(AVTh._seed_counter) * 1000003 + torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+
     def __init__(self, in_features: int, output_len: int = -1, output_len_eval: int = -1, avg_last_n: int = -1,
                  inter_dim: int = 768, future_pred_loss=None, return_past_too: bool = False, drop_last_n: int = 0,
                  quantize_before_rollout: bool = False, assign_to_centroids: str = None,
@@ -134,7 +139,7 @@ class AVTh(nn.Module):
         keep = torch.is_grad_enabled()
         # dropout masks are a pure function of (seed, element index): the seed mixes the process's torch seed (torch.manual_seed)
         # with a call counter, so a seeded run repeats and differently seeded runs differ
-        seed = ((next(AVTh._seed_counter) * 1000003 + torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF) if self.training else 0
+        seed = _seeds.fresh(AVTh._draw_seed) if self.training else 0          # (an indirect seed inside a captured step: avt_amd/seeds.py)
         dec, last = _HeadFn.apply(self, arena, keep, self.training, seed, feats, self.encoder.weight, extra, group or _NodeGroup(1))
         return dec if (extra is None and group is None) else (dec, last)
 

@@ -113,13 +113,15 @@ class Transformer(nn.Module):
         arena.refresh_shadow()
         if torch.is_grad_enabled():
             arena.attach_grads()
-        seed = ((next(Transformer._seed_counter) * 1000033 + torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF) if self.training else 0
+        seed = _seeds.fresh(Transformer._draw_seed) if self.training else 0
         enc = _TxFn.apply(self, arena, torch.is_grad_enabled(), self.training, seed, feats, self.downproject.weight)
         return (enc.mean(dim=1) if self.agg_style == 'mean' else enc[:, -1]), {}
 
 
 import itertools as _it          # noqa: E402
 Transformer._seed_counter = _it.count(1)
+Transformer._draw_seed = staticmethod(lambda: (next(Transformer._seed_counter) * 1000033 + torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF)
+from .. import seeds as _seeds   # noqa: E402
 
 
 def _tx_forward(m, arena, feats, keep, training, seed):

@@ -44,19 +44,7 @@ def persist_epilogue_kind(out_mode, act, has_bias, has_res, has_aux, has_c2, has
     return None
 
 
-def gemm_tail_split(M, N, epi=0, ok=True):
-    """Mirror of gemm_impl's 'tail round on small tiles' (csrc/gemm.hip): (big tiles of the main launch, rows of the main launch | None when the GEMM is
-    one launch).  ``ok``: no column sums and no fragment-major tensor in the call."""
-    tm, tn = (M + 255) // 256, (N + 255) // 256
-    t256 = tm * tn
-    full, rem = divmod(t256, 256)
-    r_main = full * 256 // tn
-    if ok and epi == 0 and full >= 1 and 0 < rem <= 128 and 1 <= r_main < tm:
-        return r_main * tn, r_main * 256
-    return t256, None
-
-
-def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False, split_ok=True):
+def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False):
     """Mirror of the tile choice in avt_gemm_bf16 (csrc/gemm.hip): names the kernel template a call lands on.
     ``epilogue_ok``: False / None = the persistent kernel does not cover the epilogue; True or an int = it does (an int names the kind)."""
     epk = None if (epilogue_ok is False or epilogue_ok is None) else (epilogue_ok if type(epilogue_ok) is int else -1)
@@ -79,7 +67,7 @@ def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False,
             bm = 256 if (t256 * sk >= 256 and t256 < 4096) else 128
         if bm == 256 and (K % 64 == 0 or (not a_kmajor and not b_kmajor)):
             bm = 808
-            t256 = gemm_tail_split(M, N, epi, split_ok)[0]      # (the tiles of the main launch when the tail round goes to small tiles)
+            t256 = ((M + 255) // 256) * ((N + 255) // 256)
             if (epi == 0 and a_kmajor and b_kmajor and epilogue_ok and N % 256 == 0 and K % 128 == 0 and 256 <= K <= PERSIST_KMAX
                     and 512 <= t256 < 65536):
                 bm = 809          # the persistent form (csrc/gemm_persist.hip: avt_gemm_persist)
@@ -204,7 +192,7 @@ def gemm(A, B, M, N, K, *, a_kmajor=True, b_kmajor=True, out=None, out_mode=OUT_
             ep_ok = {0: 5, 1: 6}.get(ep_ok) if ln_c is not None else ({3: 7}.get(ep_ok) if ln_stat is not None else ({2: 4}.get(ep_ok) if N % 64 == 0 else None))
         if c2_frag or aux_frag:               # the fragment-major forms: 8 / 9 = 1 / 6 writing it, 10 / 11 = 3 / 7 reading it
             ep_ok = {1: 8, 6: 9, 3: 10, 7: 11}.get(ep_ok)
-        trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, ep_ok, colsum is None and not c2_frag and not aux_frag), 2.0 * M * N * K, ev0, ev1, (M, N, K)))
+        trace.append((gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, ep_ok), 2.0 * M * N * K, ev0, ev1, (M, N, K)))
     return out
 
 
@@ -663,5 +651,11 @@ def linear_softmax_xent_bwd(logits, target, lse, gloss, x, w, C, dw=None, dbias=
 
 # ---- optimizer -------------------------------------------------------------------------------------------------------------
 def sgd_step(param, grad, buf, shadow, lr, momentum, weight_decay, grad_scale=1.0, nesterov=True, first_step=False, zero_grad=True):
+    """``lr``: a float, or a one-element fp32 device tensor (avt_sgd_step_dev: the rate of a captured step, rewritten between replays)."""
+    if torch.is_tensor(lr):
+        _chk(lr, torch.float32, 'lr')
+        _lib.call('avt_sgd_step_dev', _p(param), _p(grad), _p(buf), _p(shadow), param.numel(), _p(lr), float(momentum),
+                  float(weight_decay), float(grad_scale), int(nesterov), int(first_step), int(zero_grad), _stream())
+        return
     _lib.call('avt_sgd_step', _p(param), _p(grad), _p(buf), _p(shadow), param.numel(), float(lr), float(momentum),
               float(weight_decay), float(grad_scale), int(nesterov), int(first_step), int(zero_grad), _stream())

@@ -37,6 +37,7 @@ class FusedSGD:
         self._ranges = None
         self._uncovered = []
         self._early_lo = arena.total     # this step's update has already been applied to [_early_lo, total) (step_suffix)
+        self.lr_dev = None               # captured steps (func/graph.py): fp32 device tensor, slot i = the learning rate of param_groups[i]
 
     def _build_ranges(self):
         """[(start, end, group_index)] covering each group's parameters as maximal contiguous arena ranges."""
@@ -86,7 +87,7 @@ class FusedSGD:
                     break
             s, e = max(s, lo), min(e, hi)
             if s < e:
-                ops.sgd_step(a.master[s:e], a.grad[s:e], self.momentum_buf[s:e], a.shadow[s:e], g['lr'], g['momentum'],
+                ops.sgd_step(a.master[s:e], a.grad[s:e], self.momentum_buf[s:e], a.shadow[s:e], g['lr'] if self.lr_dev is None else self.lr_dev[gi:gi + 1], g['momentum'],
                              g['weight_decay'], grad_scale=self.grad_scale, nesterov=bool(g['nesterov']),
                              first_step=(self.steps == 0), zero_grad=True)
             i = j

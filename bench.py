@@ -203,6 +203,7 @@ def main(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-gemm-trace', action='store_true')
     ap.add_argument('--trace-steps', type=int, default=5, help='steps of the second, untimed-for-the-headline run that records a HIP-event pair around every GEMM launch (roofline.dominant_kernel)')
+    ap.add_argument('--graph', action='store_true', help='replay the step from a hipGraph (avt_amd/func/graph.py::CapturedStep: device-resident dropout seeds and learning rates; single process only) -- what a launch-bound small batch wants; the default line stays eager')
     ap.add_argument('--no-also', action='store_true', help='skip the short T = 15 / ViT-L runs that the default N = 1 line carries in "also"')
     ap.add_argument('--tail-mb', type=int, default=-1, help='the last (exposed) exchange is at most this many MiB of gradients (default: half a bucket)')
     ap.add_argument('--nccl-max-nchannels', type=int, default=0, help='export NCCL_MAX_NCHANNELS before RCCL starts: fewer channels = fewer CUs taken from the GEMMs (0 = leave the environment alone)')
@@ -236,8 +237,12 @@ def main(argv=None):
     def measure(a, steps, warmup, probe_no_comm=False):
         """Build the model of configuration ``a``, run ``warmup`` untimed and ``steps`` timed steps; returns the raw numbers."""
         trainer, data = build(a, device, world)
+        step = trainer.step
+        if getattr(a, 'graph', False) and trainer.reducer is None:
+            from avt_amd.func.graph import CapturedStep
+            step = CapturedStep(trainer, data).step          # (two eager steps on the capturing stream, then the recording)
         for _ in range(warmup):
-            trainer.step(data)
+            step(data)
         sync()
         no_comm = None
         if probe_no_comm and trainer.reducer is not None and not a.no_gemm_trace:
@@ -258,7 +263,7 @@ def main(argv=None):
         calls0 = _abi.N_CALLS
         t0 = time.perf_counter()
         for _ in range(steps):
-            loss, _, _, _ = trainer.step(data)
+            loss, _, _, _ = step(data)
         host_enqueue = time.perf_counter() - t0          # the Python side is done enqueuing; the GPU may still be running
         sync()
         elapsed_local = time.perf_counter() - t0
@@ -399,7 +404,8 @@ def main(argv=None):
                'config': {'workload': f'{args.model} + AVT-h(2048x6x4) fwd+bwd+SGD-nesterov, T={args.frames} x 224^2, C={NUM_CLASSES}, '
                                       f'{args.batch} clips/GPU, dropout 0.1/0.2 on, fp32 master weights / bf16 MFMA',
                           'clips_per_gpu': args.batch, 'global_batch': args.batch * world, 'frames': args.frames,
-                          'parallelism': f'dp{world}', 'gflop_per_clip': round(fclip / 1e9, 2), 'final_loss': round(loss_val, 4)},
+                          'parallelism': f'dp{world}', 'gflop_per_clip': round(fclip / 1e9, 2), 'final_loss': round(loss_val, 4),
+                          'launch': 'hipGraph replay (avt_amd/func/graph.py: device-resident dropout seeds and learning rates)' if (args.graph and world == 1) else 'eager'},
                'per_rank_clips_per_s': [round(args.batch * args.steps / float(x), 2) for x in per_rank],
                'host': {'abi_calls_per_step': round(abi_calls / args.steps, 1), 'enqueue_ms_per_step': round(host_enqueue / args.steps * 1e3, 2),
                         'note': 'rank 0: C-ABI calls (1-2 kernel launches each) and Python time to enqueue one step; enqueue >= ms_per_step means the step is host-bound'},
@@ -423,7 +429,10 @@ def main(argv=None):
                           ('config 2 at a quarter of the clips: ViT-B/16 + AVT-h, T = 10', dict(batch=max(1, args.batch // 4))),
                           # ... and at the batch the reference itself trains with (expts/01_ek100_avt.txt:5: 3 clips per GPU) -- weight-sized work (SGD, weight-gradient
                           # slabs, the head's weights) is most of that step
-                          ('config 2 at the reference\'s own batch: ViT-B/16 + AVT-h, T = 10', dict(batch=3))):
+                          ('config 2 at the reference\'s own batch: ViT-B/16 + AVT-h, T = 10', dict(batch=3)),
+                          # ... and that step replayed from a hipGraph (round 6, ABI 9: device-resident dropout seeds and learning rates): at 3 clips the host needs
+                          # about as long to issue the ~640 launches as the device to run them
+                          ('config 2 at the reference\'s own batch, the step replayed from a hipGraph: ViT-B/16 + AVT-h, T = 10', dict(batch=3, graph=True, no_gemm_trace=True))):
             a2 = argparse.Namespace(**{**vars(args), **kw})
             st2, wu2 = (20, 5) if a2.batch <= 8 and a2.batch < args.batch else (5, 2)      # (a 14-ms step needs more of them to leave its warm-up behind)
             try:
@@ -438,7 +447,8 @@ def main(argv=None):
             r2 = roofline_of(a2, c2, m2['trace'], max(m2['trace_steps'], 1), m2['trace_elapsed'] / max(m2['trace_steps'], 1) if m2['trace'] else m2['elapsed_local'] / st2)
             entry = {'config': f'{label}, {a2.batch} clips/GPU', 'model': a2.model, 'frames': a2.frames, 'clips_per_gpu': a2.batch,
                      'value': round(c2, 2), 'unit': 'clips/s', 'ms_per_step': round(m2['elapsed_local'] / st2 * 1e3, 3), 'steps': st2, 'warmup': wu2,
-                     'frac': r2['frac'], 'executed_frac': r2['executed_frac'], 'final_loss': round(m2['loss'], 4)}
+                     'frac': r2['frac'], 'executed_frac': r2['executed_frac'], 'final_loss': round(m2['loss'], 4),
+                     'launch': 'hipGraph replay' if getattr(a2, 'graph', False) else 'eager', 'host_enqueue_ms_per_step': round(m2['host_enqueue'] / st2 * 1e3, 2)}
             if 'gemm_family' in r2:
                 entry['gemm_family_frac'] = r2['gemm_family']['frac']
             if 'worst_large_gemm_row' in r2:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AVT_ABI_VERSION 8
+#define AVT_ABI_VERSION 9
 
 const char* avt_last_error(void);
 int avt_abi_version(void);
@@ -304,6 +304,20 @@ int avt_linear_softmax_xent_bwd(const float* logits, int ldl, const long* target
  * Also writes the bf16 shadow (may be NULL) and re-zeroes grad when zero_grad != 0. */
 int avt_sgd_step(float* param, float* grad, float* momentum_buf, void* shadow_bf16, long n, float lr, float momentum,
                  float weight_decay, float grad_scale, int nesterov, int first_step, int zero_grad, void* stream);
+
+/* ---- captured steps (ABI 9) ---------------------------------------------------------------------------------------------
+ * The reference's train_one_epoch body (func/train.py:203-239) is ~640 kernel launches at its own 3 clips per GPU, and the host needs as long to issue
+ * them as the device to run them.  Every entry point here enqueues on the caller's stream and none allocates or synchronises, so the whole step can be
+ * recorded once into a hipGraph (stream capture) and replayed -- provided the two kinds of scalars that change from step to step do not sit in the
+ * launches' arguments:
+ *   * dropout seeds: every `seed` / `drop_seed` / `dx_drop_seed` argument of this header may be INDIRECT -- bit 63 set, bits 0..47 = the device address
+ *     of a uint64 holding a base seed, bits 48..62 = an offset added to it (the modules derive a layer's seeds as base + small constants).  The host
+ *     rewrites the base seed between replays.  Plain seeds must keep bit 63 clear;
+ *   * the learning rate: avt_sgd_step_dev = avt_sgd_step with the rate read from device memory (lr_dev: one float, 4-byte aligned).
+ * avt_amd/func/graph.py::CapturedStep does exactly that on top of torch.cuda.CUDAGraph; its replays equal the eager steps bit for bit.
+ * Warm the library up on the capturing stream first (the persistent GEMM's ticket block of a new stream is allocated at its first launch). */
+int avt_sgd_step_dev(float* param, float* grad, float* momentum_buf, void* shadow_bf16, long n, const float* lr_dev, float momentum,
+                     float weight_decay, float grad_scale, int nesterov, int first_step, int zero_grad, void* stream);
 
 /* ---- gradient exchange over RCCL (ABI 8) ------------------------------------------------------------------------------
  * What the reference gets from torch.nn.parallel.DistributedDataParallel(model, device_ids=[gpu]) (func/train.py:771-778) after

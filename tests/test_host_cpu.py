@@ -481,3 +481,40 @@ def test_bench_gemm_family_filter_catches_every_large_tile_kernel_the_router_can
     assert {'gemm_8pp_kernel', 'gemm_8p_kernel', 'gemm_kernel'} <= seen
     for tile in (64, 643):
         assert not ops.gemm_variant(3940, 768, 768, True, True, ops.OUT_BF16, tile, None).startswith(big)
+
+
+def test_indirect_seed_packing_and_capture_slots():
+    """ABI 9 (include/avt_hip.h "captured steps"): an indirect seed = bit 63 | offset << 48 | device address of the base seed; `+` adds to the offset, the
+    way the modules derive a layer's seeds from the forward's base seed; inside a capture every fresh() takes the next slot and draw() refills the slots
+    from the generators, in order (here on CPU memory: the packing is address arithmetic)."""
+    import itertools
+    import torch
+    from avt_amd import seeds
+    d = seeds.DevSeed(0x7f12_3456_7890)
+    s = d + 16 * 3 + 2
+    v = int(s)
+    assert v >> 63 == 1 and (v >> 48) & 0x7FFF == 50 and v & ((1 << 48) - 1) == 0x7f12_3456_7890 and int(d + 0) == (1 << 63) | 0x7f12_3456_7890
+    assert int(2 + d) == int(d + 2)
+    with pytest.raises(AssertionError):
+        int(d + (1 << 15))
+    c1, c2 = itertools.count(1), itertools.count(100)
+    g1, g2 = (lambda: next(c1) * 1000003), (lambda: (next(c2) * 7) & 0x7FFFFFFFFFFFFFFF)
+    assert seeds.fresh(g1) == 1000003                      # eager: the value itself
+    cap = seeds.SeedCapture(torch.device('cpu'), max_slots=4)
+    with seeds.capturing(cap):
+        a, b = seeds.fresh(g1), seeds.fresh(g2)
+        assert isinstance(a, seeds.DevSeed) and b.ptr == a.ptr + 8 and a.ptr == cap.dev.data_ptr()
+    assert seeds._capture is None and seeds.fresh(g2) == 700 and next(c1) == 2          # recording drew nothing from g1
+    cap.draw()
+    assert cap.dev[:2].tolist() == [3 * 1000003, 101 * 7]
+    cap.draw()
+    assert cap.dev[:2].tolist() == [4 * 1000003, 102 * 7]
+
+
+def test_skinny_routing_mirror():
+    """ops.gemm_variant restates gemm_impl's round-6 routing: at most 32 rows of k-major A rows go to the skinny kernel."""
+    from avt_amd import ops
+    assert ops.gemm_variant(30, 2048, 8192, True, True, ops.OUT_BF16, 0) == 'gemm_skinny_kernel<1>'
+    assert ops.gemm_variant(30, 2048, 8192, True, False, ops.OUT_BF16, 0) == 'gemm_skinny_kernel<0>'
+    assert ops.gemm_variant(33, 2048, 8192, True, True, ops.OUT_BF16, 0).startswith('gemm_kernel<64,64,2,2,64,3')
+    assert 'skinny' not in ops.gemm_variant(30, 2048, 8192, False, False, ops.OUT_ACCUM_F32, 0)                    # weight gradients: not this kernel

@@ -835,6 +835,71 @@ def test_reference_loop_order_with_a_torch_optimizer_trains():
         assert rel(states['torch'][n], states['fused'][n]) < 1e-3, n
 
 
+def test_captured_step_equals_the_eager_steps():
+    """Round 6 (ABI 9): a training step recorded into a hipGraph and replayed (avt_amd/func/graph.py::CapturedStep) -- dropout ON, so the masks must be
+    fresh at every replay (indirect seeds: avt_amd/seeds.py, csrc/common.hpp resolve_seed), a learning rate that changes every step (avt_sgd_step_dev),
+    a different batch every step.  Against the same six steps issued eagerly from the same initial state and seed counters: every loss, every parameter
+    and the momentum buffer equal bit for bit."""
+    import itertools
+    from avt_amd.config import Cfg
+    from avt_amd.func.graph import CapturedStep
+    from avt_amd.func.train import Trainer
+    from avt_amd.func.train_eval_ops import Basic
+    from avt_amd.models import classifiers
+    from avt_amd.models.future_prediction import AVTh
+    from avt_amd.optim import FusedSGD
+    g = torch.Generator().manual_seed(9)
+    batches = []
+    for _ in range(6):
+        batches.append({'video': (torch.rand((3, 4, 3, 1, 32, 32), generator=g) * 2 - 1).cuda(), 'target': {'action': torch.randint(0, 17, (3,), generator=g).cuda()},
+                        'target_subclips': {'action': torch.randint(-1, 17, (3, 4, 1), generator=g).cuda()}})
+    order = [0, 0, 2, 3, 4, 5]                    # CapturedStep's two warm-up steps run on the batch it is given
+
+    class Decay:                                   # a scheduler in the reference's sense: stepped once per iteration, rewrites param_groups[i]['lr']
+        def __init__(self, opt): self.opt = opt
+        def step(self):
+            for grp in self.opt.param_groups: grp['lr'] *= 0.9
+
+    def run(captured):
+        torch.manual_seed(0)
+        classifiers._seed_counter = itertools.count(1)
+        AVTh._seed_counter = itertools.count(1)
+        model = build_hip_model('vit', 128, 64, 2, 4, 17, vit=(128, 2, 2, 32), dropout=0.2, head_drop=0.1)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.ndim >= 2:
+                    p.normal_(0, 0.1)
+        model.train()
+        assert model.dropout.p > 0 and model.future_predictor.resid_pdrop > 0
+        opt = FusedSGD([{'params': [p for n, p in model.named_parameters() if not n.endswith('bias')], 'lr': 0.05, 'weight_decay': 1e-4},
+                        {'params': [p for n, p in model.named_parameters() if n.endswith('bias')], 'lr': 0.02, 'weight_decay': 0.0}],
+                       lr=0.05, momentum=0.9, nesterov=True, arena=model.arena)
+        op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
+        tr = Trainer(model, op, opt, Decay(opt), LOSS_WTS)
+        losses = []
+        if captured:
+            cap = CapturedStep(tr, batches[0], warmup=2)
+            assert len(cap.seeds.gens) >= 2 and opt.steps == 2
+            for k in order[2:]:
+                losses.append(cap.step(batches[k])[0].detach().clone())
+            assert cap.replays == 4 and opt.steps == 6
+        else:
+            for k in order:
+                losses.append(tr.step(batches[k])[0].detach().clone())
+            losses = losses[2:]
+        torch.cuda.synchronize()
+        return [float(x) for x in losses], {n: p.detach().clone() for n, p in model.named_parameters()}, opt.momentum_buf.clone(), [grp['lr'] for grp in opt.param_groups]
+
+    le, pe, me, lre = run(False)
+    lc, pc, mc, lrc = run(True)
+    assert le == lc, (le, lc)
+    assert len(set(le)) == 4                       # (different batches and masks: the steps really differ)
+    assert lre == lrc
+    for n in pe:
+        assert torch.equal(pe[n], pc[n]), n
+    assert torch.equal(me, mc)
+
+
 def test_grad_clip_and_frozen_groups():
     """opt.grad_clip.max_norm (func/train.py:224-231) and zero-LR groups (func/train.py:735-742) are honoured."""
     from avt_amd.config import Cfg
@@ -883,6 +948,14 @@ def test_train_net_entry_runs_the_composed_experiment(tmp_path):
     assert len([l for l in r.stdout.splitlines() if l.startswith('iter ')]) == 2, r.stdout[-2000:]
     # ... by default as patch rows straight from the input kernel: no fp32 frames, no im2col pass (round 6); synthetic.emit_patches=false keeps the tensor
     assert 'abi calls: avt_im2col_patch16 0 ' in r.stdout and 'avt_video_preproc_u8 2' in r.stdout, r.stdout[-2000:]
+    # ... and with the step replayed from a hipGraph (round 6: train.captured_step=true): two eager steps on the capturing stream, then three replays
+    r = subprocess.run([sys.executable, os.path.join(root, 'train_net.py'), '-c', os.path.join(root, 'expts', '01_ek100_avt.txt'),
+                        '--steps', '5', '--batch', '2', 'train.captured_step=true'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('iter ')]
+    assert len(lines) == 3, r.stdout[-2000:]
+    losses = [float(l.split('loss ')[1].split()[0]) for l in lines]
+    assert all(l == l and 0 < l < 100 for l in losses) and len(set(losses)) == 3, losses
 
 
 def test_model_on_patch_rows_equals_model_on_the_fp32_clip():

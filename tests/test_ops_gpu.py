@@ -55,41 +55,6 @@ def test_gemm_plain(ops, M, N, K, layout):
         assert relerr(o2, ref) < 1e-2, (tile, relerr(o2, ref))
 
 
-@pytest.mark.parametrize('M,N,K', [(16 * 1970, 768, 768), (16 * 1970, 768, 3072), (16 * 1970 + 77, 768, 2304), (67000, 1024, 256), (12 * 1970, 768, 768)])
-def test_tail_round_on_small_tiles_same_bits(ops, M, N, K):
-    """Round 6: a big-tile GEMM whose last round of 256 workgroups would be at most half full is cut along M -- whole rounds on the 8-phase kernel, the
-    remaining rows on 128 x 128 tiles in a second launch (csrc/gemm.hip: gemm_impl).  The automatic choice (tile 0) takes that route for these shapes
-    (16 clips per GPU: 372 tiles = 1.45 rounds) and gives the one-launch kernel's (tile 808) bits, for every epilogue that can take it -- plain, bias +
-    residual, erf-GELU + derivative, the LayerNorm-fold modes and the row statistics; with column sums the GEMM stays one launch."""
-    main_tiles, main_rows = ops.gemm_tail_split(M, N)
-    assert main_rows is not None and main_rows % 256 == 0 and 0 < M - main_rows and main_tiles % ((N + 255) // 256) == 0 and main_tiles <= (main_tiles // 256 + 1) * 256
-    assert ops.gemm_tail_split(M, N, ok=False) == (((M + 255) // 256) * ((N + 255) // 256), None)
-    a, b = rnd((M, K), 0.5, 1), rnd((N, K), 0.05, 2)
-    bias = rnd((N,), 0.5, 3, torch.float32)
-    res = rnd((M, N), 1.0, 4)
-    sf = torch.stack([torch.rand(M, device='cuda') + 0.5, torch.randn(M, device='cuda') * 0.1], 1).contiguous()
-    c = rnd((N,), 0.5, 5, torch.float32)
-    calls = [dict(), dict(bias=bias, res=res), dict(bias=bias, act=ops.ACT_GELU_ERF, c2=True), dict(bias=bias, ln_stat=sf, ln_c=c),
-             dict(bias=bias, res=res, stat_part=True), dict(bias=bias, res=res, drop_p=0.1, seed=77)]
-    for call in calls:
-        outs = []
-        for tile in (0, 808):
-            kw = dict(call)
-            c2 = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16) if kw.pop('c2', False) else None
-            sp = ops.ln_stat_part(M, N, a.device).fill_(float('nan')) if kw.pop('stat_part', False) else None
-            full = torch.full((M + 64, N), 7.0, device='cuda', dtype=torch.bfloat16)
-            ops.gemm(a, b, M, N, K, out=full[:M], c2=c2, stat_part=sp, tile=tile, **kw)
-            torch.cuda.synchronize()
-            assert float(full[M:].float().abs().max()) == 7.0                     # nothing written past M
-            outs.append((full[:M].clone(), c2, sp))
-        for x, y in zip(outs[0], outs[1]):
-            assert (x is None) == (y is None)
-            if x is not None:
-                assert not torch.isnan(x.float()).any() and torch.equal(x, y), call.keys()
-    ref = a.float() @ b.float().t()
-    assert relerr(ops.gemm(a, b, M, N, K, out_mode=ops.OUT_F32), ref) < 2e-3
-
-
 @pytest.mark.parametrize('M,N,K', [(30, 2048, 8192), (30, 8192, 2048), (30, 6144, 2048), (30, 2048, 2048), (20, 768, 768), (32, 3072, 768), (10, 776, 3080),
                                    (1, 64, 64), (30, 2304, 768), (7, 40, 72)])
 @pytest.mark.parametrize('layout', ['NT', 'NN'])
