@@ -326,7 +326,7 @@ int dispatch_skinny(GemmParams& p, int a_kmajor, int b_kmajor, hipStream_t s) {
 // element has exactly one owner, so plain read-modify-write; C keeps the running sum of earlier GEMMs into the same gradient).
 template <int TM, int TN, int WGM, int WGN>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int ldc, int M, int N,
-                                                            int tiles_n, int ntile, int splitk) {
+                                                            int tiles_n, int ntile, int splitk, int assign) {
   constexpr int NW = WGM * WGN, WM = TM * 32, WN = TN * 32, BM = WM * WGM, BN = WN * WGN;
   constexpr int CHUNKS = NW * TM * TN * 4;                 // 1-KB chunks per tile
   const int lane = threadIdx.x & 63;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   if (n < N) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (m0 + k < M) C[(size_t)(m0 + k) * ldc + n] += v[k];
+      if (m0 + k < M) { if (assign) C[(size_t)(m0 + k) * ldc + n] = v[k]; else C[(size_t)(m0 + k) * ldc + n] += v[k]; }
   }
 }
 template <int TM, int TN, int WGM, int WGN>
@@ -360,7 +360,7 @@ int launch_reduce(const GemmParams& p, hipStream_t s) {
   const int ntile = p.tiles_m * p.tiles_n;
   constexpr int CHUNKS = WGM * WGN * TM * TN * 4;
   hipLaunchKernelGGL((splitk_reduce_kernel<TM, TN, WGM, WGN>), dim3((ntile * CHUNKS + 3) / 4), dim3(256), 0, s, (const float*)p.ws, (float*)p.C, p.ldc,
-                     p.M, p.N, p.tiles_n, ntile, p.splitk);
+                     p.M, p.N, p.tiles_n, ntile, p.splitk, p.c_assign);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { avt_set_error("avt_gemm: reduce launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
@@ -800,7 +800,7 @@ __device__ __forceinline__ void w4_frag_put(bf16x8_t (&af)[4], bf16x8_t (&bf)[4]
   if constexpr (F == 0) af[0] = v; else if constexpr (F <= 4) bf[F - 1] = v; else af[F - 4] = v;
 }
 // (cache policy of the two operand streams: default on both -- nt on the dY stream / the x stream / both measured 0 / -0.7 / -0.9 % on the step, profiles/r05e_w4_cache_policy.txt)
-template <int EPI, bool DIRECT = false>
+template <int EPI, int DIRECT = 0>
 __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
   static_assert(EPI == 2, "4-wave weight-gradient kernel: split-K slab epilogue only");
   constexpr int BM = 256, BN = 256, BK = 32, NST = 5, WM = 128, WN = 128, TM = 4, TN = 4;
@@ -974,7 +974,7 @@ __global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
 #undef W4_STEP
 #undef W4_RDF
 #undef W4_PIN
-  gemm_epilogue<TM, TN, WM, WN, EPI, 0, false, false, DIRECT ? 1 : 0>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
+  gemm_epilogue<TM, TN, WM, WN, EPI, 0, false, false, DIRECT>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
 }
 
 int dispatch_w4(GemmParams& p, int a_kmajor, int b_kmajor, int splitk, hipStream_t s) {
@@ -989,12 +989,14 @@ int dispatch_w4(GemmParams& p, int a_kmajor, int b_kmajor, int splitk, hipStream
   constexpr int smem = 5 * 2 * 32 * 512;               // 160 KB
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_w4_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  if (splitk == 1) hipLaunchKernelGGL((gemm_w4_kernel<2, true>), dim3(p.tiles_m * p.tiles_n), dim3(256), smem, s, p);      // adds its tiles into C itself
-  else hipLaunchKernelGGL((gemm_w4_kernel<2, false>), dim3(p.tiles_m * p.tiles_n * splitk), dim3(256), smem, s, p);
+  if (splitk == 1 && p.c_assign) hipLaunchKernelGGL((gemm_w4_kernel<2, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), smem, s, p);      // writes its tiles into C itself
+  else if (splitk == 1) hipLaunchKernelGGL((gemm_w4_kernel<2, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), smem, s, p);             // adds its tiles into C itself
+  else hipLaunchKernelGGL((gemm_w4_kernel<2, 0>), dim3(p.tiles_m * p.tiles_n * splitk), dim3(256), smem, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return splitk == 1 ? 0 : launch_reduce<4, 4, 2, 2>(p, s);            // (splitk == 1: the kernel added its tiles into C itself)
@@ -1009,7 +1011,7 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
                      void* C2, int ldc2, const void* res, int ldres, int res_period,
                      float drop_p, uint64_t drop_seed, float* colsum,
                      int out_mode, int splitk, int tile, void* ws, size_t ws_bytes, float* part, size_t part_bytes, void* stream,
-                     const float* ln_stat = nullptr, const float* ln_c = nullptr, float* stat_part = nullptr) {
+                     const float* ln_stat = nullptr, const float* ln_c = nullptr, float* stat_part = nullptr, int c_assign = 0) {
   AVT_CHECK(A && B && C, "avt_gemm_bf16: null operand");
   AVT_CHECK(M > 0 && N > 0 && K > 0, "avt_gemm_bf16: bad dims M=%d N=%d K=%d", M, N, K);
   AVT_CHECK(aligned16(A) && aligned16(B) && aligned16(C), "avt_gemm_bf16: operands must be 16-byte aligned");
@@ -1028,6 +1030,7 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
   p.res_period = res_period; p.act = act; p.out_f32 = (out_mode == 1);
   p.drop_thresh = drop_threshold(drop_p); p.drop_scale = 1.0f / (1.0f - drop_p); p.drop_seed = drop_seed;
   p.ln_stat = ln_stat; p.ln_c = ln_c; p.stat_part = stat_part;
+  p.c_assign = (c_assign && out_mode == 3) ? 1 : 0;
   // ldc2 == 0 / ldaux == 0: the fragment-major private layout of the persistent kernel (include/avt_hip.h, gemm_persist.hip)
   p.c2_frag = (C2 && ldc2 == 0) ? 1 : 0; p.aux_frag = (aux && ldaux == 0) ? 1 : 0;
   if (p.c2_frag || p.aux_frag) {
@@ -1172,6 +1175,12 @@ extern "C" int avt_gemm_accum_bf16(const void* A, int lda, const void* B, int ld
                                    int splitk, int tile, void* workspace, size_t workspace_bytes, void* stream) {
   return gemm_impl(A, 0, lda, B, 0, ldb, C, ldc, M, N, K, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, nullptr,
                    3, splitk, tile, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+extern "C" int avt_gemm_assign_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                                    int splitk, int tile, void* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_impl(A, 0, lda, B, 0, ldb, C, ldc, M, N, K, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0.f, 0, nullptr,
+                   3, splitk, tile, workspace, workspace_bytes, nullptr, 0, stream, nullptr, nullptr, nullptr, 1);
 }
 
 extern "C" size_t avt_gemm_accum_workspace_bytes(int M, int N, int K) {

@@ -36,6 +36,9 @@ struct GemmParams {
   // weight-gradient slabs (EPI 2): walk a split's tiles column-major (the output has more column tiles than row tiles), so that the contiguous
   // range of the walk an XCD owns covers few operand panels either way (accum_slab; profiles/r06h_wgrad_xcd.txt)
   int tile_cm;
+  // EPI 2 (deterministic weight gradients): C = result instead of C += result (avt_gemm_assign_bf16: the caller knows C holds zeros -- the fused optimizer
+  // has just re-zeroed the gradient buffer -- so reading it back is 4 bytes per weight for nothing)
+  int c_assign;
 };
 // gemm_persist.hip: the persistent form of the 8-phase kernel (one workgroup per CU walks a queue of output tiles and keeps the
 // next tile's first operand half-tiles in flight while it converts and stores the current one).  Returns 1 = launched,
@@ -804,7 +807,7 @@ __device__ __forceinline__ void epi_fast_ext(const GemmParams& p, const f32x16_t
 // split-K slab stores (written once, read once by splitk_reduce_kernel): plain -- nontemporal measured +0.15 % (noise), profiles/r05e_w4_cache_policy.txt
 #define AVT_SLAB_ST(ptr, val) (*(f32x4_t*)(ptr) = (val))
 // LN: compile the LayerNorm-fold variants of the epilogue (only the kernels with both operands k-major are ever asked for them)
-// DIRECT (EPI 2): 1 = the workgroup holds the whole reduction (splitk == 1) and adds its tile into C itself, 0 = slabs.  Only the 4-wave weight-gradient
+// DIRECT (EPI 2): 1 = the workgroup holds the whole reduction (splitk == 1) and adds its tile into C itself, 2 = ... writes it (GemmParams::c_assign), 0 = slabs.  Only the 4-wave weight-gradient
 // kernel has the direct form, as a separate instantiation (both in one body spilled 16 of its registers; in the generic 128 x 128 kernel the 64 values in
 // flight would cost the second workgroup per CU): the head's 2048 x 8192 weights are what it is for.
 template <int TM, int TN, int WM, int WN, int EPI, int PR = 0, bool TAB = false, bool LN = false, int DIRECT = 0>
@@ -813,7 +816,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
   // row0/col0: global coordinates of this wave's tile origin
   static_assert(WM == TM * 32 && WN == TN * 32 && TM <= 4, "wave tile geometry");
   if (EPI == 2) {
-    if constexpr (DIRECT == 1) {
+    if constexpr (DIRECT >= 1) {
       // (round 6) the whole reduction sits in this workgroup: C += acc right here -- every C element has exactly one owner, plain read-modify-write,
       // the same sum bit for bit as a one-slab reduce -- instead of a slab round trip (tile written, re-read, C read and written) and a second launch.
       // Each store instruction covers two rows x 32 consecutive columns: two full 128-byte lines.  (The head's 2048 x 8192 weights at <= 2560 rows.)
@@ -836,7 +839,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16_t (&ac
             const int m0 = row0 + i * 32 + 8 * q + hq;
             off[j][q] = n < p.N ? (uint32_t)m0 * ld4 + (uint32_t)n * 4u : 0xFFFFFFF0u;      // (rows past M end up past the descriptor's range by themselves)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) old[j][4 * q + k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, off[j][q] == 0xFFFFFFF0u ? off[j][q] : off[j][q] + (uint32_t)k * ld4, 0, 0));
+            for (int k = 0; k < 4; ++k)
+              old[j][4 * q + k] = DIRECT == 2 ? 0.f      // (assign: C is known to hold zeros -- 0 + acc = acc bit for bit, accumulators never hold -0)
+                                              : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, off[j][q] == 0xFFFFFFF0u ? off[j][q] : off[j][q] + (uint32_t)k * ld4, 0, 0));
           }
         }
 #pragma unroll

@@ -19,6 +19,7 @@ SIGNATURES = {
     'avt_gemm_bf16': [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _U64, _P,
                       _I, _I, _I, _P, _SZ, _P],
     'avt_gemm_accum_bf16': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, ctypes.c_size_t, _P],
+    'avt_gemm_assign_bf16': [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, ctypes.c_size_t, _P],      # (ABI 9: C = result, for a C known to hold zeros)
     'avt_gemm_ln_bf16': [_P, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _I, _I, _F, _U64, _P,
                          _I, _I, _I, _P, _SZ, _P, _P, _P, _P],
     'avt_ln_stats_finalize': [_P, _I, _I, _I, _F, _P, _P, _P],

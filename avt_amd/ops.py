@@ -211,10 +211,54 @@ def _wgrad_workspace(device, nbytes):
     return ws
 
 
+# ---- gradient regions known to hold zeros (round 6) -------------------------------------------------------------------------------
+# FusedSGD re-zeroes the flat gradient buffer as it consumes it (avt_sgd_step's zero_grad) and says so here; the FIRST weight gradient written
+# into a region of such a buffer afterwards is stored instead of added (avt_gemm_assign_bf16: no read of 4 bytes of zeros per weight), every
+# later one into an overlapping region is added as before (multi-crop clips, a roll-out with gradients, anything that runs a layer twice).
+# Only weight gradients go through here and no other kind of kernel writes into a weight's gradient (biases, LayerNorm parameters and embeddings
+# are their own tensors; folded layers' weight gradients and the fused classifier + loss node never call gemm_accum), so "not yet written by
+# gemm_accum" means "still zero".  Anything else that writes into a registered buffer between two optimizer steps must call forget_zeroed().
+_ZEROED = {}                     # first byte of a buffer -> [byte past its end, intervals written since it was zeroed]
+ASSIGN_FIRST_WGRAD = True
+
+
+def mark_zeroed(buf):
+    """``buf`` (a flat fp32 gradient buffer) has just been re-zeroed in stream order by the kernel that consumed it.  The entry lives as long as
+    the tensor object does (a freed buffer's address may be handed to a tensor nobody zeroed)."""
+    import weakref
+    p = buf.data_ptr()
+    _ZEROED[p] = [p + buf.numel() * buf.element_size(), [], weakref.ref(buf, lambda _r, _p=p: _ZEROED.pop(_p, None))]
+
+
+def forget_zeroed(buf=None):
+    if buf is None:
+        _ZEROED.clear()
+    else:
+        _ZEROED.pop(buf.data_ptr(), None)
+
+
+def _first_write(C, rows):
+    if not ASSIGN_FIRST_WGRAD or not _ZEROED:
+        return False
+    lo = C.data_ptr()
+    hi = lo + ((rows - 1) * _ld(C) + C.size(1)) * 4
+    for b0, (b1, seen, _alive) in _ZEROED.items():
+        if b0 <= lo and hi <= b1:
+            if len(seen) > 8192:                            # nobody re-zeroes this buffer any more (another optimizer took over): stop tracking it
+                del _ZEROED[b0]
+                return False
+            fresh = all(hi <= s or e <= lo for s, e in seen)
+            seen.append((lo, hi))
+            return fresh
+    return False
+
+
 def gemm_accum(A, B, C, M, N, K):
     """C[M,N] (fp32) += sum_k A[k,m] B[k,n], both operands stored reduction-index-major; split-K partials go through a
-    workspace and are added in a fixed order (avt_gemm_accum_bf16) -- bit-reproducible weight gradients."""
+    workspace and are added in a fixed order (avt_gemm_accum_bf16) -- bit-reproducible weight gradients.  The first write into a region that
+    FusedSGD has just re-zeroed is a store (avt_gemm_assign_bf16; same bits)."""
     if not DETERMINISTIC_WGRAD or FORCE_TILE:
+        _first_write(C, M)                                  # (the atomic path adds: the region counts as written)
         return gemm(A, B, M, N, K, a_kmajor=False, b_kmajor=False, out=C, out_mode=OUT_ACCUM_F32)
     _chk(A, BF16, 'A'); _chk(B, BF16, 'B'); _chk(C, torch.float32, 'C')
     need = _lib.load().avt_gemm_accum_workspace_bytes(M, N, K)
@@ -223,7 +267,8 @@ def gemm_accum(A, B, C, M, N, K):
     if trace is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _lib.call('avt_gemm_accum_bf16', _p(A), _ld(A), _p(B), _ld(B), _p(C), _ld(C), M, N, K, 0, WGRAD_TILE, _p(ws), ws.numel(), _stream())
+    _lib.call('avt_gemm_assign_bf16' if _first_write(C, M) else 'avt_gemm_accum_bf16', _p(A), _ld(A), _p(B), _ld(B), _p(C), _ld(C), M, N, K, 0, WGRAD_TILE,
+              _p(ws), ws.numel(), _stream())
     if trace is not None:
         ev1.record()
         name = gemm_variant(M, N, K, False, False, OUT_ACCUM_F32, WGRAD_TILE if WGRAD_TILE != 2565 else 0).replace(',1>', ',2>')   # EPI 2 = slabs + ordered reduce
@@ -231,6 +276,33 @@ def gemm_accum(A, B, C, M, N, K):
             name = 'gemm_w4_kernel<2>'                    # the library's default for 256x256-tile weight gradients
         trace.append((name, 2.0 * M * N * K, ev0, ev1, (M, N, K)))
     return C
+
+
+class SideStream:
+    """Weight gradients off the backward's critical path (round 6, models/vit.py: the small-batch route): ``run(fn, *tensors)`` enqueues ``fn`` on a second
+    stream, ordered behind everything enqueued so far on the current one; ``tensors`` (its inputs) are kept from being reused by the caching allocator until
+    the side stream is done with them.  ``join()`` orders the current stream behind the side stream.  Between 256 and 512 output tiles a big-tile data
+    gradient leaves up to 140 CUs idle in its second round; a weight gradient running next to it takes them."""
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.pending = False
+
+    def run(self, fn, *tensors):
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self.stream.wait_event(ev)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            fn()
+        self.pending = True
+
+    def join(self):
+        if self.pending:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.pending = False
 
 
 # ---- the six contractions of a Linear (weight (out,in)) / HF Conv1D (weight (in,out)) layer ---------------------

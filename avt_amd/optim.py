@@ -109,6 +109,7 @@ class FusedSGD:
         self._early_lo = a.total
         for s0, e0 in self._uncovered:           # frozen parameters: nobody consumes their gradients, keep the range clean
             a.grad[s0:e0].zero_()
+        ops.mark_zeroed(a.grad)                  # the whole gradient buffer holds zeros again: the next weight gradients are stored, not added (ops.gemm_accum)
         self.steps += 1
         a.mark_shadow_current()
 

@@ -96,6 +96,12 @@ int avt_gemm_frag_ok(int M, int N, int K);
 int avt_gemm_accum_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
                         int splitk, int tile, void* workspace, size_t workspace_bytes, void* stream);
 size_t avt_gemm_accum_workspace_bytes(int M, int N, int K);
+/* The same product WRITTEN into C (ABI 9): for a caller that knows C holds zeros -- the reference's optimizer.zero_grad() (func/train.py:221), here
+ * avt_sgd_step's zero_grad -- the accumulate form reads 4 bytes per weight back for nothing (394 M weights: 1.6 GB per step, which at the reference's
+ * 3 clips per GPU is 2 % of it).  Same kernels, same bits as accumulating into zeros; the one-split kernel skips its loads of C, the slab reduce stores
+ * instead of adding.  avt_amd/ops.py::gemm_accum takes this form for the first write into a region of a gradient buffer since avt_amd/optim.py::FusedSGD re-zeroed it. */
+int avt_gemm_assign_bf16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                         int splitk, int tile, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- LayerNorm ---------------------------------------------------------------------------------------------------
  * [timm] Block.norm1/norm2/VisionTransformer.norm (eps 1e-6); [hf] GPT2 ln_1/ln_2/ln_f (eps 1e-5).

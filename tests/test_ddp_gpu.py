@@ -38,7 +38,7 @@ opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9, nesterov=True, weight_
 op = Basic(model, torch.device('cuda'), None, Cfg(_target_='func.train_eval_ops.BasicLossAccuracy'))
 # early optimizer step (round 6): AVT_TEST_EARLY_MIN=1 lets every exchanged bucket of this small model be stepped behind its collective; '0' switches it off
 if os.environ.get('AVT_TEST_EARLY_MIN') == '0': Trainer.EARLY_STEP = False
-elif os.environ.get('AVT_TEST_EARLY_MIN'): Trainer.EARLY_MIN_ELEMS = int(os.environ['AVT_TEST_EARLY_MIN'])
+elif os.environ.get('AVT_TEST_EARLY_MIN'): Trainer.EARLY_STEP, Trainer.EARLY_MIN_ELEMS = True, int(os.environ['AVT_TEST_EARLY_MIN'])      # (an option, off by default)
 tr = Trainer(model, op, opt, None, LOSS_WTS, distributed=world > 1, bucket_bytes=64 << 10, reduce_mode=os.environ.get('AVT_TEST_REDUCE_MODE', 'all_reduce'),
              reduce_transport=os.environ.get('AVT_TEST_TRANSPORT', 'torch'))
 early_calls = []
@@ -347,8 +347,10 @@ def test_bench_single_gpu_line_carries_configs_4_and_5():
     assert d['n_gpus'] == 1 and d['config']['clips_per_gpu'] == 8 and d['value'] > 0
     also = d['also']
     # (configs 4 and 5 at half / three eighths of the clips, config 2 at a quarter of them and at the reference's own 3 clips per GPU)
-    assert [a['frames'] for a in also] == [15, 10, 10, 10]
-    assert [a['model'] for a in also] == ['vit_base_patch16_224', 'vit_large_patch16_224', 'vit_base_patch16_224', 'vit_base_patch16_224']
-    assert [a['clips_per_gpu'] for a in also] == [4, 3, 2, 3] and all(a['value'] > 0 and 0 < a['executed_frac'] < a['frac'] for a in also)
+    assert [a['frames'] for a in also] == [15, 10, 10, 10, 10]
+    assert [a['model'] for a in also] == ['vit_base_patch16_224', 'vit_large_patch16_224', 'vit_base_patch16_224', 'vit_base_patch16_224', 'vit_base_patch16_224']
+    assert [a['clips_per_gpu'] for a in also] == [4, 3, 2, 3, 3] and all(a['value'] > 0 and 0 < a['executed_frac'] < a['frac'] for a in also)
+    # (round 6) the last entry is the reference's own batch again, the step replayed from a hipGraph
+    assert [a['launch'] for a in also] == ['eager'] * 4 + ['hipGraph replay'] and all(a['host_enqueue_ms_per_step'] > 0 for a in also)
     w = d['roofline']['worst_large_gemm_row']
     assert w['tflops'] > 0 and len(w['MNK']) == 3 and w['share_of_step_time'] >= 0.02

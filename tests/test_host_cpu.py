@@ -518,3 +518,28 @@ def test_skinny_routing_mirror():
     assert ops.gemm_variant(30, 2048, 8192, True, False, ops.OUT_BF16, 0) == 'gemm_skinny_kernel<0>'
     assert ops.gemm_variant(33, 2048, 8192, True, True, ops.OUT_BF16, 0).startswith('gemm_kernel<64,64,2,2,64,3')
     assert 'skinny' not in ops.gemm_variant(30, 2048, 8192, False, False, ops.OUT_ACCUM_F32, 0)                    # weight gradients: not this kernel
+
+
+def test_zeroed_gradient_registry():
+    """ops.mark_zeroed / _first_write (round 6): the first write into a region of a registered buffer is 'fresh', an overlapping later one is not, regions
+    outside every registered buffer never are, and an entry dies with its tensor (a freed buffer's address may be handed to a tensor nobody zeroed)."""
+    import gc
+    import torch
+    from avt_amd import ops
+    ops.forget_zeroed()
+    buf = torch.zeros(4096)
+    a, b = buf[:1024].view(32, 32), buf[1024:2048].view(32, 32)
+    assert not ops._first_write(a, 32)                      # nothing registered
+    ops.mark_zeroed(buf)
+    assert ops._first_write(a, 32) and not ops._first_write(a, 32)
+    assert not ops._first_write(buf[512:1536].view(32, 32), 32)            # overlaps a
+    assert not ops._first_write(b, 32)                                      # ... and that attempt counted as a write into half of b
+    assert ops._first_write(buf[2048:3072].view(32, 32), 16) and not ops._first_write(buf[2048:3072].view(32, 32), 32)
+    other = torch.zeros(1024).view(32, 32)
+    assert not ops._first_write(other, 32)
+    ops.mark_zeroed(buf)                                                    # the optimizer stepped: everything is fresh again
+    assert ops._first_write(a, 32)
+    n = len(ops._ZEROED)
+    del buf, a, b
+    gc.collect()
+    assert len(ops._ZEROED) == n - 1

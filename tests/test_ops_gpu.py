@@ -991,6 +991,49 @@ def test_deterministic_wgrad_accumulate(ops, M, P, Q):
         assert relerr(dw3[:P - 17] - base[:P - 17], ref[:P - 17]) < 2e-3 and torch.equal(dw3[P - 17:], base[P - 17:])      # rows past the limit untouched
 
 
+@pytest.mark.parametrize('M,P,Q', [(500, 768, 768), (5910, 2304, 768), (30, 2048, 8192), (640, 2000, 8200), (50000, 768, 3072), (77, 64, 32)])
+def test_first_weight_gradient_into_a_zeroed_buffer_is_stored(ops, M, P, Q):
+    """Round 6 (ABI 9, avt_gemm_assign_bf16): the first weight gradient written into a region of a gradient buffer that the fused optimizer has just
+    re-zeroed is STORED -- C is not read (here it holds NaNs: a kernel that read it would show them) -- with the bits of accumulating into zeros; a second
+    product into the same region, or into one that overlaps it, is added; an unregistered buffer always accumulates."""
+    from avt_amd import ops as O
+    dy, x = rnd((M, P), 1.0, 41), rnd((M, Q), 1.0, 42)
+    zero = torch.zeros((P, Q), device='cuda')
+    O.forget_zeroed()
+    ref = O.linear_wgrad(dy, x, zero.clone())                                     # accumulate into zeros (unregistered: the accumulate form)
+    buf = torch.full((2 * P * Q + 64,), float('nan'), device='cuda')              # "the gradient buffer": registered as zeroed, but full of NaNs
+    O.mark_zeroed(buf)
+    dw = buf[64:64 + P * Q].view(P, Q)
+    calls0 = dict(lib_calls())
+    O.linear_wgrad(dy, x, dw)
+    torch.cuda.synchronize()
+    assert lib_calls().get('avt_gemm_assign_bf16', 0) == calls0.get('avt_gemm_assign_bf16', 0) + 1
+    assert torch.equal(dw, ref)
+    assert torch.isnan(buf[:64]).all() and torch.isnan(buf[64 + P * Q:]).all()   # nothing else touched
+    O.linear_wgrad(dy, x, dw)                                                     # same region again: added
+    if P >= 128:
+        O.linear_wgrad(dy, x, dw, rows=P - 17)                                   # an overlapping region (fewer rows): added
+    torch.cuda.synchronize()
+    assert lib_calls().get('avt_gemm_assign_bf16', 0) == calls0.get('avt_gemm_assign_bf16', 0) + 1
+    k = 3 if P >= 128 else 2
+    assert relerr(dw[:P - 17 if P >= 128 else P], k * ref[:P - 17 if P >= 128 else P]) < 1e-6
+    dw2 = buf[64 + P * Q:64 + 2 * P * Q].view(P, Q)                               # a second, disjoint region of the same buffer: stored again
+    O.linear_wgrad(dy, x, dw2)
+    torch.cuda.synchronize()
+    assert torch.equal(dw2, ref) and lib_calls().get('avt_gemm_assign_bf16', 0) == calls0.get('avt_gemm_assign_bf16', 0) + 2
+    O.forget_zeroed(buf)
+    base = rnd((P, Q), 1.0, 43, torch.float32)
+    out = base.clone()
+    O.linear_wgrad(dy, x, out)
+    torch.cuda.synchronize()
+    assert relerr(out - base, ref) < 2e-3 and lib_calls().get('avt_gemm_assign_bf16', 0) == calls0.get('avt_gemm_assign_bf16', 0) + 2
+
+
+def lib_calls():
+    from avt_amd import lib
+    return lib.CALLS_BY_NAME
+
+
 def test_video_preproc_vs_reference_golden_and_oracle(ops, golden_dir):
     """Fused uint8 -> resize -> flip -> scale -> normalise -> crop kernel against (a) the golden produced by the
     reference's own transform functions and (b) the oracle at the training geometry (456x256 frames -> 248..280 -> 224 crop).
