@@ -47,9 +47,6 @@ class _Block(nn.Module):
         self.mlp = _Mlp(dim, dim * mlp_ratio)
 
 
-WGRAD_SIDE_STREAM = False        # HipViT.wgrad_side_stream default (lab switch while the A/B is open: tools/lab/wgrad_side_ab.py)
-
-
 class _PatchEmbed(nn.Module):
     def __init__(self, dim):
         super().__init__()
@@ -93,7 +90,6 @@ class HipViT(nn.Module):
         nn.init.trunc_normal_(self.pos_embed, std=.02)
         nn.init.trunc_normal_(self.cls_token, std=.02)
         self.grad_ready_hook = None          # callable(first_param, last_param) fired as backward finishes a segment
-        self.wgrad_side_stream = WGRAD_SIDE_STREAM
 
     def forward(self, frames):
         """frames fp32 (N, 3, H, W) -> CLS features fp32 (N, D).  A ``PatchVideo`` (the input pipeline's patch rows) is taken as it is."""
@@ -236,21 +232,6 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
     first_full = m.depth - 1
     if saved['fold']:
         arena.fold_scratch_guard()
-    # Weight gradients of the all-token blocks on a second stream (the LayerNorm-kernel route only -- token counts below HipViT.fold_min_rows -- and only
-    # between the tile counts where the data gradients' big tiles leave a half-empty second round): they are off the critical path and take the CUs a data
-    # gradient's last round leaves idle (ops.SideStream).
-    side = None
-    t768 = ((M + 255) // 256) * ((D + 255) // 256)
-    if m.wgrad_side_stream and not saved['fold'] and (256 < t768 < 512 or m.wgrad_side_stream == 'always'):
-        side = getattr(m, '_wgrad_side', None)
-        if side is None:
-            side = m._wgrad_side = ops.SideStream(dfeat.device)
-
-    def wgrad(dy, xin, dw):
-        if side is None:
-            ops.linear_wgrad(dy, xin, dw)
-        else:
-            side.run(lambda: ops.linear_wgrad(dy, xin, dw), dy, xin)
     if saved['cls_last']:
         dx2 = ops.layernorm_bwd(dfeat, x, meanf, rstdf, m.norm.weight, gr(m.norm.weight), gr(m.norm.bias),
                                 colsum=gr(last.mlp.fc2.bias))
@@ -306,32 +287,28 @@ def _vit_backward(m: HipViT, arena, saved, dfeat):
         (x, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, pre, act) = saved['blocks'][i]
         saved['blocks'][i] = None
         # x2 = act @ W2^T + b2 + x1          (db2 was accumulated by the producer of dx)
-        wgrad(dx, act, gr(blk.mlp.fc2.weight))
+        ops.linear_wgrad(dx, act, gr(blk.mlp.fc2.weight))
         # data gradients read the transposed bf16 shadow W^T k-major (arena.transposed_of): both operands k-major = the persistent 8-phase kernel
         dh = ops.linear_fwd(dx, sh_t(blk.mlp.fc2.weight), act=ops.ACT_MUL_AUX, aux=pre, colsum=gr(blk.mlp.fc1.bias))
         del act, pre
-        wgrad(dh, ln2, gr(blk.mlp.fc1.weight))
+        ops.linear_wgrad(dh, ln2, gr(blk.mlp.fc1.weight))
         dln2 = ops.linear_fwd(dh, sh_t(blk.mlp.fc1.weight))
         del dh, ln2
         dx1 = ops.layernorm_bwd(dln2, x1, mean2, rstd2, blk.norm2.weight, gr(blk.norm2.weight), gr(blk.norm2.bias),
                                 dres=dx, colsum=gr(blk.attn.proj.bias))
         del dln2, x1, dx
-        wgrad(dx1, att, gr(blk.attn.proj.weight))
+        ops.linear_wgrad(dx1, att, gr(blk.attn.proj.weight))
         datt = ops.linear_fwd(dx1, sh_t(blk.attn.proj.weight))
         dqkv = ops.vit_attn_bwd(qkv, att, datt, lse, N, S, H, dbias=gr(blk.attn.qkv.bias))
         del datt, att, qkv
-        wgrad(dqkv, ln1, gr(blk.attn.qkv.weight))
+        ops.linear_wgrad(dqkv, ln1, gr(blk.attn.qkv.weight))
         dln1 = ops.linear_fwd(dqkv, sh_t(blk.attn.qkv.weight))
         del dqkv, ln1
         dx = ops.layernorm_bwd(dln1, x, mean1, rstd1, blk.norm1.weight, gr(blk.norm1.weight), gr(blk.norm1.bias),
                                dres=dx1, colsum=prev_bias)
         del dln1, dx1, x
         if hook:
-            if side is not None:
-                side.join()                  # (the segment's weight gradients are part of what the hook reports as finished)
             hook(blk.norm1.weight, blk.mlp.fc2.bias)
-    if side is not None:
-        side.join()
     ops.linear_wgrad(dx, saved['patches'], gr(m.patch_embed.proj.weight).view(D, 768))
     ops.patch_embed_bwd_reduce(dx, gr(m.pos_embed).view(-1), gr(m.cls_token).view(-1), gr(m.patch_embed.proj.bias), N, S, D)
     if hook:

@@ -278,33 +278,6 @@ def gemm_accum(A, B, C, M, N, K):
     return C
 
 
-class SideStream:
-    """Weight gradients off the backward's critical path (round 6, models/vit.py: the small-batch route): ``run(fn, *tensors)`` enqueues ``fn`` on a second
-    stream, ordered behind everything enqueued so far on the current one; ``tensors`` (its inputs) are kept from being reused by the caching allocator until
-    the side stream is done with them.  ``join()`` orders the current stream behind the side stream.  Between 256 and 512 output tiles a big-tile data
-    gradient leaves up to 140 CUs idle in its second round; a weight gradient running next to it takes them."""
-    def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)
-        self.pending = False
-
-    def run(self, fn, *tensors):
-        main = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)
-        self.stream.wait_event(ev)
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.stream)
-        with torch.cuda.stream(self.stream):
-            fn()
-        self.pending = True
-
-    def join(self):
-        if self.pending:
-            torch.cuda.current_stream().wait_stream(self.stream)
-            self.pending = False
-
-
 # ---- the six contractions of a Linear (weight (out,in)) / HF Conv1D (weight (in,out)) layer ---------------------
 def linear_fwd(x, w, **kw):
     """y[M,N] = x[M,K] @ w[N,K]^T"""
