@@ -981,7 +981,10 @@ int dispatch_w4(GemmParams& p, int a_kmajor, int b_kmajor, int splitk, hipStream
   if (a_kmajor || b_kmajor) { avt_set_error("avt_gemm_accum_bf16: operands must both be stored reduction-index-major"); return -1; }
   p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + 255) / 256;
   const int nk64 = (p.K + 63) / 64;
-  if (splitk <= 0) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk64, 1, 8);      // same choice as the 8-phase kernel: the workspace query mirrors it
+  // (at least 16 K tiles = 1024 rows per split: at the reference's 3 clips per GPU -- 5910 rows -- 7-9 splits of 650-850 rows are mostly prologue, slab and
+  //  reduce: 5 splits are 3-4 us per call faster, profiles/r06s_wgrad_split_sweep.txt; from 8 clips on the choice is what it was.  The workspace query
+  //  assumes 8 tiles per split: an upper bound)
+  if (splitk <= 0) splitk = pick_splitk((long)p.tiles_m * p.tiles_n, nk64, 1, 16);
   if (splitk > nk64) splitk = nk64;
   p.splitk = splitk;
   p.tile_cm = p.tiles_n > p.tiles_m;
