@@ -1,5 +1,5 @@
 #!/bin/bash
-# r06m: (1) tail round on small tiles: parity + whole-step A/B; (2) captured step (hipGraph, ABI 9): parity test, bench lines eager vs --graph at 1 / 2 / 3 / 8 clips
+# r06m: (1) tail round on small tiles: parity + whole-step A/B (the library's split and tools/lab/tail_split_ab.py were removed after this session: profiles/r06m_tail_split.txt); (2) captured step (hipGraph, ABI 9): parity test, bench lines eager vs --graph at 1 / 2 / 3 / 8 clips
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_model_gpu.py -m gpu -q -x -k "captured_step or dropout_on" > gpurun_out/r06m_pytest_graph.log 2>&1; tail -15 gpurun_out/r06m_pytest_graph.log
