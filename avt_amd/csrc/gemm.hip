@@ -229,8 +229,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
   gemm_epilogue<TM, TN, WM, WN, EPI, 0, false, A_KMAJOR && B_KMAJOR>(p, acc, lds, wave, lane, tm0 + wm * WM, tn0 + wn * WN);
 }
 
-// ---- skinny kernel: at most 32 output rows (the head at the reference's own 3 clips per GPU: 30 rows; the CLS-only last ViT block) ----------------
-// C[M <= 32, N] = epilogue(A[M,K] . op(B)), A k-major.  Such a GEMM is a stream of the weight matrix (2048 x 8192 bf16 = 33.5 MB against 0.5 MB of
+// ---- skinny kernel: at most 64 output rows (the head at the reference's own 3 clips per GPU: 30 rows at T = 10, 45 at T = 15; the CLS-only last ViT block) ----
+// C[M <= 64, N] = epilogue(A[M,K] . op(B)), A k-major.  Such a GEMM is a stream of the weight matrix (2048 x 8192 bf16 = 33.5 MB against 0.5 MB of
 // activations) and the 64 x 64 kernel runs it as 32 workgroups of N / 64 -- one eighth of the chip, each with two 16-KB stages in flight: 33 us = 1 TB/s
 // (profiles/r06h_kernel_trace_B3.txt).  Split-K would fill the chip but change the fp32 summation order, and every tile route of this library gives the
 // same bits for a shape (the batch-invariance tests).  So the reduction stays ONE ordered chain of v_mfma_f32_32x32x16_bf16 per 32 x 32 output tile, and
@@ -238,10 +238,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, MINW) void gemm_kernel(GemmParams p
 // of an 18-stage ring of [32 x 64] A + [32 x 64] B tiles (144 KB; 17 stages = 68 KB of weights in flight per workgroup, a wave's own counter sees 34
 // requests), wave 0 alone runs the chain (4 MFMAs per stage, the next stage's fragments requested before them).  Stages past the end of the reduction
 // are requested all the same (out of range -> zeros, no traffic): the counted wait stays one constant.
-template <bool B_KMAJOR>
+template <bool B_KMAJOR, int TMR = 1>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
-  constexpr int BM = 32, BN = 32, BK = 64, NST = 18, NW = 4;
+  // TMR = row tiles of 32 (1: M <= 32, 18 stages; 2: M <= 64 -- the head at 3 clips x 15 frames = 45 rows, BASELINE config 4 at the reference's batch -- two
+  // independent chains per wave, 13 stages of 12 KB)
+  constexpr int BM = 32 * TMR, BN = 32, BK = 64, NST = TMR == 1 ? 18 : 13, NW = 4;
   constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2, STAGE = A_TILE + B_TILE;
+  constexpr int PER = TMR + 1;                             // LDS-DMA requests per wave and stage
+  static_assert(NST * STAGE <= 160 * 1024 && PER * (NST - 1) <= 63, "skinny kernel: LDS / request counter");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -252,30 +256,39 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
   const int nk = (p.K + BK - 1) / BK;
   __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, p.a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, p.b_bytes, 0x00020000);
-  auto stage = [&](int buf, int kt) __attribute__((always_inline)) {       // two requests per wave
+  auto stage = [&](int buf, int kt) __attribute__((always_inline)) {       // PER requests per wave
     char* base = lds + buf * STAGE;
     const int k0 = kt * BK;
     stage_kmajor<BM, NW, BK>(ra, base, 0, k0, p.lda, p.K, wave, lane);
     if (B_KMAJOR) stage_kmajor<BN, NW, BK>(rb, base + A_TILE, tn0, k0, p.ldb, p.K, wave, lane);
     else stage_kstrided<BN, NW, BK>(rb, base + A_TILE, tn0, k0 < p.K ? k0 : p.K, p.ldb, p.N, wave, lane);
   };
-  f32x16_t acc[1][1];
+  f32x16_t acc[TMR][1];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-  bf16x8_t af[2][4], bfr[2][4];
+  for (int i = 0; i < TMR; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+  bf16x8_t af[2][TMR][4], bfr[2][4];
   auto frags = [&](int slot, int b) __attribute__((always_inline)) {
     const char* la = lds + slot * STAGE;
     const char* lb = la + A_TILE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      af[b][ks] = frag_kmajor<BK>(la, 0, ks, lane);
+#pragma unroll
+      for (int i = 0; i < TMR; ++i) af[b][i][ks] = frag_kmajor<BK>(la, i, ks, lane);
       bfr[b][ks] = B_KMAJOR ? frag_kmajor<BK>(lb, 0, ks, lane) : frag_kstrided_na<BN>(lb, 0, ks, lane);
     }
   };
   auto chain = [&](int b) __attribute__((always_inline)) {
-    if (!B_KMAJOR) frag_wait<0>(af[b], bfr[b]);          // (inline-assembly reads: the compiler does not wait for them)
+    if (!B_KMAJOR) {                                       // (inline-assembly reads: the compiler does not wait for them)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) acc[0][0] = mma<0>(af[b][ks], bfr[b][ks], acc[0][0]);
+      for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(bfr[b][ks]));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int i = 0; i < TMR; ++i) acc[i][0] = mma<0>(af[b][i][ks], bfr[b][ks], acc[i][0]);
   };
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) stage(s, s);
@@ -284,13 +297,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
   for (int it = 0; it < nk; it += 2) {
     // even stage: its fragments go into set 0 while the chain of the previous (odd) stage runs on set 1
     // (lgkmcnt(0): wave 0's fragment reads of the slot refilled below have retired -- they were issued a whole chain ago)
-    wait_vmcnt<2 * (NST - 2)>();
+    wait_vmcnt<PER * (NST - 2)>();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     { int fill = slot + NST - 1; if (fill >= NST) fill -= NST; stage(fill, it + NST - 1); }
     if (wave == 0) { frags(slot, 0); if (it) chain(1); }
     if (++slot == NST) slot = 0;
     // odd stage (past the end when nk is odd: fetched as zeros, never multiplied)
-    wait_vmcnt<2 * (NST - 2)>();
+    wait_vmcnt<PER * (NST - 2)>();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     { int fill = slot + NST - 1; if (fill >= NST) fill -= NST; stage(fill, it + NST); }
     if (wave == 0) { frags(slot, 1); chain(0); }
@@ -299,23 +312,30 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
   if (wave == 0 && !(nk & 1)) chain(1);
   wait_vmcnt<0>();                                        // the zero stages past the end have landed: the ring is quiet
   asm volatile("s_barrier" ::: "memory");
-  if (wave == 0) gemm_epilogue<1, 1, 32, 32, 0, 0, false, B_KMAJOR>(p, acc, lds, 0, lane, 0, tn0);
+  if (wave == 0) gemm_epilogue<TMR, 1, 32 * TMR, 32, 0, 0, false, B_KMAJOR>(p, acc, lds, 0, lane, 0, tn0);
 }
 
 int dispatch_skinny(GemmParams& p, int a_kmajor, int b_kmajor, hipStream_t s) {
-  if (!a_kmajor || p.M > 32) { avt_set_error("avt_gemm_bf16: tile 32 is the skinny kernel: A k-major, M <= 32 (got M = %d)", p.M); return -1; }
+  if (!a_kmajor || p.M > 64) { avt_set_error("avt_gemm_bf16: tile 32 is the skinny kernel: A k-major, M <= 64 (got M = %d)", p.M); return -1; }
   // (a B stored [K][N] is addressed up to one stage past its last row: that offset must not wrap)
   if (!b_kmajor && (uint64_t)p.b_bytes + 64ull * (uint64_t)p.ldb * 2ull >= (1ull << 32)) { avt_set_error("avt_gemm_bf16: tile 32: B too large"); return -1; }
   p.tiles_m = 1; p.tiles_n = (p.N + 31) / 32; p.splitk = 1;
-  constexpr int smem = 18 * 8192;
+  constexpr int smem1 = 18 * 8192, smem2 = 13 * 12288;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
+    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem1);
+    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
+    (void)hipFuncSetAttribute((const void*)gemm_skinny_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem2);
     attr_set = true;
   }
-  if (b_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<true>), dim3(p.tiles_n), dim3(256), smem, s, p);
-  else hipLaunchKernelGGL((gemm_skinny_kernel<false>), dim3(p.tiles_n), dim3(256), smem, s, p);
+  if (p.M <= 32) {
+    if (b_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<true, 1>), dim3(p.tiles_n), dim3(256), smem1, s, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<false, 1>), dim3(p.tiles_n), dim3(256), smem1, s, p);
+  } else {
+    if (b_kmajor) hipLaunchKernelGGL((gemm_skinny_kernel<true, 2>), dim3(p.tiles_n), dim3(256), smem2, s, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<false, 2>), dim3(p.tiles_n), dim3(256), smem2, s, p);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { avt_set_error("avt_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
@@ -1091,9 +1111,10 @@ static int gemm_impl(const void* A, int a_kmajor, int lda, const void* B, int b_
   }
   if (tile == 0 && bm == 256 && (K % 64 == 0 || (!a_kmajor && !b_kmajor))) bm = 8080;      // default big-tile kernel: the 8-phase schedule, persistent where that is faster
   if (tile == 0 && bm == 8080 && epi == 2) bm = 2565;                                          // weight gradients: 4 waves of 128x128 (+2-3 % over the 8-phase kernel)
-  // at most 32 output rows of k-major A rows (the head at the reference's 3 clips per GPU, the CLS-only last ViT block): the skinny kernel -- N / 32
-  // workgroups, one ordered MFMA chain each, an 18-stage ring: same bits, 2-3x the weight stream of the 64 x 64 tiles (profiles/r06j_skinny_gemm.txt)
-  if (tile == 0 && bm == 64 && epi == 0 && a_kmajor && M <= 32 && (b_kmajor || (uint64_t)bb + 64ull * (uint64_t)ldb * 2ull < (1ull << 32))) bm = 32;
+  // at most 64 output rows of k-major A rows (the head at the reference's 3 clips per GPU -- 30 rows at T = 10, 45 at T = 15 --, the CLS-only last ViT block): the skinny kernel -- N / 32
+  // workgroups, one ordered MFMA chain each, an 18-stage ring: same bits, 2-3x the weight stream of the 64 x 64 tiles (profiles/r06j_skinny_gemm.txt).  33-64 rows (two
+  // row tiles, 13 stages): only with k-major weights -- with B stored [K][N] the 64 x 64 ring is as fast or faster there (profiles/r06w_skinny64.txt)
+  if (tile == 0 && bm == 64 && epi == 0 && a_kmajor && (M <= 32 || (M <= 64 && b_kmajor)) && (b_kmajor || (uint64_t)bb + 64ull * (uint64_t)ldb * 2ull < (1ull << 32))) bm = 32;
   if (tile == 0 && bm == 64 && epi == 0 && a_kmajor && (b_kmajor || (long)((M + 63) / 64) * ((N + 63) / 64) <= 256)) bm = 643;                                // small outputs of k-major rows: 3-deep ring (+15-25 % on the head's data gradients; late round 5: also with B stored [K][N] while the tiles fit one round -- the head's forward at 30 .. 160 rows: 60 -> 46 us at K = 8192; at 2560 rows the 2-deep ring is the faster one there)
   AVT_CHECK(!(p.c2_frag || p.aux_frag) || bm == 8080 || bm == 809,
             "avt_gemm_bf16: a fragment-major C2 / aux (ldc2 == 0 / ldaux == 0) needs the persistent kernel, which does not take this shape: ask avt_gemm_frag_ok(M, N, K) first");
@@ -1147,7 +1168,7 @@ static int gemm_dispatch(GemmParams& p, int bm, int epi, int a_kmajor, int b_kma
       return dispatch_epi<256, 256, 2, 4, 64, 2, true>(p, epi, a_kmajor, b_kmajor, splitk, s);
     default: break;
   }
-  avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 32 (M <= 32), 64, 128, 643, 256 / 2568 (one barrier per K tile), 808 (8-phase) or 809 (8-phase, persistent) (got %d)", bm);
+  avt_set_error("avt_gemm_bf16: tile must be 0 (choose), 32 (M <= 64), 64, 128, 643, 256 / 2568 (one barrier per K tile), 808 (8-phase) or 809 (8-phase, persistent) (got %d)", bm);
   return -1;
 }
 

@@ -71,7 +71,7 @@ def gemm_variant(M, N, K, a_kmajor, b_kmajor, out_mode, tile, epilogue_ok=False)
             if (epi == 0 and a_kmajor and b_kmajor and epilogue_ok and N % 256 == 0 and K % 128 == 0 and 256 <= K <= PERSIST_KMAX
                     and 512 <= t256 < 65536):
                 bm = 809          # the persistent form (csrc/gemm_persist.hip: avt_gemm_persist)
-        if bm == 64 and epi == 0 and a_kmajor and M <= 32:
+        if bm == 64 and epi == 0 and a_kmajor and (M <= 32 or (M <= 64 and b_kmajor)):
             bm = 32           # the skinny kernel (csrc/gemm.hip: gemm_skinny_kernel)
         if bm == 64 and epi == 0 and a_kmajor and (b_kmajor or ((M + 63) // 64) * ((N + 63) // 64) <= 256):
             bm = 643

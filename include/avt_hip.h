@@ -48,15 +48,15 @@ int avt_abi_version(void);
  *     v += res[(res_period ? m % res_period : m), n];  colsum[n] += v (over the bf16-rounded values when C is bf16; see "partials" below);  C[m,n] = v
  * out_mode 2: C (fp32) += acc with atomics, no epilogue; splitk > 1 splits the reduction over workgroups
  *             (splitk <= 0 picks a factor that fills the chip).  Used for weight gradients.
- * tile: 0 = choose; 32 (M <= 32) | 64 | 128 | 256 | 808 (256x256 tile, 8-phase schedule, one tile per workgroup) | 809 (the same schedule as a persistent
+ * tile: 0 = choose; 32 (M <= 64) | 64 | 128 | 256 | 808 (256x256 tile, 8-phase schedule, one tile per workgroup) | 809 (the same schedule as a persistent
  * kernel: one workgroup per CU draws tiles from a queue and fetches the next tile's first K tile under its epilogue; bit-identical to 808;
  * k-major operands, N % 256 == 0, K % 128 == 0, >= 512 tiles, bf16 output, bias | GELU | bias + residual | saved-derivative epilogue --
  * an error otherwise; the automatic choice takes it for K <= 4096) force a kernel.  The automatic choice walks the
  * tiles of an activation GEMM whose B operand exceeds an XCD's 4-MB L2 (N*K*2 > 4 MB, e.g. the fc1 weight) in column strips, so that
  * the strip of B stays L2-resident (results do not depend on the tile order).  Small outputs (fewer than 200 tiles of 256 x 256; the reference's own
  * 3 clips per GPU, expts/01_ek100_avt.txt:5): all-k-major contractions take the 8-phase kernel from 96 such tiles and 64 x 64 tiles with a 3-deep ring
- * below that when K <= 3072; everything else 128 x 128 tiles (>= 192 of them) or 64 x 64; at most 32 output rows of k-major A rows (round 6; the head at
- * 3 clips per GPU): tile 32, the skinny kernel -- N / 32 workgroups, each one ordered MFMA chain fed by an 18-stage LDS-DMA ring (a weight stream: HBM-bound;
+ * below that when K <= 3072; everything else 128 x 128 tiles (>= 192 of them) or 64 x 64; at most 64 output rows of k-major A rows (round 6; the head at
+ * 3 clips per GPU: 30 rows at T = 10, 45 at T = 15): tile 32, the skinny kernel -- N / 32 workgroups, each one ordered MFMA chain fed by an 18-stage LDS-DMA ring (a weight stream: HBM-bound;
  * same bits as every other tile).  Requirements: 16-B aligned pointers, lda/ldb % 8 == 0,
  * K % 8 == 0 when an operand is k-major, N % 4 == 0 and ldc % 4 == 0 for out_mode 0/1. */
 int avt_gemm_bf16(const void* A, int a_kmajor, int lda, const void* B, int b_kmajor, int ldb,

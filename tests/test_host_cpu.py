@@ -512,11 +512,13 @@ def test_indirect_seed_packing_and_capture_slots():
 
 
 def test_skinny_routing_mirror():
-    """ops.gemm_variant restates gemm_impl's round-6 routing: at most 32 rows of k-major A rows go to the skinny kernel."""
+    """ops.gemm_variant restates gemm_impl's round-6 routing: at most 64 rows of k-major A rows go to the skinny kernel."""
     from avt_amd import ops
     assert ops.gemm_variant(30, 2048, 8192, True, True, ops.OUT_BF16, 0) == 'gemm_skinny_kernel<1>'
     assert ops.gemm_variant(30, 2048, 8192, True, False, ops.OUT_BF16, 0) == 'gemm_skinny_kernel<0>'
-    assert ops.gemm_variant(33, 2048, 8192, True, True, ops.OUT_BF16, 0).startswith('gemm_kernel<64,64,2,2,64,3')
+    assert ops.gemm_variant(45, 2048, 8192, True, True, ops.OUT_BF16, 0) == 'gemm_skinny_kernel<1>'          # 3 clips x 15 frames
+    assert ops.gemm_variant(45, 2048, 8192, True, False, ops.OUT_BF16, 0).startswith('gemm_kernel<64,64,2,2,64,3')   # ... B stored [K][N]: the 64 x 64 ring
+    assert ops.gemm_variant(65, 2048, 8192, True, True, ops.OUT_BF16, 0).startswith('gemm_kernel<64,64,2,2,64,3')
     assert 'skinny' not in ops.gemm_variant(30, 2048, 8192, False, False, ops.OUT_ACCUM_F32, 0)                    # weight gradients: not this kernel
 
 

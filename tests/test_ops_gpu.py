@@ -56,17 +56,18 @@ def test_gemm_plain(ops, M, N, K, layout):
 
 
 @pytest.mark.parametrize('M,N,K', [(30, 2048, 8192), (30, 8192, 2048), (30, 6144, 2048), (30, 2048, 2048), (20, 768, 768), (32, 3072, 768), (10, 776, 3080),
-                                   (1, 64, 64), (30, 2304, 768), (7, 40, 72)])
+                                   (1, 64, 64), (30, 2304, 768), (7, 40, 72), (45, 2048, 8192), (45, 8192, 2048), (64, 768, 3072), (33, 776, 3080), (60, 6144, 2048)])
 @pytest.mark.parametrize('layout', ['NT', 'NN'])
 def test_skinny_gemm_bit_equal_to_the_64_tile_kernels(ops, M, N, K, layout):
-    """Round 6: at most 32 output rows of k-major A rows (the head at the reference's own 3 clips per GPU, the CLS-only last ViT block) go to
-    gemm_skinny_kernel (tile 32: N / 32 workgroups, one ordered MFMA chain each, 18-stage LDS-DMA ring).  The automatic choice lands on it, the
+    """Round 6: at most 64 output rows of k-major A rows (the head at the reference's own 3 clips per GPU -- 30 rows at T = 10, 45 at T = 15 --, the CLS-only
+    last ViT block) go to gemm_skinny_kernel (tile 32: N / 32 workgroups, one ordered MFMA chain per 32-row tile, 18- / 13-stage LDS-DMA ring).  The automatic choice lands on it, the
     result equals the fp32 reference and -- the reduction is the same ordered chain -- the 64 x 64 kernels' bit for bit, with every epilogue the
     head uses (bias, tanh-GELU + derivative, erf-GELU, residual, dropout, column sums, saved-derivative product), strided A rows, ragged N and K."""
     if layout == 'NN' and N % 8:
         pytest.skip('unsupported alignment for this layout')
     kk = layout == 'NT'
-    assert ops.gemm_variant(M, N, K, True, kk, ops.OUT_BF16, 0) == f'gemm_skinny_kernel<{int(kk)}>'
+    if M <= 32 or kk:               # (33-64 rows with B stored [K][N]: the automatic choice stays with the 64 x 64 ring; tile 32 is still exercised below)
+        assert ops.gemm_variant(M, N, K, True, kk, ops.OUT_BF16, 0) == f'gemm_skinny_kernel<{int(kk)}>'
     a = rnd((M, K), 1.0, 1)
     b = rnd((N, K) if kk else (K, N), 0.05, 2)
     ref = a.float() @ (b.float().t() if kk else b.float())
@@ -90,12 +91,18 @@ def test_skinny_gemm_bit_equal_to_the_64_tile_kernels(ops, M, N, K, layout):
             torch.cuda.synchronize()
             outs[tile] = (out, c2, cs)
         for tile in (0, 32, 643):
-            for x, y in zip(outs[tile], outs[64]):
+            for idx, (x, y) in enumerate(zip(outs[tile], outs[64])):
                 assert (x is None) == (y is None)
-                if x is not None:
+                if x is None:
+                    continue
+                if idx == 2 and M > 32:
+                    # column sums over 33-64 rows: the skinny kernel's one wave folds both 32-row tiles itself, the 64 x 64 kernel two wave rows' partials -- the
+                    # same numbers added in another order (fp32); every per-element output stays bit-equal
+                    assert relerr(x, y) < 1e-6, (tile, call.keys())
+                else:
                     assert torch.equal(x.view(torch.int16 if x.dtype == torch.bfloat16 else torch.int32), y.view(torch.int16 if y.dtype == torch.bfloat16 else torch.int32)), (tile, call.keys())
     with pytest.raises(Exception):
-        ops.gemm(rnd((40, K), 1.0, 1), b, 40, N, K, a_kmajor=True, b_kmajor=kk, tile=32)       # more than 32 rows: refused
+        ops.gemm(rnd((70, K), 1.0, 1), b, 70, N, K, a_kmajor=True, b_kmajor=kk, tile=32)       # more than 64 rows: refused
 
 
 @pytest.mark.parametrize('M,P,Q', [(64, 128, 128), (500, 768, 768), (3152, 2304, 768), (160, 2048, 6144), (176, 3840, 768),

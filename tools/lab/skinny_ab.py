@@ -6,7 +6,7 @@ from avt_amd import lib
 if sys.argv[1] == 'tiles64':
     real = lib.call
     def call(name, *a):
-        if name in ('avt_gemm_bf16', 'avt_gemm_ln_bf16') and a[25] == 0 and a[23] in (0, 1) and a[1] and a[8] <= 32:
+        if name in ('avt_gemm_bf16', 'avt_gemm_ln_bf16') and a[25] == 0 and a[23] in (0, 1) and a[1] and a[8] <= 64:
             M, N = a[8], a[9]
             a = a[:25] + (643 if (a[4] or ((M + 63) // 64) * ((N + 63) // 64) <= 256) else 64,) + a[26:]
         return real(name, *a)

@@ -15,7 +15,7 @@ for name, N, K, kk in shapes:
     ws = [r(N, K) if kk else r(K, N) for _ in range(8)]
     row = f'{name:20s} N {N:5d} K {K:5d} {"NT" if kk else "NN"}  '
     for tile in (32, 643, 64, 128):
-        if tile == 32 and M > 32:
+        if tile == 32 and M > 64:
             continue
         for w in ws:
             ops.gemm(a, w, M, N, K, a_kmajor=True, b_kmajor=kk, tile=tile)
