@@ -948,6 +948,49 @@ def test_xent(ops):
     assert float(dl[:, C:].float().abs().max()) == 0.0
 
 
+def test_indirect_seeds_and_device_learning_rate(ops):
+    """ABI 9 ("captured steps"): a seed argument with bit 63 set is the device address of a base seed plus an offset (avt_amd/seeds.py::DevSeed) -- every
+    dropout-bearing kernel (avt_dropout_bf16, avt_embed_pos_fwd / _bwd, the GEMM epilogue, avt_head_attn_fwd / _bwd) gives with it the bits of the plain seed
+    base + offset, and follows the slot when it is rewritten; avt_sgd_step_dev reads the learning rate from device memory."""
+    from avt_amd.seeds import DevSeed
+    slot = torch.tensor([123456789, 0], dtype=torch.int64, device='cuda')
+    ind = DevSeed(slot.data_ptr()) + 37
+    x = rnd((64, 256), 1.0, 1)
+    B, T, H, hd, E = 3, 10, 4, 64, 256
+    qkv = rnd((B * T, 3 * E), 0.5, 2)
+    enc, wpe = rnd((B * T, E), 1.0, 3), rnd((T, E), 1.0, 4, torch.float32)
+    a, w, res = rnd((30, 512), 0.5, 5), rnd((256, 512), 0.1, 6), rnd((30, 256), 1.0, 7)
+
+    def run(seed):
+        o = [ops.dropout(x, 0.3, seed), ops.embed_pos_fwd(enc, wpe, B, T, E, 0.1, seed), ops.gemm(a, w, 30, 256, 512, drop_p=0.25, seed=seed, res=res),
+             ops.gemm(rnd((300, 512), 0.5, 8), w, 300, 256, 512, drop_p=0.25, seed=seed, tile=128)]
+        out, probs = ops.causal_attn_fwd(qkv, B, T, H, hd, drop_p=0.2, seed=seed)
+        o += [out, ops.causal_attn_bwd(qkv, probs, rnd((B * T, E), 1.0, 9), B, T, H, hd, drop_p=0.2, seed=seed)]
+        dwpe = torch.zeros((T, E), device='cuda')
+        o += [ops.embed_pos_bwd(rnd((B * T, E), 1.0, 10), dwpe, B, T, E, 0.1, seed), dwpe]
+        torch.cuda.synchronize()
+        return [t.clone() for t in o]
+
+    for base in (123456789, 987654321012345):
+        slot[0] = base
+        plain, indirect = run(base + 37), run(ind)
+        for p_, i_ in zip(plain, indirect):
+            assert torch.equal(p_.view(torch.int16) if p_.dtype == torch.bfloat16 else p_, i_.view(torch.int16) if i_.dtype == torch.bfloat16 else i_)
+    assert not torch.equal(run(123456789 + 37)[0].view(torch.int16), plain[0].view(torch.int16))          # (the two base seeds give different masks)
+    # the learning rate from device memory
+    n = 10007
+    p0, g0 = rnd((n,), 1.0, 11, torch.float32), rnd((n,), 1.0, 12, torch.float32)
+    outs = []
+    for lr in (0.05, torch.tensor([0.05], device='cuda')):
+        p_, g_, buf, sh = p0.clone(), g0.clone(), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda', dtype=torch.bfloat16)
+        for step in range(2):
+            ops.sgd_step(p_, g_.clone(), buf, sh, lr, 0.9, 1e-4, grad_scale=0.5, nesterov=True, first_step=(step == 0), zero_grad=False)
+        torch.cuda.synchronize()
+        outs.append((p_, buf, sh.view(torch.int16)))
+    for x_, y_ in zip(*outs):
+        assert torch.equal(x_, y_)
+
+
 def test_sgd_step(ops):
     n = 100003
     p = torch.randn(n, device='cuda'); g = torch.randn(n, device='cuda'); buf = torch.zeros(n, device='cuda')
