@@ -8,6 +8,7 @@ from avt_amd.models.vit import HipViT
 for B in [int(b) for b in os.environ.get("PROBE_BATCHES", "3,5,8,16").split(",")]:
     for fold in (True, False, True, False):
         HipViT.fold_layernorm = fold
+        HipViT.fold_min_rows = 0              # (the product folds from 60000 token rows on; this probe decides by `fold` alone)
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
             bench.main(['--batch', str(B), '--steps', '30', '--warmup', '5', '--no-cpu-baseline', '--no-also', '--no-gemm-trace'])
