@@ -3,6 +3,8 @@
 Every function enqueues HIP kernels on torch's current stream and returns immediately.  Inputs must live on the
 GPU; there is no CPU or eager fallback -- a missing library raises ``AvtHipError``.
 """
+import bisect
+
 import torch
 
 from . import lib as _lib
@@ -227,7 +229,7 @@ def mark_zeroed(buf):
     the tensor object does (a freed buffer's address may be handed to a tensor nobody zeroed)."""
     import weakref
     p = buf.data_ptr()
-    _ZEROED[p] = [p + buf.numel() * buf.element_size(), [], weakref.ref(buf, lambda _r, _p=p: _ZEROED.pop(_p, None))]
+    _ZEROED[p] = [p + buf.numel() * buf.element_size(), ([], []), weakref.ref(buf, lambda _r, _p=p: _ZEROED.pop(_p, None))]
 
 
 def forget_zeroed(buf=None):
@@ -242,14 +244,21 @@ def _first_write(C, rows):
         return False
     lo = C.data_ptr()
     hi = lo + ((rows - 1) * _ld(C) + C.size(1)) * 4
-    for b0, (b1, seen, _alive) in _ZEROED.items():
+    for b0, (b1, (los, his), _alive) in _ZEROED.items():
         if b0 <= lo and hi <= b1:
-            if len(seen) > 8192:                            # nobody re-zeroes this buffer any more (another optimizer took over): stop tracking it
-                del _ZEROED[b0]
-                return False
-            fresh = all(hi <= s or e <= lo for s, e in seen)
-            seen.append((lo, hi))
-            return fresh
+            # the intervals written since the buffer was zeroed: sorted and disjoint (a write that overlaps some is merged with them), so a look-up
+            # is a bisection, not a scan (a step makes ~85 weight-gradient calls)
+            i = bisect.bisect_right(los, lo) - 1
+            j = i if (i >= 0 and his[i] > lo) else i + 1           # first interval that overlaps [lo, hi), if any
+            k = j
+            while k < len(los) and los[k] < hi:
+                k += 1
+            if j == k:
+                los.insert(j, lo); his.insert(j, hi)
+                return True
+            nlo, nhi = min(lo, los[j]), max(hi, his[k - 1])
+            los[j:k] = [nlo]; his[j:k] = [nhi]
+            return False
     return False
 
 

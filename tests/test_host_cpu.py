@@ -545,3 +545,34 @@ def test_zeroed_gradient_registry():
     del buf, a, b
     gc.collect()
     assert len(ops._ZEROED) == n - 1
+
+
+def test_zeroed_gradient_registry_against_a_brute_force_model():
+    """The registry keeps the written intervals sorted and merged; against a byte map over 2000 random writes: 'fresh' exactly when no byte of the
+    region was written before."""
+    import random
+    import torch
+    from avt_amd import ops
+    ops.forget_zeroed()
+    buf = torch.zeros(4096)
+    ops.mark_zeroed(buf)
+    written = [False] * 4096
+    rng = random.Random(5)
+    base = buf.data_ptr()
+    for _ in range(2000):
+        if rng.random() < 0.02:
+            ops.mark_zeroed(buf)
+            written = [False] * 4096
+        cols = rng.choice([1, 2, 4, 8, 16])
+        rows = rng.randint(1, 8)
+        ld = cols * rng.choice([1, 1, 2])
+        start = rng.randint(0, 4096 - rows * ld)
+        view = torch.as_strided(buf, (rows, cols), (ld, 1), start)
+        lo, hi = start, start + (rows - 1) * ld + cols           # the region the kernel may touch: first to last element
+        want = not any(written[lo:hi])
+        assert ops._first_write(view, rows) == want
+        for i in range(lo, hi):
+            written[i] = True
+    los, his = ops._ZEROED[base][1]
+    assert los == sorted(los) and all(h <= l for h, l in zip(his[:-1], los[1:]))
+    ops.forget_zeroed()
